@@ -1,0 +1,131 @@
+/*
+ * mpcgpu.h -- C-ABI of the MI355X-native batched NLP solver for the receding-horizon optimisation of
+ *             TGoldC/Motion-Planning-for-Autonomous-Driving-with-MPC (MPC_Planner/optimizer.py).
+ *
+ * This is the drop-in boundary.  What each entry point replaces in the reference:
+ *
+ *   mpc_create / mpc_destroy ........ `ca.nlpsol('solver','ipopt', nlp_prob, opts_setting)`
+ *                                     (MPC_Planner/optimizer.py:513-560, rebuilt every step at :605) and
+ *                                     `model.generate_solver(options=codeoptions)` (optimizer.py:197-245).
+ *                                     The handle owns the device workspace; create it once, reuse it.
+ *   mpc_set_bounds .................. the `lbg, ubg, lbx, ubx` lists of `inequal_constraints()`
+ *                                     (optimizer.py:413-491) that the reference passes to every `sol(...)` call.
+ *   mpc_solve_batch ................. `res = sol(x0=init_control, p=c_p, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)`
+ *                                     (optimizer.py:607) for B independent instances at once; row b of x_out is
+ *                                     `res['x'].full().ravel()` of instance b (optimizer.py:609).
+ *                                     FORCESPRO twin: `solver.solve(problem)` (optimizer.py:326), C side
+ *                                     `FORCESNLPsolver_solve(params, output, info, fs, extfunc)`
+ *                                     (test/FORCESNLPsolver/include/FORCESNLPsolver.h:219); the status codes
+ *                                     below follow that header's exit codes (FORCESNLPsolver.h:68-106).
+ *   mpc_solve_batch_dev ............. same with device-resident buffers on a caller-supplied HIP stream
+ *                                     (no PCIe traffic; this is what bench.py times).
+ *   mpc_plant_step .................. `shift_movement` plant update `x0 + delta_t * f(x0, u[:,0])`
+ *                                     (optimizer.py:645-650) / `model.eq` RK4 step (optimizer.py:98,356).
+ *
+ * Conventions (modelled on FORCESNLPsolver.h:117-203): caller-owned plain buffers, int return codes, no
+ * exceptions, no callbacks, no globals; the library never keeps a host pointer past the call.
+ * Row layout of x0 / p / x_out is the reference's decision-vector order (optimizer.py:550,552):
+ *     [u_0(2) u_1(2) ... u_{N-1}(2) | x_0(nx) x_1(nx) ... x_N(nx)],   n_w = 2 N + nx (N + 1)
+ * All floating point is IEEE double.  A handle is not thread-safe: one handle per host thread / stream.
+ */
+#ifndef MPCGPU_H
+#define MPCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCGPU_ABI_VERSION 1
+
+/* per-instance numerical status (FORCESNLPsolver.h:68-106 semantics) */
+#define MPC_STATUS_CONVERGED   1    /* OPTIMAL: scaled KKT error <= tol                        */
+#define MPC_STATUS_MAXITER     0    /* MAXITREACHED                                            */
+#define MPC_STATUS_NAN        (-6)  /* BADFUNCEVAL: NaN/Inf met in a function evaluation       */
+#define MPC_STATUS_NOPROGRESS (-7)  /* NOPROGRESS: line search or regularisation gave up       */
+
+/* API return codes (0 = ok, negative = error; mpc_last_error() has the text) */
+#define MPC_OK                 0
+#define MPC_ERR_INVALID      (-1)   /* bad argument / unsupported problem shape                */
+#define MPC_ERR_HIP          (-2)   /* HIP runtime failure (no device, OOM, launch error)      */
+#define MPC_ERR_BOUNDS       (-3)   /* lbg/ubg do not have the structure of optimizer.py:421-469 */
+#define MPC_ERR_STATE        (-4)   /* call order (e.g. solve before set_bounds)               */
+
+/* formulation of the stage model */
+#define MPC_FORM_CASADI_EULER  0    /* CasadiOptimizer: forward Euler multiple shooting (optimizer.py:380-382) */
+
+typedef struct mpc_handle mpc_handle;
+
+typedef struct mpc_problem_desc {
+    int32_t N;             /* predict_horizon (optimizer.py:520); 1 <= N <= 127                          */
+    int32_t nx;            /* 5 = reference state [x, y, delta, v, psi]; 6 appends a decoupled progress
+                              state s (s' = v, no weight, unbounded) used by the synthetic benchmark      */
+    int32_t nu;            /* must be 2: [deltaDot, aLong]                                                */
+    int32_t formulation;   /* MPC_FORM_CASADI_EULER                                                       */
+    int32_t max_iter;      /* ipopt.max_iter = 100 (optimizer.py:556)                                     */
+    int32_t fixed_iters;   /* 0 = iterate to convergence; k > 0 = exactly k iterations (benchmark mode)   */
+    int32_t obst_mult;     /* 3: each of the 3 circle-pair distances is appended 3x (optimizer.py:395-403)*/
+    int32_t device;        /* HIP device ordinal                                                          */
+    double dt;             /* scenario.dt (optimizer.py:52)                                               */
+    double wheelbase;      /* p.a + p.b = 2.5789128 (configuration.py:362-363)                            */
+    double friction_div;   /* literal 2.578 of optimizer.py:378                                           */
+    double ego_offset;     /* centre offset of the front/rear ego circle, 0.75 (configuration.py:69-93)   */
+    double tol;            /* IPOPT tol, 1e-8                                                             */
+    double Q[8];           /* diag(weight_x, weight_y, weight_steering_angle, weight_velocity,
+                              weight_heading_angle[, 0]) (optimizer.py:500-502)                           */
+    double R[2];           /* diag(weight_velocity_steering_angle, weight_long_acceleration) (:503)       */
+    double P[8];           /* terminal weights (:504-505) -- built but unused by the CasADi cost (dead
+                              expression at :510); kept for the FORCES formulation                        */
+    double obstacle[6];    /* obstacle circle centres (x,y) x 3: centre, front, rear (optimizer.py:60-64) */
+} mpc_problem_desc;
+
+/* fills *desc with the reference defaults for horizon N and nx in {5,6} (ZAM_Over-1_1 lane-following
+ * weights, dummy obstacle at (-100,0)) */
+void mpc_default_desc(mpc_problem_desc* desc, int32_t N, int32_t nx);
+
+int mpc_create(mpc_handle** out, const mpc_problem_desc* desc);
+int mpc_destroy(mpc_handle* h);
+const char* mpc_last_error(const mpc_handle* h);   /* h may be NULL: error of the last failed mpc_create */
+
+/* lbx/ubx: n_w entries (optimizer.py:470-491), +-inf = absent.  lbg/ubg: n_g = 1 + nx(N+1) + 9(N+1) entries
+ * (optimizer.py:421-469): row 0 friction [lo, hi]; nx(N+1) equality rows (lbg == ubg); 9(N+1) obstacle rows,
+ * all with the same [lo, hi].  Anything else -> MPC_ERR_BOUNDS.  A friction lower bound <= 0 is implied by the
+ * absolute value in the row and gets no barrier.  Passing NULL for all four installs the reference defaults. */
+int mpc_set_bounds(mpc_handle* h, const double* lbx, const double* ubx, const double* lbg, const double* ubg);
+
+/* Host-buffer entry point.  x0, p, x_out: [B, n_w] row-major.  obst: [B, 6] per-instance obstacle circle
+ * centres or NULL (shared centres of the descriptor).  status/iters/kkt: [B], any may be NULL.            */
+int mpc_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst,
+                    double* x_out, int32_t* status, int32_t* iters, double* kkt);
+
+/* Device-buffer entry point: same arguments as device pointers, work enqueued on `stream` (a hipStream_t,
+ * NULL = default stream).  Returns after enqueueing + the convergence polls; the outputs are complete when
+ * the stream is synchronised (the call itself synchronises the stream unless fixed_iters > 0).            */
+int mpc_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst,
+                        double* d_x_out, int32_t* d_status, int32_t* d_iters, double* d_kkt, void* stream);
+
+/* Batched plant step on the device path: x_next = x + dt f(x,u) (integrator 0 = forward Euler,
+ * optimizer.py:649-650) or one RK4 step (integrator 1, optimizer.py:97-98).  x: [B, nx], u: [B, 2] host. */
+int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x, const double* u, double* x_next);
+
+/* ---- measurement helpers (bench.py / tests) ---------------------------------------------------------- */
+/* kernel timing of the LAST mpc_solve_batch[_dev] call, measured with HIP events on the solve stream when
+ * profiling is enabled: out[0] = total ms in the Riccati factor/solve kernel, out[1] = its launch count,
+ * out[2] = total ms in the stage (line-search/assemble) kernel, out[3] = its launch count,
+ * out[4] = ms in init + output kernels, out[5] = IPM iterations launched.                                 */
+int mpc_set_profiling(mpc_handle* h, int32_t enable);
+int mpc_get_profile(const mpc_handle* h, double out[6]);
+
+/* debugging: per-iteration per-instance scalars of a host solve.  trace: [max_iter+1, 8, B] doubles
+ * rows {mu, theta, phi, alpha, alpha_dual, delta_w, E0, n_trials}; returns iterations launched in *n_it. */
+int mpc_solve_batch_trace(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst,
+                          double* x_out, int32_t* status, int32_t* iters, double* kkt,
+                          double* trace, int32_t trace_rows, int32_t* n_it);
+
+int mpc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCGPU_H */

@@ -1,0 +1,16 @@
+"""
+MI355X-native batched NLP solver for the receding-horizon optimisation of
+TGoldC/Motion-Planning-for-Autonomous-Driving-with-MPC (MPC_Planner/optimizer.py).
+
+  solver.BatchedMPCSolver ....... owner of the C-ABI handle (include/mpcgpu.h -> csrc/libmpcgpu.so, HIP/gfx950)
+  optimizer.CasadiOptimizer ..... look-alike of the reference class (constructor, solver(), optimize())
+  optimizer.ForcesproOptimizer .. call-surface twin (solver.solve(problem))
+
+The directory name contains hyphens (it is fixed by the build contract); import it with
+`importlib.import_module("motion-planning-for-autonomous-driving-with-mpc_amd")` or through the `mpc_amd` shim
+at the repository root.
+"""
+from ._abi import MpcLibraryError, load_library  # noqa: F401
+from .solver import BatchedMPCSolver, MpcError, SolveResult  # noqa: F401
+from . import optimizer, sharding  # noqa: E402,F401
+from .optimizer import CasadiOptimizer, ForcesproOptimizer  # noqa: E402,F401

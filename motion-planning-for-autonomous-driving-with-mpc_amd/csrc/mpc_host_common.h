@@ -1,0 +1,172 @@
+// mpc_host_common.h -- host-side problem bookkeeping shared by the HIP library (mpcgpu.hip) and the CPU
+// emulation harness used by tests (tests/emu/emu.cpp): descriptor validation, parsing of the reference's
+// lbx/ubx/lbg/ubg lists (optimizer.py:413-491), IPOPT bound relaxation, workspace layout.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcgpu.h"
+#include "mpc_stage_math.h"
+
+namespace mpc {
+
+constexpr double BOUND_RELAX = 1e-8;   // IPOPT bound_relax_factor
+
+struct HostProblem {
+    mpc_problem_desc desc{};
+    std::vector<double> LB, UB;         // [(N+1)*NZ] relaxed, +-inf = absent
+    int has_fl = 0, has_fu = 0, has_ol = 0, has_ou = 0;
+    double fl = 0, fu = 0, ol = 0, ou = 0;
+    int n_mult = 0, n_z = 0;
+    bool bounds_set = false;
+    int NZ() const { return desc.nx + 2; }
+    size_t n_w() const { return (size_t)2 * desc.N + (size_t)desc.nx * (desc.N + 1); }
+    size_t n_g() const { return (size_t)1 + (size_t)desc.nx * (desc.N + 1) + (size_t)9 * (desc.N + 1); }
+};
+
+inline double relax_lo(double lo) { return std::isfinite(lo) ? lo - BOUND_RELAX * std::fmax(1.0, std::fabs(lo)) : -INFINITY; }
+inline double relax_hi(double hi) { return std::isfinite(hi) ? hi + BOUND_RELAX * std::fmax(1.0, std::fabs(hi)) : INFINITY; }
+
+inline int validate_desc(const mpc_problem_desc& d, std::string& err) {
+    char buf[256];
+    if (d.N < 1 || d.N > 127) { snprintf(buf, sizeof buf, "N=%d outside [1,127]", d.N); err = buf; return MPC_ERR_INVALID; }
+    if (d.nx != 5 && d.nx != 6) { snprintf(buf, sizeof buf, "nx=%d (supported: 5, 6)", d.nx); err = buf; return MPC_ERR_INVALID; }
+    if (d.nu != 2) { err = "nu must be 2"; return MPC_ERR_INVALID; }
+    if (d.formulation != MPC_FORM_CASADI_EULER) { err = "unsupported formulation"; return MPC_ERR_INVALID; }
+    if (!(d.dt > 0) || !(d.wheelbase > 0) || !(d.friction_div != 0) || !(d.tol > 0)) { err = "dt, wheelbase, tol must be > 0"; return MPC_ERR_INVALID; }
+    if (d.obst_mult < 1 || d.max_iter < 1 || d.fixed_iters < 0) { err = "obst_mult>=1, max_iter>=1, fixed_iters>=0 required"; return MPC_ERR_INVALID; }
+    return MPC_OK;
+}
+
+// reference defaults of inequal_constraints() for the vehicle-2 limits (optimizer.py:37-46, 421-491)
+inline void default_bounds(const mpc_problem_desc& d, std::vector<double>& lbx, std::vector<double>& ubx,
+                           std::vector<double>& lbg, std::vector<double>& ubg) {
+    const int N = d.N, nx = d.nx;
+    lbx.clear(); ubx.clear(); lbg.clear(); ubg.clear();
+    for (int k = 0; k < N; ++k) { lbx.push_back(-0.4); ubx.push_back(0.4); lbx.push_back(-INFINITY); ubx.push_back(11.5); }
+    for (int k = 0; k <= N; ++k) {
+        const double lo[6] = {-INFINITY, -INFINITY, -1.066, 0.0, -INFINITY, -INFINITY};
+        const double hi[6] = {INFINITY, INFINITY, 1.066, 50.8, INFINITY, INFINITY};
+        for (int i = 0; i < nx; ++i) { lbx.push_back(lo[i]); ubx.push_back(hi[i]); }
+    }
+    lbg.push_back(0.0); ubg.push_back(11.5);
+    for (int i = 0; i < nx * (N + 1); ++i) { lbg.push_back(0.0); ubg.push_back(0.0); }
+    // r_ego + r_obstacle with a zero-size dummy obstacle: 1.2000000000000002 (configuration.py:40-66)
+    for (int i = 0; i < 9 * (N + 1); ++i) { lbg.push_back(1.2000000000000002); ubg.push_back(INFINITY); }
+}
+
+inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, const double* lbg, const double* ubg, std::string& err) {
+    const mpc_problem_desc& d = hp.desc;
+    const int N = d.N, nx = d.nx, NZ = nx + 2;
+    std::vector<double> dlbx, dubx, dlbg, dubg;
+    if (!lbx && !ubx && !lbg && !ubg) {
+        default_bounds(d, dlbx, dubx, dlbg, dubg);
+        lbx = dlbx.data(); ubx = dubx.data(); lbg = dlbg.data(); ubg = dubg.data();
+    } else if (!lbx || !ubx || !lbg || !ubg) {
+        err = "lbx, ubx, lbg, ubg must be all given or all NULL";
+        return MPC_ERR_INVALID;
+    }
+    char buf[256];
+    hp.LB.assign((size_t)(N + 1) * NZ, -INFINITY);
+    hp.UB.assign((size_t)(N + 1) * NZ, INFINITY);
+    int nb = 0;
+    for (int k = 0; k <= N; ++k)
+        for (int i = 0; i < NZ; ++i) {
+            if (i < 2 && k == N) continue;
+            const size_t src = (i < 2) ? (size_t)2 * k + i : (size_t)2 * N + (size_t)nx * k + (i - 2);
+            const double lo = lbx[src], hi = ubx[src];
+            if (std::isnan(lo) || std::isnan(hi) || lo > hi) { snprintf(buf, sizeof buf, "lbx/ubx[%zu]: invalid pair", src); err = buf; return MPC_ERR_BOUNDS; }
+            if (lo == hi) { snprintf(buf, sizeof buf, "lbx == ubx at %zu: fixed variables are not supported", src); err = buf; return MPC_ERR_BOUNDS; }
+            hp.LB[(size_t)k * NZ + i] = relax_lo(lo);
+            hp.UB[(size_t)k * NZ + i] = relax_hi(hi);
+            nb += (int)std::isfinite(lo) + (int)std::isfinite(hi);
+        }
+    // g rows: [friction | nx(N+1) equalities | 9(N+1) obstacle rows]  (optimizer.py:421-469)
+    const double flo = lbg[0], fhi = ubg[0];
+    if (std::isnan(flo) || std::isnan(fhi) || !(flo < fhi)) { err = "friction row needs lbg[0] < ubg[0]"; return MPC_ERR_BOUNDS; }
+    for (int i = 0; i < nx * (N + 1); ++i)
+        if (!(lbg[1 + i] == 0.0 && ubg[1 + i] == 0.0)) { snprintf(buf, sizeof buf, "g row %d must be an equality with lbg = ubg = 0", 1 + i); err = buf; return MPC_ERR_BOUNDS; }
+    const size_t o0 = (size_t)1 + (size_t)nx * (N + 1);
+    const double olo = lbg[o0], ohi = ubg[o0];
+    for (int i = 0; i < 9 * (N + 1); ++i)
+        if (!(lbg[o0 + i] == olo && ubg[o0 + i] == ohi)) { err = "obstacle rows must share one [lbg, ubg] pair"; return MPC_ERR_BOUNDS; }
+    if (std::isnan(olo) || std::isnan(ohi) || !(olo < ohi)) { err = "obstacle rows need lbg < ubg"; return MPC_ERR_BOUNDS; }
+    hp.has_fl = std::isfinite(flo) && flo > 0.0;     // |y| >= lo with lo <= 0 is implied by the absolute value
+    hp.has_fu = std::isfinite(fhi);
+    hp.fl = relax_lo(flo); hp.fu = relax_hi(fhi);
+    hp.has_ol = std::isfinite(olo); hp.has_ou = std::isfinite(ohi);
+    hp.ol = relax_lo(olo); hp.ou = relax_hi(ohi);
+    const int m = d.obst_mult;
+    hp.n_mult = nx * (N + 1) + 3 * m * (N + 1) + 1;
+    hp.n_z = nb + 3 * m * (N + 1) * (hp.has_ol + hp.has_ou) + hp.has_fl + hp.has_fu;
+    hp.bounds_set = true;
+    return MPC_OK;
+}
+
+// ---- workspace: one allocation of doubles + one of int32 -------------------------------------------------
+struct WsLayout {
+    size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, EV, ROLL, SC, FILT, OBST, total;
+    size_t itotal;
+};
+
+inline WsLayout ws_layout(int N, int nx, size_t Bp) {
+    const size_t NZ = nx + 2, NS = (size_t)nx * (nx + 1) / 2, S = N + 1;
+    const size_t NBLK = NS + 10 + 2 * nx, NPK = NS + nx, NKK = 2 * nx + 2;
+    WsLayout w{};
+    size_t off = 0;
+    auto take = [&](size_t rows) { const size_t o = off; off += rows * Bp; return o; };
+    w.Z = take(S * NZ); w.ZL = take(S * NZ); w.ZU = take(S * NZ);
+    w.SO = take(S * 3); w.NUO = take(S * 3); w.ZLO = take(S * 3); w.ZUO = take(S * 3);
+    w.LAM = take(S * nx); w.REF = take(S * nx); w.DZ = take(S * NZ);
+    w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.EV = take(S * 12); w.ROLL = take(S * nx);
+    w.SC = take(SC_COUNT); w.FILT = take(2 * FILTER_MAX); w.OBST = take(6);
+    w.total = off;
+    w.itotal = (size_t)IS_COUNT * Bp;
+    return w;
+}
+
+inline int pick_bx(int N, int max_threads) {
+    int bx = 64;
+    while (bx > 8 && bx * (N + 1) > max_threads) bx >>= 1;
+    return bx;
+}
+
+inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int bx, double* base, int32_t* ibase,
+                        const double* dLB, const double* dUB) {
+    const mpc_problem_desc& d = hp.desc;
+    const WsLayout w = ws_layout(d.N, d.nx, Bp);
+    P.B = B; P.Bp = (int32_t)Bp; P.N = d.N; P.nx = d.nx; P.bx = bx;
+    P.obst_mult = d.obst_mult; P.max_iter = d.max_iter; P.fixed_iters = d.fixed_iters;
+    P.has_fl = hp.has_fl; P.has_fu = hp.has_fu; P.has_ol = hp.has_ol; P.has_ou = hp.has_ou; P.per_inst_obst = 0;
+    P.dt = d.dt; P.wheelbase = d.wheelbase; P.friction_div = d.friction_div; P.ego_offset = d.ego_offset; P.tol = d.tol;
+    for (int i = 0; i < 6; ++i) P.Q[i] = (i < d.nx) ? d.Q[i] : 0.0;
+    P.R[0] = d.R[0]; P.R[1] = d.R[1];
+    for (int i = 0; i < 6; ++i) P.obst[i] = d.obstacle[i];
+    P.fl = hp.fl; P.fu = hp.fu; P.ol = hp.ol; P.ou = hp.ou;
+    P.x0 = nullptr; P.p = nullptr; P.LB = dLB; P.UB = dUB;
+    P.Z = base + w.Z; P.ZL = base + w.ZL; P.ZU = base + w.ZU;
+    P.SO = base + w.SO; P.NUO = base + w.NUO; P.ZLO = base + w.ZLO; P.ZUO = base + w.ZUO;
+    P.LAM = base + w.LAM; P.REF = base + w.REF; P.DZ = base + w.DZ; P.PK = base + w.PK; P.KK = base + w.KK;
+    P.BLK = base + w.BLK; P.EV = base + w.EV; P.ROLL = base + w.ROLL; P.SC = base + w.SC; P.FILT = base + w.FILT; P.OBST = base + w.OBST;
+    P.ISC = ibase;
+    P.x_out = nullptr; P.status_out = nullptr; P.iters_out = nullptr; P.kkt_out = nullptr;
+}
+
+inline void default_desc(mpc_problem_desc* d, int32_t N, int32_t nx) {
+    *d = mpc_problem_desc{};
+    d->N = N; d->nx = nx; d->nu = 2; d->formulation = MPC_FORM_CASADI_EULER;
+    d->max_iter = 100; d->fixed_iters = 0; d->obst_mult = 3; d->device = 0;
+    d->dt = 0.1; d->wheelbase = 2.5789128; d->friction_div = 2.578; d->ego_offset = 0.75; d->tol = 1e-8;
+    const double Q[5] = {2.3, 2.3, 500.0, 0.1, 10.0};          // config_LF_ZAM_Over-1_1.yaml:20-24
+    for (int i = 0; i < 5; ++i) d->Q[i] = Q[i];
+    d->R[0] = 2.0; d->R[1] = 0.2;                               // config_LF_ZAM_Over-1_1.yaml:25-26
+    const double Pt[5] = {80.0, 80.0, 100.0, 0.1, 100.0};       // config_LF_ZAM_Over-1_1.yaml:27-31
+    for (int i = 0; i < 5; ++i) d->P[i] = Pt[i];
+    for (int j = 0; j < 3; ++j) { d->obstacle[2 * j] = -100.0; d->obstacle[2 * j + 1] = 0.0; }   // configuration.py:471-483
+}
+
+}  // namespace mpc

@@ -1,0 +1,1253 @@
+// mpc_stage_math.h -- per-thread math of the batched interior-point solver (product code).
+//
+// Every function here is the body of one *phase* of a HIP kernel for ONE thread, written as
+// `__host__ __device__` so that the very same source is (a) inlined into the gfx950 kernels of
+// mpc_kernels.hip and (b) stepped thread-by-thread by the CPU emulation harness used in tests
+// (tests/emu/), which exists because the build container has no GPU.  The emulation harness is test
+// infrastructure only; the shipped library (libmpcgpu.so) contains no CPU solve path.
+//
+// Problem solved (reference: MPC_Planner/optimizer.py, CasadiOptimizer):
+//   decision vector / parameters ........ optimizer.py:550,552
+//   cost ................................. optimizer.py:507-511
+//   constraints g ........................ optimizer.py:378-403   (friction | x0 pin | Euler defects | obstacle)
+//   bounds ............................... optimizer.py:421-491
+//   ODE .................................. configuration.py:353-368
+//   circle geometry ...................... configuration.py:69-93
+//   the call being replaced .............. optimizer.py:607   sol(x0=,p=,lbg=,lbx=,ubg=,ubx=)
+//
+// Data layout in HBM: structure-of-arrays, `row * Bp + b` with the instance index b fastest, so that a
+// wavefront working on 64 (or 32/16) consecutive instances of one horizon stage reads 512 (256/128)
+// contiguous bytes per field.  Rows are (stage k, component i) pairs; see the *_ROW helpers.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPC_HD __host__ __device__ __forceinline__
+#else
+#define MPC_HD inline
+#endif
+
+namespace mpc {
+
+// ---- IPOPT default constants (Waechter & Biegler 2006) -------------------------------------------------
+constexpr double MU_INIT = 0.1, KAPPA_EPS = 10.0, KAPPA_MU = 0.2, THETA_MU = 1.5, TAU_MIN = 0.99;
+constexpr double KAPPA_1 = 1e-2, KAPPA_2 = 1e-2, S_MAX = 100.0, KAPPA_SIGMA = 1e10;
+constexpr double GAMMA_THETA = 1e-5, GAMMA_PHI = 1e-8, LS_DELTA = 1.0, S_THETA = 1.1, S_PHI = 2.3;
+constexpr double ETA_PHI = 1e-8, GAMMA_ALPHA = 0.05;
+constexpr double DW_MIN = 1e-20, DW_0 = 1e-4, DW_MAX = 1e40, KW_MINUS = 1.0 / 3.0, KW_PLUS = 8.0, KW_PLUS_BAR = 100.0;
+constexpr double SCALING_MAX_GRAD = 100.0;
+constexpr int FILTER_MAX = 32;
+constexpr int ST_RUNNING = 99;          // internal status while iterating
+constexpr double BIG = 1e300;
+constexpr double ROLLOUT_FACTOR = 10.0;   // start-point safeguard, see prestart_instance()
+
+// ---- per-instance scalar rows ----------------------------------------------------------------------------
+enum ScRow {
+    SC_MU = 0, SC_TAU, SC_DF, SC_THETA, SC_FCOST, SC_LOGSUM, SC_THMAX, SC_THMIN, SC_DLAST, SC_DELTA, SC_E0,
+    SC_SF, SC_NUF, SC_ZLF, SC_ZUF, SC_DFRIC, SC_GFR0, SC_GFR1, SC_GFR2, SC_HUX0, SC_HUX1,
+    SC_C0,                       // 6 rows: c_0 = x_0 - r_0
+    SC_ALPHA = SC_C0 + 6, SC_ADU, SC_PHI, SC_NTRIAL,
+    SC_COUNT
+};
+enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_COUNT };
+
+struct Params {
+    int32_t B, Bp, N, nx, bx;    // instances, padded instances (multiple of 64), horizon, states, instances/block
+    int32_t obst_mult, max_iter, fixed_iters;
+    int32_t has_fl, has_fu, has_ol, has_ou, per_inst_obst;
+    double dt, wheelbase, friction_div, ego_offset, tol;
+    double Q[6], R[2], obst[6];
+    double fl, fu, ol, ou;       // relaxed slack bounds of the friction / obstacle rows
+    const double* x0;            // [B][n_w] row-major (ABI input)
+    const double* p;             // [B][n_w] row-major (ABI input)
+    const double* LB;            // [(N+1)*NZ] relaxed variable bounds, -inf = absent
+    const double* UB;
+    double *Z, *ZL, *ZU;         // [(N+1)*NZ][Bp]   iterate (u|x per stage) and its bound multipliers
+    double *SO, *NUO, *ZLO, *ZUO;  // [(N+1)*3][Bp]  obstacle slacks, row multipliers, slack-bound multipliers
+    double *LAM;                 // [(N+1)*NX][Bp]   equality multipliers (stage 0: x_0 pin, k>=1: defect k-1 -> k)
+    double *REF;                 // [(N+1)*NX][Bp]   X_ref
+    double *DZ;                  // [(N+1)*NZ][Bp]   Newton step from the Riccati sweep
+    double *PK;                  // [(N+1)*(NS+NX)][Bp]  cost-to-go P_k (upper triangle) and p_k
+    double *KK;                  // [N*(2*NX+2)][Bp]     feedback gains K_k, k_k
+    double *BLK;                 // [(N+1)*NBLK][Bp]     condensed stage blocks consumed by the Riccati sweep
+    double *EV;                  // [(N+1)*12][Bp]       circle distances (3) and their Jacobians (9) at the iterate
+    double *ROLL;                // [(N+1)*NX][Bp]       dynamics rollout of the warm-start controls (start-point safeguard)
+    double *SC;                  // [SC_COUNT][Bp]
+    double *FILT;                // [2*FILTER_MAX][Bp]
+    const double* OBST;          // [6][Bp] per-instance obstacle centres (optional)
+    int32_t* ISC;                // [IS_COUNT][Bp]
+    double* x_out;               // [B][n_w] row-major (ABI output)
+    int32_t* status_out;
+    int32_t* iters_out;
+    double* kkt_out;
+};
+
+template <int NX>
+struct Dim {
+    static constexpr int NU = 2;
+    static constexpr int NZ = NX + 2;
+    static constexpr int NS = NX * (NX + 1) / 2;
+    // BLK rows per stage
+    static constexpr int B_H = 0, B_RUU = NS, B_A = NS + 2, B_GX = NS + 8, B_GU = NS + 8 + NX, B_CN = NS + 10 + NX;
+    static constexpr int NBLK = NS + 10 + 2 * NX;
+    static constexpr int NPK = NS + NX;
+    static constexpr int NKK = 2 * NX + 2;
+    static constexpr int NEV = 12;
+    MPC_HD static constexpr int sidx(int i, int j) { return i * NX - i * (i - 1) / 2 + (j - i); }   // i <= j
+};
+
+// ---- reductions over the stages of one instance ---------------------------------------------------------
+struct Red0 { double gmax; };
+struct Red1 { double a_pr, a_du, dphi; };
+struct Red2 { double theta, fcost, logsum, bad; };
+struct Red3 { double dual_inf, prim_inf, cmin, cmax, sum_mult, sum_z, theta, fcost, logsum, nan; };
+
+MPC_HD Red0 red_neutral0() { return Red0{0.0}; }
+MPC_HD Red1 red_neutral1() { return Red1{1.0, 1.0, 0.0}; }
+MPC_HD Red2 red_neutral2() { return Red2{0.0, 0.0, 0.0, 0.0}; }
+MPC_HD Red3 red_neutral3() { return Red3{0.0, 0.0, BIG, -BIG, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
+MPC_HD void red_combine(Red0& a, const Red0& b) { a.gmax = fmax(a.gmax, b.gmax); }
+MPC_HD void red_combine(Red1& a, const Red1& b) { a.a_pr = fmin(a.a_pr, b.a_pr); a.a_du = fmin(a.a_du, b.a_du); a.dphi += b.dphi; }
+MPC_HD void red_combine(Red2& a, const Red2& b) { a.theta += b.theta; a.fcost += b.fcost; a.logsum += b.logsum; a.bad = fmax(a.bad, b.bad); }
+MPC_HD void red_combine(Red3& a, const Red3& b) {
+    a.dual_inf = fmax(a.dual_inf, b.dual_inf); a.prim_inf = fmax(a.prim_inf, b.prim_inf);
+    a.cmin = fmin(a.cmin, b.cmin); a.cmax = fmax(a.cmax, b.cmax);
+    a.sum_mult += b.sum_mult; a.sum_z += b.sum_z; a.theta += b.theta; a.fcost += b.fcost; a.logsum += b.logsum;
+    a.nan = fmax(a.nan, b.nan);
+}
+
+// ---- small helpers -----------------------------------------------------------------------------------------
+MPC_HD bool has_lo(double lb) { return lb > -BIG; }
+MPC_HD bool has_hi(double ub) { return ub < BIG; }
+
+MPC_HD double push_in(double v, double lo, double hi) {
+    const bool hl = has_lo(lo), hu = has_hi(hi);
+    if (hl && hu) {
+        const double pl = fmin(KAPPA_1 * fmax(1.0, fabs(lo)), KAPPA_2 * (hi - lo));
+        const double pu = fmin(KAPPA_1 * fmax(1.0, fabs(hi)), KAPPA_2 * (hi - lo));
+        v = fmax(v, lo + pl);
+        v = fmin(v, hi - pu);
+    } else if (hl) {
+        v = fmax(v, lo + KAPPA_1 * fmax(1.0, fabs(lo)));
+    } else if (hu) {
+        v = fmin(v, hi - KAPPA_1 * fmax(1.0, fabs(hi)));
+    }
+    return v;
+}
+
+MPC_HD double zreset(double z, double gap, double mu) {
+    const double lo = mu / (KAPPA_SIGMA * gap), hi = KAPPA_SIGMA * mu / gap;
+    return fmin(fmax(z, lo), hi);
+}
+
+// per-thread context kept in registers across the phases of the stage kernel
+template <int NX>
+struct Ctx {
+    static constexpr int NZ = NX + 2;
+    int b, k;
+    bool valid;      // b < B and k <= N
+    bool active;     // valid and instance still iterating
+    // --- iterate pieces live across the line search
+    double z[NZ], dz[NZ];
+    double xn[NX], dxn[NX];          // x_{k+1} and its step (k < N)
+    double rn[NX];                   // r_{k+1} (k < N)
+    double so[3], dso[3];
+    double sf, dsf;                  // friction slack (k == 0)
+    double zt[NZ], sot[3], sft;      // current / accepted trial point
+    double obst[6];
+    // --- per-instance scalars (every thread of the instance holds the same values)
+    double mu, tau, df, theta, phi, thmax, thmin;
+    double a_pr, a_du, dphi, alpha, a_min;
+    int nfilt, ntrial, iters, status;
+    bool searching, accepted, ftype;
+    bool conv;       // fixed-iteration (benchmark) mode: tolerance already reached, steps are accepted as they come
+    // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
+    double gxa[NX], gxb[NX], gua[2], gub[2];
+};
+
+#define MPC_AT(ptr, row) (ptr)[(size_t)(row) * (size_t)P.Bp + (size_t)c.b]
+
+// ---- model pieces ----------------------------------------------------------------------------------------
+// kinematic single-track ODE, configuration.py:353-368
+template <int NX>
+MPC_HD void ode_eval(const Params& P, const double* x, const double* u, double* f, double& sps, double& cps, double& td) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x[4], &sps, &cps);
+#else
+    sps = sin(x[4]); cps = cos(x[4]);
+#endif
+    td = tan(x[2]);
+    f[0] = x[3] * cps;
+    f[1] = x[3] * sps;
+    f[2] = u[0];
+    f[3] = u[1];
+    f[4] = x[3] / P.wheelbase * td;
+    if (NX == 6) f[5] = x[3];
+}
+
+// circle distances of the pairs (0,0),(1,1),(2,2) (optimizer.py:395-403), optionally Jacobian wrt (sx,sy,psi)
+// and the 6 distinct Hessian entries per pair: order (00,01,02,11,12,22)
+MPC_HD void obstacle_eval(const Params& P, const double* obst, double sx, double sy, double sps, double cps,
+                          double dist[3], double J[9], double H[18], bool derivs) {
+    const double rho = P.ego_offset;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double sg = (j == 0) ? 0.0 : (j == 1 ? 1.0 : -1.0);
+        const double cx = sx + sg * rho * cps - obst[2 * j];
+        const double cy = sy + sg * rho * sps - obst[2 * j + 1];
+        const double r = sqrt(cx * cx + cy * cy);
+        dist[j] = r;
+        if (!derivs) continue;
+        const double ir = 1.0 / r;
+        const double ex = cx * ir, ey = cy * ir;
+        const double tx = -sg * rho * sps, ty = sg * rho * cps;
+        J[3 * j + 0] = ex;
+        J[3 * j + 1] = ey;
+        J[3 * j + 2] = ex * tx + ey * ty;
+        const double m00 = (1 - ex * ex) * ir, m01 = -ex * ey * ir, m11 = (1 - ey * ey) * ir;
+        const double mt0 = m00 * tx + m01 * ty, mt1 = m01 * tx + m11 * ty;
+        const double nxx = -sg * rho * cps, nyy = -sg * rho * sps;
+        H[6 * j + 0] = m00; H[6 * j + 1] = m01; H[6 * j + 2] = mt0;
+        H[6 * j + 3] = m11; H[6 * j + 4] = mt1;
+        H[6 * j + 5] = tx * mt0 + ty * mt1 + ex * nxx + ey * nyy;
+    }
+}
+
+// friction row optimizer.py:378: sqrt((a^2 + v*(tan(delta)*v/2.578))^2) = |y|; d|y| = sign(y) dy, sign(0) = 0.
+// g: derivative wrt (a, delta, v); h: (aa, dd, dv, vv) second derivatives
+MPC_HD double friction_eval(const Params& P, double a, double dl, double v, double g[3], double h[4], bool derivs) {
+    const double kap = P.friction_div;
+    const double td = tan(dl);
+    const double y = a * a + v * (td * v / kap);
+    if (derivs) {
+        const double cd = cos(dl), icd2 = 1.0 / (cd * cd);
+        const double sg = (y > 0.0) ? 1.0 : ((y < 0.0) ? -1.0 : 0.0);
+        g[0] = sg * 2 * a;
+        g[1] = sg * v * v * icd2 / kap;
+        g[2] = sg * 2 * v * td / kap;
+        h[0] = sg * 2.0;
+        h[1] = sg * 2 * v * v * td * icd2 / kap;
+        h[2] = sg * 2 * v * icd2 / kap;
+        h[3] = sg * 2 * td / kap;
+    }
+    return fabs(y);
+}
+
+template <int NX>
+MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.obst[i] = P.per_inst_obst ? MPC_AT(P.OBST, i) : P.obst[i];
+}
+
+// =========================================================================================================
+// Start-point safeguard (one instance per thread, before the init kernel).
+// The caller's x0 is IPOPT's starting point in the reference (optimizer.py:602,607).  The reference's very first
+// MPC step hands over a state guess in a transposed layout whose dynamics defects are of
+// the order of 1e3; from such a point an interior-point method jams against the steering-rate bounds.  When
+// the defect of the given state guess exceeds ROLLOUT_FACTOR * max(1, defect of a forward rollout of the
+// (bound-projected) control guess), the state guess is replaced by that rollout.  The optimum the solver
+// converges to is a KKT point of the same NLP either way.
+// =========================================================================================================
+template <int NX>
+MPC_HD void prestart_instance(const Params& P, int b) {
+    constexpr int NZ = NX + 2;
+    const int N = P.N;
+    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
+    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+    const double* x0b = P.x0 + bb * nw;
+    const double* pb = P.p + bb * nw;
+    double xg[NX], xr[NX], f[NX], u[2], s, c, td;
+    double th_g = 0.0, th_r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const double r0 = pb[2 * N + i];
+        xg[i] = push_in(x0b[2 * N + i], P.LB[2 + i], P.UB[2 + i]);
+        xr[i] = push_in(r0, P.LB[2 + i], P.UB[2 + i]);
+        th_g += fabs(xg[i] - r0);
+        th_r += fabs(xr[i] - r0);
+        P.ROLL[(size_t)i * Bp + bb] = xr[i];
+    }
+    for (int k = 0; k < N; ++k) {
+        u[0] = push_in(x0b[2 * k], P.LB[k * NZ], P.UB[k * NZ]);
+        u[1] = push_in(x0b[2 * k + 1], P.LB[k * NZ + 1], P.UB[k * NZ + 1]);
+        double fr[NX];
+        ode_eval<NX>(P, xg, u, f, s, c, td);
+        ode_eval<NX>(P, xr, u, fr, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double lb = P.LB[(k + 1) * NZ + 2 + i], ub = P.UB[(k + 1) * NZ + 2 + i];
+            const double gn = push_in(x0b[2 * N + NX * (k + 1) + i], lb, ub);
+            th_g += fabs(gn - (f[i] * P.dt + xg[i]));
+            xg[i] = gn;
+            const double rraw = fr[i] * P.dt + xr[i];
+            const double rn = push_in(rraw, lb, ub);
+            th_r += fabs(rn - rraw);
+            xr[i] = rn;
+            P.ROLL[((size_t)(k + 1) * NX + i) * Bp + bb] = rn;
+        }
+    }
+    const bool use = !(th_g <= ROLLOUT_FACTOR * fmax(1.0, th_r));      // also true when th_g is NaN
+    P.ISC[(size_t)IS_ROLL * Bp + bb] = use ? 1 : 0;
+}
+
+// =========================================================================================================
+// Phase 0 (init kernel only): build the start iterate from the caller's x0 (IPOPT section 3.6)
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    red = red_neutral0();
+    if (!c.valid) return;
+    const int N = P.N, k = c.k;
+    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+    const double* x0b = P.x0 + (size_t)c.b * nw;
+    const double* pb = P.p + (size_t)c.b * nw;
+    load_obst(P, c);
+    const bool roll = MPC_AT(P.ISC, IS_ROLL) != 0;
+    double gmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        double raw = 0.0, lb = -INFINITY, ub = INFINITY;
+        if (!(isu && k == N)) {
+            raw = isu ? x0b[2 * k + i] : (roll ? MPC_AT(P.ROLL, k * NX + (i - 2)) : x0b[2 * N + NX * k + (i - 2)]);
+            lb = P.LB[k * NZ + i];
+            ub = P.UB[k * NZ + i];
+        }
+        if (k < N) {
+            // |grad f| at the user's start point (objective scaling, IPOPT section 3.8)
+            const double g = isu ? 2 * P.R[i] * raw : 2 * P.Q[i - 2] * (raw - pb[2 * N + NX * (k + 1) + (i - 2)]);
+            gmax = fmax(gmax, fabs(g));
+        }
+        const double v = push_in(raw, lb, ub);
+        c.z[i] = v;
+        MPC_AT(P.Z, k * NZ + i) = v;
+        MPC_AT(P.ZL, k * NZ + i) = has_lo(lb) ? 1.0 : 0.0;
+        MPC_AT(P.ZU, k * NZ + i) = has_hi(ub) ? 1.0 : 0.0;
+        MPC_AT(P.DZ, k * NZ + i) = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        MPC_AT(P.REF, k * NX + i) = pb[2 * N + NX * k + i];
+        MPC_AT(P.LAM, k * NX + i) = 0.0;
+    }
+    // slacks: s = d(w0) pushed inside its bounds
+    double sps, cps;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(c.z[2 + 4], &sps, &cps);
+#else
+    sps = sin(c.z[2 + 4]); cps = cos(c.z[2 + 4]);
+#endif
+    double dist[3];
+    obstacle_eval(P, c.obst, c.z[2], c.z[3], sps, cps, dist, nullptr, nullptr, false);
+    const double ol = P.has_ol ? P.ol : -INFINITY, ou = P.has_ou ? P.ou : INFINITY;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        c.so[j] = push_in(dist[j], ol, ou);
+        MPC_AT(P.SO, k * 3 + j) = c.so[j];
+        MPC_AT(P.NUO, k * 3 + j) = 0.0;
+        MPC_AT(P.ZLO, k * 3 + j) = P.has_ol ? 1.0 : 0.0;
+        MPC_AT(P.ZUO, k * 3 + j) = P.has_ou ? 1.0 : 0.0;
+    }
+    if (k == 0) {
+        const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
+        const double dfr = friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false);
+        c.sf = push_in(dfr, fl, fu);
+        MPC_AT(P.SC, SC_SF) = c.sf;
+        MPC_AT(P.SC, SC_NUF) = 0.0;
+        MPC_AT(P.SC, SC_ZLF) = P.has_fl ? 1.0 : 0.0;
+        MPC_AT(P.SC, SC_ZUF) = P.has_fu ? 1.0 : 0.0;
+    }
+    red.gmax = gmax;
+}
+
+template <int NX>
+MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
+    if (!c.valid) return;
+    c.df = red.gmax > SCALING_MAX_GRAD ? SCALING_MAX_GRAD / red.gmax : 1.0;
+    c.mu = MU_INIT;
+    c.tau = fmax(TAU_MIN, 1.0 - c.mu);
+    c.nfilt = 0;
+    c.iters = 0;
+    c.status = ST_RUNNING;
+    c.active = true;
+    c.conv = false;
+    c.thmax = 0.0;
+    c.thmin = 0.0;
+    if (c.k == 0) {
+        MPC_AT(P.SC, SC_DF) = c.df;
+        MPC_AT(P.SC, SC_DLAST) = 0.0;
+        MPC_AT(P.SC, SC_DELTA) = 0.0;
+        MPC_AT(P.SC, SC_THMAX) = 0.0;
+        MPC_AT(P.SC, SC_THMIN) = 0.0;
+        MPC_AT(P.SC, SC_ALPHA) = 0.0;
+        MPC_AT(P.SC, SC_ADU) = 0.0;
+        MPC_AT(P.SC, SC_PHI) = 0.0;
+        MPC_AT(P.SC, SC_NTRIAL) = 0.0;
+        MPC_AT(P.ISC, IS_NFILT) = 0;
+        MPC_AT(P.ISC, IS_HAVETH0) = 0;
+        MPC_AT(P.ISC, IS_CONV) = 0;
+        MPC_AT(P.ISC, IS_ITERS) = 0;
+    }
+}
+
+// =========================================================================================================
+// Phase 1: load the Newton step, slack/dual steps, fraction-to-the-boundary candidates, d(phi)
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
+    c.status = c.valid ? MPC_AT(P.ISC, IS_STATUS) : 0;
+    c.active = c.valid && c.status == ST_RUNNING;
+    if (!c.active) return;
+    c.mu = MPC_AT(P.SC, SC_MU);
+    c.tau = MPC_AT(P.SC, SC_TAU);
+    c.df = MPC_AT(P.SC, SC_DF);
+    c.theta = MPC_AT(P.SC, SC_THETA);
+    c.phi = c.df * MPC_AT(P.SC, SC_FCOST) - c.mu * MPC_AT(P.SC, SC_LOGSUM);
+    c.thmax = MPC_AT(P.SC, SC_THMAX);
+    c.thmin = MPC_AT(P.SC, SC_THMIN);
+    c.nfilt = MPC_AT(P.ISC, IS_NFILT);
+    c.iters = MPC_AT(P.ISC, IS_ITERS);
+    c.conv = P.fixed_iters > 0 && MPC_AT(P.ISC, IS_CONV) != 0;
+    if (!MPC_AT(P.ISC, IS_HAVETH0)) {      // first iteration: theta_max / theta_min from theta(w_0)
+        c.thmax = 1e4 * fmax(1.0, c.theta);
+        c.thmin = 1e-4 * fmax(1.0, c.theta);
+    }
+}
+
+template <int NX>
+MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    red = red_neutral1();
+    if (!c.active) return;
+    const int N = P.N, k = c.k, m = P.obst_mult;
+    const double mu = c.mu, tau = c.tau;
+    double a_pr = 1.0, a_du = 1.0, dphi = 0.0;
+    load_obst(P, c);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) c.rn[i] = (k < N) ? MPC_AT(P.REF, (k + 1) * NX + i) : 0.0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        const double zi = MPC_AT(P.Z, k * NZ + i);
+        const double dv = MPC_AT(P.DZ, k * NZ + i);
+        c.z[i] = zi;
+        c.dz[i] = dv;
+        if (isu && k == N) continue;
+        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        double gradf = 0.0;
+        if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
+        double gb = 0.0;
+        if (has_lo(lb)) {
+            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            const double dzl = mu / gap - zl - zl / gap * dv;
+            gb -= mu / gap;
+            if (dv < 0) a_pr = fmin(a_pr, -tau * gap / dv);
+            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
+        }
+        if (has_hi(ub)) {
+            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            const double dzu = mu / gap - zu + zu / gap * dv;
+            gb += mu / gap;
+            if (dv > 0) a_pr = fmin(a_pr, tau * gap / dv);
+            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
+        }
+        dphi += (gradf + gb) * dv;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        c.xn[i] = (k < N) ? MPC_AT(P.Z, (k + 1) * NZ + 2 + i) : 0.0;
+        c.dxn[i] = (k < N) ? MPC_AT(P.DZ, (k + 1) * NZ + 2 + i) : 0.0;
+    }
+    // obstacle slacks: ds = J dx + (d - s)
+    const int oi[3] = {0, 1, 4};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = MPC_AT(P.SO, k * 3 + j);
+        double ds = MPC_AT(P.EV, k * D::NEV + j) - s;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ds += MPC_AT(P.EV, k * D::NEV + 3 + 3 * j + a) * c.dz[2 + oi[a]];
+        c.so[j] = s;
+        c.dso[j] = ds;
+        double gb = 0.0;
+        if (P.has_ol) {
+            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            const double dzl = mu / gap - zl - zl / gap * ds;
+            gb -= mu / gap;
+            if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
+            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
+        }
+        if (P.has_ou) {
+            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            const double dzu = mu / gap - zu + zu / gap * ds;
+            gb += mu / gap;
+            if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
+            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
+        }
+        dphi += m * gb * ds;
+    }
+    c.sf = 0.0;
+    c.dsf = 0.0;
+    if (k == 0) {
+        const double s = MPC_AT(P.SC, SC_SF);
+        const double ds = MPC_AT(P.SC, SC_DFRIC) - s + MPC_AT(P.SC, SC_GFR0) * c.dz[1] + MPC_AT(P.SC, SC_GFR1) * c.dz[2 + 2] +
+                          MPC_AT(P.SC, SC_GFR2) * c.dz[2 + 3];
+        c.sf = s;
+        c.dsf = ds;
+        double gb = 0.0;
+        if (P.has_fl) {
+            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            const double dzl = mu / gap - zl - zl / gap * ds;
+            gb -= mu / gap;
+            if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
+            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
+        }
+        if (P.has_fu) {
+            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            const double dzu = mu / gap - zu + zu / gap * ds;
+            gb += mu / gap;
+            if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
+            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
+        }
+        dphi += gb * ds;
+    }
+    red.a_pr = a_pr;
+    red.a_du = a_du;
+    red.dphi = dphi;
+}
+
+// after the reduction: start of the filter line search (Waechter & Biegler section 2.3, eq. (23) for alpha_min)
+template <int NX>
+MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red) {
+    c.searching = false;
+    c.accepted = false;
+    c.ftype = false;
+    c.ntrial = 0;
+    if (!c.active) return;
+    c.a_pr = red.a_pr;
+    c.a_du = red.a_du;
+    c.dphi = red.dphi;
+    double a_min;
+    if (c.dphi < 0 && c.theta <= c.thmin)
+        a_min = fmin(fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi)), LS_DELTA * pow(c.theta, S_THETA) / pow(-c.dphi, S_PHI));
+    else if (c.dphi < 0)
+        a_min = fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi));
+    else
+        a_min = GAMMA_THETA;
+    c.a_min = c.conv ? 0.0 : a_min * GAMMA_ALPHA;
+    c.alpha = c.a_pr;
+    c.searching = c.alpha >= c.a_min;
+    if (!c.searching) c.status = -7;       // no admissible step length at all
+}
+
+// =========================================================================================================
+// Phase 2: evaluate constraint violation / barrier objective at the trial point w + alpha dw
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    red = red_neutral2();
+    if (!(c.active && c.searching)) return;
+    const int N = P.N, k = c.k, m = P.obst_mult;
+    const double al = c.alpha;
+    double theta = 0.0, fc = 0.0, ls = 0.0, bad = 0.0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        const double v = c.z[i] + al * c.dz[i];
+        c.zt[i] = v;
+        if (isu && k == N) continue;
+        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+        if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+        if (k < N) {
+            if (isu) fc += P.R[i] * v * v;
+            else { const double e = v - c.rn[i - 2]; fc += P.Q[i - 2] * e * e; }
+        }
+    }
+    double f[NX], sps, cps, td;
+    ode_eval<NX>(P, c.zt + 2, c.zt, f, sps, cps, td);
+    if (k < N) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xnt = c.xn[i] + al * c.dxn[i];
+            theta += fabs(xnt - (f[i] * P.dt + c.zt[2 + i]));
+        }
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - MPC_AT(P.REF, i));
+    }
+    double dist[3];
+    obstacle_eval(P, c.obst, c.zt[2], c.zt[3], sps, cps, dist, nullptr, nullptr, false);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = c.so[j] + al * c.dso[j];
+        c.sot[j] = s;
+        theta += m * fabs(dist[j] - s);
+        if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
+        if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
+    }
+    if (k == 0) {
+        const double s = c.sf + al * c.dsf;
+        c.sft = s;
+        const double dfr = friction_eval(P, c.zt[1], c.zt[2 + 2], c.zt[2 + 3], nullptr, nullptr, false);
+        theta += fabs(dfr - s);
+        if (P.has_fl) { const double gap = s - P.fl; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+        if (P.has_fu) { const double gap = P.fu - s; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+    }
+    red.theta = theta;
+    red.fcost = fc;
+    red.logsum = ls;
+    red.bad = bad;
+}
+
+// acceptance test of the trial point against the filter, the switching and the Armijo conditions
+template <int NX>
+MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red) {
+    if (!(c.active && c.searching)) return;
+    ++c.ntrial;
+    const double th_t = red.theta;
+    const double ph_t = red.bad > 0.0 ? INFINITY : c.df * red.fcost - c.mu * red.logsum;
+    bool good = isfinite(th_t) && isfinite(ph_t) && th_t <= c.thmax;
+    for (int q = 0; q < c.nfilt && good; ++q) {
+        const double tf = MPC_AT(P.FILT, 2 * q), pf = MPC_AT(P.FILT, 2 * q + 1);
+        if (!(th_t < tf || ph_t < pf)) good = false;
+    }
+    if (good && c.conv) {
+        c.accepted = true;
+        c.ftype = true;
+    } else if (good) {
+        const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha * pow(-c.dphi, S_PHI) > LS_DELTA * pow(c.theta, S_THETA);
+        if (sw) {
+            if (ph_t <= c.phi + ETA_PHI * c.alpha * c.dphi) { c.accepted = true; c.ftype = true; }
+        } else if (th_t <= (1 - GAMMA_THETA) * c.theta || ph_t <= c.phi - GAMMA_PHI * c.theta) {
+            c.accepted = true;
+        }
+    }
+    if (c.accepted) {
+        c.searching = false;
+    } else {
+        c.alpha *= 0.5;
+        if (c.alpha < c.a_min || c.ntrial >= 64) { c.searching = false; c.status = -7; }
+    }
+}
+
+// =========================================================================================================
+// Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    if (!c.active) return;
+    const int N = P.N, k = c.k;
+    if (!c.accepted) {                      // line search failed: freeze the instance
+        c.active = false;
+        if (k == 0) { MPC_AT(P.ISC, IS_STATUS) = c.status; MPC_AT(P.SC, SC_ALPHA) = 0.0; MPC_AT(P.SC, SC_NTRIAL) = c.ntrial; }
+        return;
+    }
+    const double mu = c.mu, al = c.alpha, ad = c.a_du;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        if (i < 2 && k == N) continue;
+        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
+        MPC_AT(P.Z, k * NZ + i) = zn;
+        if (has_lo(lb)) {
+            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            const double dzl = mu / gap - zl - zl / gap * dv;
+            MPC_AT(P.ZL, k * NZ + i) = zreset(zl + ad * dzl, zn - lb, mu);
+        }
+        if (has_hi(ub)) {
+            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            const double dzu = mu / gap - zu + zu / gap * dv;
+            MPC_AT(P.ZU, k * NZ + i) = zreset(zu + ad * dzu, ub - zn, mu);
+        }
+        c.z[i] = zn;
+    }
+    // equality multipliers: lambda+ = -(P_k dx_k + p_k)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double s = MPC_AT(P.PK, k * D::NPK + D::NS + i);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int r = (i <= j) ? D::sidx(i, j) : D::sidx(j, i);
+            s += MPC_AT(P.PK, k * D::NPK + r) * c.dz[2 + j];
+        }
+        const double lam = MPC_AT(P.LAM, k * NX + i);
+        MPC_AT(P.LAM, k * NX + i) = lam + al * (-s - lam);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
+        double sg = 0.0, gb = 0.0;
+        if (P.has_ol) {
+            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            const double dzl = mu / gap - zl - zl / gap * ds;
+            sg += zl / gap; gb -= mu / gap;
+            MPC_AT(P.ZLO, k * 3 + j) = zreset(zl + ad * dzl, sn - P.ol, mu);
+        }
+        if (P.has_ou) {
+            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            const double dzu = mu / gap - zu + zu / gap * ds;
+            sg += zu / gap; gb += mu / gap;
+            MPC_AT(P.ZUO, k * 3 + j) = zreset(zu + ad * dzu, P.ou - sn, mu);
+        }
+        const double nu = MPC_AT(P.NUO, k * 3 + j);
+        MPC_AT(P.NUO, k * 3 + j) = nu + al * (gb - nu + sg * ds);
+        MPC_AT(P.SO, k * 3 + j) = sn;
+        c.so[j] = sn;
+    }
+    if (k == 0) {
+        const double s = c.sf, ds = c.dsf, sn = c.sft;
+        double sg = 0.0, gb = 0.0;
+        if (P.has_fl) {
+            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            const double dzl = mu / gap - zl - zl / gap * ds;
+            sg += zl / gap; gb -= mu / gap;
+            MPC_AT(P.SC, SC_ZLF) = zreset(zl + ad * dzl, sn - P.fl, mu);
+        }
+        if (P.has_fu) {
+            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            const double dzu = mu / gap - zu + zu / gap * ds;
+            sg += zu / gap; gb += mu / gap;
+            MPC_AT(P.SC, SC_ZUF) = zreset(zu + ad * dzu, P.fu - sn, mu);
+        }
+        const double nu = MPC_AT(P.SC, SC_NUF);
+        MPC_AT(P.SC, SC_NUF) = nu + al * (gb - nu + sg * ds);
+        MPC_AT(P.SC, SC_SF) = sn;
+        c.sf = sn;
+        // filter augmentation (h-type iteration) and bookkeeping
+        if (!c.ftype) {
+            int nf = c.nfilt;
+            if (nf == FILTER_MAX) {
+                for (int q = 1; q < FILTER_MAX; ++q) {
+                    MPC_AT(P.FILT, 2 * (q - 1)) = MPC_AT(P.FILT, 2 * q);
+                    MPC_AT(P.FILT, 2 * (q - 1) + 1) = MPC_AT(P.FILT, 2 * q + 1);
+                }
+                --nf;
+            }
+            MPC_AT(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
+            MPC_AT(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
+            MPC_AT(P.ISC, IS_NFILT) = nf + 1;
+        }
+        MPC_AT(P.ISC, IS_ITERS) = c.iters + 1;
+        MPC_AT(P.ISC, IS_HAVETH0) = 1;
+        MPC_AT(P.SC, SC_THMAX) = c.thmax;
+        MPC_AT(P.SC, SC_THMIN) = c.thmin;
+        MPC_AT(P.SC, SC_ALPHA) = al;
+        MPC_AT(P.SC, SC_ADU) = ad;
+        MPC_AT(P.SC, SC_PHI) = c.phi;
+        MPC_AT(P.SC, SC_NTRIAL) = c.ntrial;
+    }
+    if (!c.ftype) { if (c.nfilt == FILTER_MAX) --c.nfilt; ++c.nfilt; }
+    ++c.iters;
+}
+
+// =========================================================================================================
+// Phase 4: derivatives at the (new) iterate, KKT residuals, condensed Hessian blocks
+//          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ, NS = D::NS;
+    red = red_neutral3();
+    if (!c.active) return;
+    const int N = P.N, k = c.k, m = P.obst_mult;
+    const double dt = P.dt, df = c.df;
+    const double* x = c.z + 2;
+    const double* u = c.z;
+    double H[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) H[i] = 0.0;
+    double lamn[NX], lam[NX], f[NX], sps, cps, td, cn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        lam[i] = MPC_AT(P.LAM, k * NX + i);
+        lamn[i] = (k < N) ? MPC_AT(P.LAM, (k + 1) * NX + i) : 0.0;
+        c.xn[i] = (k < N) ? MPC_AT(P.Z, (k + 1) * NZ + 2 + i) : 0.0;
+        c.rn[i] = (k < N) ? MPC_AT(P.REF, (k + 1) * NX + i) : 0.0;
+    }
+    ode_eval<NX>(P, x, u, f, sps, cps, td);
+    const double cd = cos(x[2]), secd2 = 1.0 / (cd * cd), v = x[3], il = 1.0 / P.wheelbase;
+    // A = I + dt * df/dx : six off-identity entries
+    const double a03 = dt * cps, a04 = -dt * v * sps, a13 = dt * sps, a14 = dt * v * cps;
+    const double a42 = dt * v * secd2 * il, a43 = dt * td * il;
+    double theta = 0.0, fc = 0.0, ls = 0.0, prim = 0.0, dual = 0.0, cmin = BIG, cmax = -BIG, smult = 0.0, sz = 0.0;
+    // rx: stationarity residual of x_k ; start with lambda terms
+    double rx[NX], ru[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        rx[i] = lam[i];
+        smult += fabs(lam[i]);
+        c.gxa[i] = 0.0;
+        c.gxb[i] = 0.0;
+    }
+    c.gua[0] = c.gua[1] = c.gub[0] = c.gub[1] = 0.0;
+    double ruu[2] = {0.0, 0.0};
+    if (k < N) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            cn[i] = c.xn[i] - (f[i] * dt + x[i]);
+            theta += fabs(cn[i]);
+            prim = fmax(prim, fabs(cn[i]));
+            rx[i] -= lamn[i];
+            const double e = x[i] - c.rn[i];
+            fc += P.Q[i] * e * e;
+            const double g = df * 2 * P.Q[i] * e;
+            c.gxa[i] = g;
+            rx[i] += g;
+            H[D::sidx(i, i)] = df * 2 * P.Q[i];
+        }
+        // - (dt Fx)' lambda_{k+1}
+        rx[2] -= a42 * lamn[4];
+        rx[3] -= a03 * lamn[0] + a13 * lamn[1] + a43 * lamn[4];
+        rx[4] -= a04 * lamn[0] + a14 * lamn[1];
+        if (NX == 6) rx[3] -= dt * lamn[5];
+        // - dt * sum_r lambda_{k+1,r} Hess f_r
+        H[D::sidx(2, 2)] -= dt * (lamn[4] * v * 2.0 * td * secd2 * il);
+        H[D::sidx(2, 3)] -= dt * (lamn[4] * secd2 * il);
+        H[D::sidx(3, 4)] -= dt * (-lamn[0] * sps + lamn[1] * cps);
+        H[D::sidx(4, 4)] -= dt * (-v * (lamn[0] * cps + lamn[1] * sps));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fc += P.R[i] * u[i] * u[i];
+            const double g = df * 2 * P.R[i] * u[i];
+            c.gua[i] = g;
+            ru[i] = g - dt * lamn[2 + i];
+            ruu[i] = df * 2 * P.R[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) cn[i] = 0.0;
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double c0 = x[i] - MPC_AT(P.REF, i);
+            MPC_AT(P.SC, SC_C0 + i) = c0;
+            theta += fabs(c0);
+            prim = fmax(prim, fabs(c0));
+        }
+    }
+    // variable bounds
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        if (isu && k == N) continue;
+        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        const double zi = c.z[i];
+        double sg = 0.0, gbb = 0.0, rz = 0.0;
+        if (has_lo(lb)) {
+            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            sg += zl / gap; gbb -= 1.0 / gap; rz -= zl;
+            const double cc = gap * zl;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
+            ls += log(gap);
+        }
+        if (has_hi(ub)) {
+            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            sg += zu / gap; gbb += 1.0 / gap; rz += zu;
+            const double cc = gap * zu;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
+            ls += log(gap);
+        }
+        if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
+        else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
+    }
+    // obstacle rows
+    double dist[3], J[9], Ho[18];
+    obstacle_eval(P, c.obst, x[0], x[1], sps, cps, dist, J, Ho, true);
+    const int oi[3] = {0, 1, 4};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = c.so[j], nu = MPC_AT(P.NUO, k * 3 + j);
+        double sg = 0.0, gbb = 0.0, rs = -nu;
+        if (P.has_ol) {
+            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
+            const double cc = gap * zl;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zl;
+            ls += m * log(gap);
+        }
+        if (P.has_ou) {
+            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            sg += zu / gap; gbb += 1.0 / gap; rs += zu;
+            const double cc = gap * zu;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zu;
+            ls += m * log(gap);
+        }
+        dual = fmax(dual, fabs(rs));
+        const double res = dist[j] - s;
+        theta += m * fabs(res);
+        prim = fmax(prim, fabs(res));
+        smult += m * fabs(nu);
+        MPC_AT(P.EV, k * D::NEV + j) = dist[j];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double ja = J[3 * j + a];
+            MPC_AT(P.EV, k * D::NEV + 3 + 3 * j + a) = ja;
+            rx[oi[a]] += m * nu * ja;
+            c.gxa[oi[a]] += ja * (m * sg * res);
+            c.gxb[oi[a]] += ja * (m * gbb);
+#pragma unroll
+            for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += m * (nu * Ho[6 * j + q] + sg * ja * J[3 * j + bq]);
+        }
+    }
+    // friction row (stage 0)
+    if (k == 0) {
+        double g[3], h[4];
+        const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
+        const double s = c.sf, nu = MPC_AT(P.SC, SC_NUF);
+        double sg = 0.0, gbb = 0.0, rs = -nu;
+        if (P.has_fl) {
+            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
+            const double cc = gap * zl;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
+            ls += log(gap);
+        }
+        if (P.has_fu) {
+            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            sg += zu / gap; gbb += 1.0 / gap; rs += zu;
+            const double cc = gap * zu;
+            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
+            ls += log(gap);
+        }
+        dual = fmax(dual, fabs(rs));
+        const double res = dfr - s;
+        theta += fabs(res);
+        prim = fmax(prim, fabs(res));
+        smult += fabs(nu);
+        ru[1] += nu * g[0];
+        rx[2] += nu * g[1];
+        rx[3] += nu * g[2];
+        c.gua[1] += g[0] * sg * res; c.gub[1] += g[0] * gbb;
+        c.gxa[2] += g[1] * sg * res; c.gxb[2] += g[1] * gbb;
+        c.gxa[3] += g[2] * sg * res; c.gxb[3] += g[2] * gbb;
+        ruu[1] += nu * h[0] + sg * g[0] * g[0];
+        H[D::sidx(2, 2)] += nu * h[1] + sg * g[1] * g[1];
+        H[D::sidx(2, 3)] += nu * h[2] + sg * g[1] * g[2];
+        H[D::sidx(3, 3)] += nu * h[3] + sg * g[2] * g[2];
+        MPC_AT(P.SC, SC_HUX0) = sg * g[0] * g[1];
+        MPC_AT(P.SC, SC_HUX1) = sg * g[0] * g[2];
+        MPC_AT(P.SC, SC_DFRIC) = dfr;
+        MPC_AT(P.SC, SC_GFR0) = g[0];
+        MPC_AT(P.SC, SC_GFR1) = g[1];
+        MPC_AT(P.SC, SC_GFR2) = g[2];
+    }
+    double nanflag = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        dual = fmax(dual, fabs(rx[i]));
+        if (!isfinite(rx[i])) nanflag = 1.0;
+    }
+    if (k < N) dual = fmax(dual, fmax(fabs(ru[0]), fabs(ru[1])));
+    // stage blocks that do not depend on the barrier parameter
+    const int base = k * D::NBLK;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) MPC_AT(P.BLK, base + D::B_H + i) = H[i];
+    MPC_AT(P.BLK, base + D::B_RUU + 0) = ruu[0];
+    MPC_AT(P.BLK, base + D::B_RUU + 1) = ruu[1];
+    MPC_AT(P.BLK, base + D::B_A + 0) = a03;
+    MPC_AT(P.BLK, base + D::B_A + 1) = a04;
+    MPC_AT(P.BLK, base + D::B_A + 2) = a13;
+    MPC_AT(P.BLK, base + D::B_A + 3) = a14;
+    MPC_AT(P.BLK, base + D::B_A + 4) = a42;
+    MPC_AT(P.BLK, base + D::B_A + 5) = a43;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) MPC_AT(P.BLK, base + D::B_CN + i) = cn[i];
+    red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
+    red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
+}
+
+// =========================================================================================================
+// Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
+// =========================================================================================================
+template <int NX>
+MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
+    using D = Dim<NX>;
+    if (!c.active) return;
+    const int k = c.k;
+    const int nden = n_mult + n_z;
+    const double s_d = fmax(S_MAX, (red.sum_mult + red.sum_z) / (nden > 0 ? nden : 1)) / S_MAX;
+    const double s_c = fmax(S_MAX, red.sum_z / (n_z > 0 ? n_z : 1)) / S_MAX;
+    const double base = fmax(red.dual_inf / s_d, red.prim_inf);
+    const double E0 = fmax(base, (n_z ? fmax(red.cmax, -red.cmin) : 0.0) / s_c);
+    int status = ST_RUNNING;
+    const int cap = P.fixed_iters > 0 ? P.fixed_iters : P.max_iter;
+    if (red.nan > 0.0 || !isfinite(E0) || !isfinite(red.fcost)) status = -6;
+    else if (P.fixed_iters <= 0 && E0 <= P.tol) status = 1;
+    else if (c.iters >= cap) status = P.fixed_iters > 0 ? 1 : 0;
+    double mu = c.mu, tau = c.tau;
+    bool mu_changed = false;
+    if (status == ST_RUNNING) {
+        for (int guard = 0; guard < 64; ++guard) {
+            const double Emu = fmax(base, (n_z ? fmax(red.cmax - mu, mu - red.cmin) : 0.0) / s_c);
+            if (!(Emu <= KAPPA_EPS * mu)) break;
+            const double nm = fmax(P.tol / 10.0, fmin(KAPPA_MU * mu, pow(mu, THETA_MU)));
+            if (nm == mu) break;
+            mu = nm;
+            tau = fmax(TAU_MIN, 1.0 - mu);
+            mu_changed = true;
+        }
+        const int base_row = k * D::NBLK;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) MPC_AT(P.BLK, base_row + D::B_GX + i) = c.gxa[i] + mu * c.gxb[i];
+        MPC_AT(P.BLK, base_row + D::B_GU + 0) = c.gua[0] + mu * c.gub[0];
+        MPC_AT(P.BLK, base_row + D::B_GU + 1) = c.gua[1] + mu * c.gub[1];
+    }
+    c.status = status;
+    if (k == 0) {
+        MPC_AT(P.SC, SC_MU) = mu;
+        MPC_AT(P.SC, SC_TAU) = tau;
+        MPC_AT(P.SC, SC_THETA) = red.theta;
+        MPC_AT(P.SC, SC_FCOST) = red.fcost;
+        MPC_AT(P.SC, SC_LOGSUM) = red.logsum;
+        MPC_AT(P.SC, SC_E0) = E0;
+        MPC_AT(P.ISC, IS_STATUS) = status;
+        if (mu_changed) MPC_AT(P.ISC, IS_NFILT) = 0;       // the filter is reset whenever mu changes
+        if (P.fixed_iters > 0 && E0 <= P.tol) MPC_AT(P.ISC, IS_CONV) = 1;
+    }
+}
+
+// =========================================================================================================
+// Riccati factor/solve of the condensed KKT system: ONE instance per thread, sequential over the stages.
+//   backward:  P_N = H_N,  p_N = g_N
+//              Lam = Ruu + B' P+ B,  G = Hux + B' P+ A,  K = -Lam^-1 G,  kff = -Lam^-1 (gu + B'(p+ + P+ b))
+//              P_k = H_k + A' P+ A + G' K,   p_k = gx + A'(p+ + P+ b) + G' kff
+//   forward:   dx_0 = -c_0,  du_k = K dx_k + kff,  dx_{k+1} = A dx_k + B du_k + b_k,   b_k = -c_{k+1}
+// with A = I + dt*df/dx (six off-identity entries) and B = dt*[e_delta e_v], both exploited below.
+// Inertia correction: if some 2x2 block Lam is not positive definite the factorisation is repeated with
+// delta_w * I added to the Hessian (IPOPT section 3.1 schedule).
+// =========================================================================================================
+template <int NX>
+struct RicStage {
+    double H[Dim<NX>::NS], ruu[2], a[6], gx[NX], gu[2], cn[NX];
+};
+
+template <int NX>
+MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
+    using D = Dim<NX>;
+    const size_t base = (size_t)k * D::NBLK;
+#define RL(row) P.BLK[(base + (row)) * (size_t)P.Bp + (size_t)b]
+#pragma unroll
+    for (int i = 0; i < D::NS; ++i) s.H[i] = RL(D::B_H + i);
+    s.ruu[0] = RL(D::B_RUU); s.ruu[1] = RL(D::B_RUU + 1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.a[i] = RL(D::B_A + i);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { s.gx[i] = RL(D::B_GX + i); s.cn[i] = RL(D::B_CN + i); }
+    s.gu[0] = RL(D::B_GU); s.gu[1] = RL(D::B_GU + 1);
+#undef RL
+}
+
+// M = P * A for the sparse A (columns 2,3,4 get extra terms); P symmetric, stored upper
+template <int NX>
+MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>::sidx(i, j) : Dim<NX>::sidx(j, i)]; }
+
+template <int NX>
+MPC_HD void riccati_instance(const Params& P, int b) {
+    using D = Dim<NX>;
+    constexpr int NS = D::NS;
+    const int N = P.N;
+    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
+    if (P.ISC[(size_t)IS_STATUS * Bp + bb] != ST_RUNNING) return;
+    const double dt = P.dt;
+    const double delta_last = P.SC[(size_t)SC_DLAST * Bp + bb];
+    const double hux0 = P.SC[(size_t)SC_HUX0 * Bp + bb], hux1 = P.SC[(size_t)SC_HUX1 * Bp + bb];
+    double delta = 0.0;
+    bool ok = false;
+    for (;;) {
+        ok = true;
+        double Ps[NS], pv[NX];
+        {
+            RicStage<NX> s;
+            ric_load<NX>(P, b, N, s);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
+            const size_t pk = (size_t)N * D::NPK;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) P.PK[(pk + i) * Bp + bb] = Ps[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) P.PK[(pk + NS + i) * Bp + bb] = pv[i];
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            RicStage<NX> s;
+            ric_load<NX>(P, b, k, s);
+            const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
+            // h = p+ - P+ c_{k+1}
+            double h[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double t = pv[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) t -= sym<NX>(Ps, i, j) * s.cn[j];
+                h[i] = t;
+            }
+            // PA = P+ A
+            double PA[NX][NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double pi0 = sym<NX>(Ps, i, 0), pi1 = sym<NX>(Ps, i, 1), pi4 = sym<NX>(Ps, i, 4);
+                PA[i][0] = pi0;
+                PA[i][1] = pi1;
+                PA[i][2] = sym<NX>(Ps, i, 2) + pi4 * a42;
+                double t3 = sym<NX>(Ps, i, 3) + pi0 * a03 + pi1 * a13 + pi4 * a43;
+                if (NX == 6) t3 += sym<NX>(Ps, i, 5) * dt;
+                PA[i][3] = t3;
+                PA[i][4] = pi4 + pi0 * a04 + pi1 * a14;
+                if (NX == 6) PA[i][5] = sym<NX>(Ps, i, 5);
+            }
+            // G = B' P+ A (+ Hux at stage 0), Lam = Ruu + B' P+ B, l = gu + B' h
+            double G[2][NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { G[0][j] = dt * PA[2][j]; G[1][j] = dt * PA[3][j]; }
+            if (k == 0) { G[1][2] += hux0; G[1][3] += hux1; }
+            const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
+            const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
+            const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
+            const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
+            const double det = L00 * L11 - L01 * L01;
+            if (!(L00 > 0.0) || !(det > 0.0)) { ok = false; break; }
+            const double idet = 1.0 / det;
+            const double i00 = L11 * idet, i01 = -L01 * idet, i11 = L00 * idet;
+            double K0[NX], K1[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                K0[j] = -(i00 * G[0][j] + i01 * G[1][j]);
+                K1[j] = -(i01 * G[0][j] + i11 * G[1][j]);
+            }
+            const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
+            // p_k = gx + A' h + G' kff
+            double pn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pn[i] = s.gx[i] + h[i] + G[0][i] * kf0 + G[1][i] * kf1;
+            pn[2] += a42 * h[4];
+            pn[3] += a03 * h[0] + a13 * h[1] + a43 * h[4];
+            if (NX == 6) pn[3] += dt * h[5];
+            pn[4] += a04 * h[0] + a14 * h[1];
+            // P_k = H + A' (P+ A) + G' K   (upper triangle)
+            double Pn[NS];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = i; j < NX; ++j) {
+                    double t = s.H[D::sidx(i, j)] + PA[i][j] + G[0][i] * K0[j] + G[1][i] * K1[j];
+                    if (i == 2) t += a42 * PA[4][j];
+                    if (i == 3) { t += a03 * PA[0][j] + a13 * PA[1][j] + a43 * PA[4][j]; if (NX == 6) t += dt * PA[5][j]; }
+                    if (i == 4) t += a04 * PA[0][j] + a14 * PA[1][j];
+                    if (i == j) t += delta;
+                    Pn[D::sidx(i, j)] = t;
+                }
+            }
+            // PA is not exactly symmetric-consistent in floating point for (i<j) vs (j<i): symmetrise the way
+            // the oracle does, P_ij = (P_ij + P_ji)/2, using the lower-triangle expression as well
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = i + 1; j < NX; ++j) {
+                    // lower entry (j,i): H_ji + (A'PA)_ji + G_j' K_i
+                    double t = s.H[D::sidx(i, j)] + PA[j][i] + G[0][j] * K0[i] + G[1][j] * K1[i];
+                    if (j == 2) t += a42 * PA[4][i];
+                    if (j == 3) { t += a03 * PA[0][i] + a13 * PA[1][i] + a43 * PA[4][i]; if (NX == 6) t += dt * PA[5][i]; }
+                    if (j == 4) t += a04 * PA[0][i] + a14 * PA[1][i];
+                    Pn[D::sidx(i, j)] = 0.5 * (Pn[D::sidx(i, j)] + t);
+                }
+            }
+            // store gains and cost-to-go, roll
+            const size_t kk = (size_t)k * D::NKK, pk = (size_t)k * D::NPK;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                P.KK[(kk + j) * Bp + bb] = K0[j];
+                P.KK[(kk + NX + j) * Bp + bb] = K1[j];
+            }
+            P.KK[(kk + 2 * NX) * Bp + bb] = kf0;
+            P.KK[(kk + 2 * NX + 1) * Bp + bb] = kf1;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { Ps[i] = Pn[i]; P.PK[(pk + i) * Bp + bb] = Pn[i]; }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { pv[i] = pn[i]; P.PK[(pk + NS + i) * Bp + bb] = pn[i]; }
+        }
+        if (ok) break;
+        if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);
+        else delta *= (delta_last == 0.0) ? KW_PLUS_BAR : KW_PLUS;
+        if (delta > DW_MAX) break;
+    }
+    if (!ok) { P.ISC[(size_t)IS_STATUS * Bp + bb] = -7; return; }
+    if (delta > 0.0) P.SC[(size_t)SC_DLAST * Bp + bb] = delta;
+    P.SC[(size_t)SC_DELTA * Bp + bb] = delta;
+    // forward sweep
+    double dx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = -P.SC[(size_t)(SC_C0 + i) * Bp + bb];
+    for (int k = 0; k < N; ++k) {
+        const size_t kk = (size_t)k * D::NKK, zr = (size_t)k * D::NZ, br = (size_t)k * D::NBLK;
+        double du0 = P.KK[(kk + 2 * NX) * Bp + bb], du1 = P.KK[(kk + 2 * NX + 1) * Bp + bb];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            du0 += P.KK[(kk + j) * Bp + bb] * dx[j];
+            du1 += P.KK[(kk + NX + j) * Bp + bb] * dx[j];
+        }
+        P.DZ[(zr + 0) * Bp + bb] = du0;
+        P.DZ[(zr + 1) * Bp + bb] = du1;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) P.DZ[(zr + 2 + i) * Bp + bb] = dx[i];
+        const double a03 = P.BLK[(br + D::B_A + 0) * Bp + bb], a04 = P.BLK[(br + D::B_A + 1) * Bp + bb];
+        const double a13 = P.BLK[(br + D::B_A + 2) * Bp + bb], a14 = P.BLK[(br + D::B_A + 3) * Bp + bb];
+        const double a42 = P.BLK[(br + D::B_A + 4) * Bp + bb], a43 = P.BLK[(br + D::B_A + 5) * Bp + bb];
+        double dn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dn[i] = dx[i] - P.BLK[(br + D::B_CN + i) * Bp + bb];
+        dn[0] += a03 * dx[3] + a04 * dx[4];
+        dn[1] += a13 * dx[3] + a14 * dx[4];
+        dn[2] += dt * du0;
+        dn[3] += dt * du1;
+        dn[4] += a42 * dx[2] + a43 * dx[3];
+        if (NX == 6) dn[5] += dt * dx[3];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = dn[i];
+    }
+    {
+        const size_t zr = (size_t)N * D::NZ;
+        P.DZ[(zr + 0) * Bp + bb] = 0.0;
+        P.DZ[(zr + 1) * Bp + bb] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) P.DZ[(zr + 2 + i) * Bp + bb] = dx[i];
+    }
+}
+
+// =========================================================================================================
+// output: SoA iterate -> caller's row-major x_out + per-instance status
+// =========================================================================================================
+template <int NX>
+MPC_HD void output_instance(const Params& P, int b) {
+    using D = Dim<NX>;
+    const int N = P.N;
+    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
+    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+    double* xo = P.x_out + bb * nw;
+    for (int k = 0; k <= N; ++k) {
+        if (k < N) {
+            xo[2 * k] = P.Z[((size_t)k * D::NZ + 0) * Bp + bb];
+            xo[2 * k + 1] = P.Z[((size_t)k * D::NZ + 1) * Bp + bb];
+        }
+        for (int i = 0; i < NX; ++i) xo[2 * N + NX * k + i] = P.Z[((size_t)k * D::NZ + 2 + i) * Bp + bb];
+    }
+    int st = P.ISC[(size_t)IS_STATUS * Bp + bb];
+    if (st == ST_RUNNING) st = 0;     // iteration budget of the launch loop exhausted
+    if (P.status_out) P.status_out[b] = st;
+    if (P.iters_out) P.iters_out[b] = P.ISC[(size_t)IS_ITERS * Bp + bb];
+    if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)SC_E0 * Bp + bb];
+}
+
+}  // namespace mpc

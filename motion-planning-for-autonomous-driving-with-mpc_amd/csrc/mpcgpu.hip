@@ -1,0 +1,521 @@
+// mpcgpu.hip -- gfx950 (MI355X, CDNA4) kernels and the C-ABI of include/mpcgpu.h.
+//
+// Replaces, for B independent MPC instances at once, the call
+//     res = sol(x0=init_control, p=c_p, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)     MPC_Planner/optimizer.py:607
+// i.e. CasADi's nlpsol('ipopt') on the multiple-shooting NLP of optimizer.py:373-558.
+//
+// Kernels (one IPM iteration = k_riccati + k_stage):
+//   k_stage<NX, INIT>  one thread per (instance, horizon stage); a workgroup holds all N+1 stages of `bx`
+//                      instances so that per-instance reductions (step lengths, filter line search, KKT error)
+//                      stay inside the workgroup: wave-level xor-shuffles across the stages that share a
+//                      wavefront, then a small LDS exchange across wavefronts.  Evaluates the bicycle dynamics,
+//                      cost, circle-distance rows and their derivatives, condenses slacks/bounds into the stage
+//                      Hessian and writes the banded KKT blocks.
+//   k_riccati<NX>      one thread per instance, sequential over the stages: block-tridiagonal (Riccati)
+//                      factor + solve of the condensed KKT system, with the sparsity of A_k, B_k hard-wired.
+//   k_output<NX>       SoA iterate -> caller's row-major result.
+// HBM layout: structure-of-arrays [row][instance]; a 64-lane wavefront touches 64 (k_riccati) or bx (k_stage)
+// consecutive doubles per row => fully coalesced 512 B / 128-256 B segments.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mpc_host_common.h"
+
+using namespace mpc;
+
+// ============================================================================================== device
+namespace {
+
+constexpr int STAGE_MAX_THREADS = 512;
+
+template <typename R>
+__device__ __forceinline__ R shfl_xor_struct(const R& r, int mask) {
+    constexpr int NQ = sizeof(R) / sizeof(double);
+    R o;
+    const double* s = reinterpret_cast<const double*>(&r);
+    double* d = reinterpret_cast<double*>(&o);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) d[i] = __shfl_xor(s[i], mask, 64);
+    return o;
+}
+
+// combine `r` over all stages k of each instance column bl = threadIdx.x % bx; every thread of the column
+// ends with the same bits (commutative pairwise combines, identical order in the LDS pass)
+template <typename R>
+__device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
+    constexpr int NQ = sizeof(R) / sizeof(double);
+    for (int m = bx; m < 64; m <<= 1) {
+        const R o = shfl_xor_struct(r, m);
+        red_combine(r, o);
+    }
+    const int nw = blockDim.x >> 6;
+    if (nw > 1) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, bl = lane & (bx - 1);
+        double* mine = reinterpret_cast<double*>(&r);
+        if (lane < bx) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) lds[(wave * NQ + q) * bx + lane] = mine[q];
+        }
+        __syncthreads();
+        R acc;
+        double* a = reinterpret_cast<double*>(&acc);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a[q] = lds[q * bx + bl];
+        for (int w = 1; w < nw; ++w) {
+            R o;
+            double* op = reinterpret_cast<double*>(&o);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) op[q] = lds[(w * NQ + q) * bx + bl];
+            red_combine(acc, o);
+        }
+        r = acc;
+        __syncthreads();
+    }
+}
+
+template <int NX, bool INIT>
+__global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, const int n_mult, const int n_z) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    Ctx<NX> c;
+    const int bx = P.bx, t = threadIdx.x;
+    c.k = t / bx;
+    c.b = blockIdx.x * bx + (t & (bx - 1));
+    c.valid = (c.k <= P.N) && (c.b < P.B);
+    c.active = false;
+    c.status = 0;
+    c.iters = 0;
+    if (INIT) {
+        Red0 r0;
+        phase_init_point<NX>(P, c, r0);
+        block_reduce(r0, bx, lds);
+        phase_init_scalars<NX>(P, c, r0);
+        __syncthreads();
+    } else {
+        phase_load_scalars<NX>(P, c);
+        if (!__syncthreads_or(c.active ? 1 : 0)) return;
+        Red1 r1;
+        phase_step_candidates<NX>(P, c, r1);
+        block_reduce(r1, bx, lds);
+        phase_linesearch_begin<NX>(P, c, r1);
+        while (__syncthreads_or((c.active && c.searching) ? 1 : 0)) {
+            Red2 r2;
+            phase_trial_eval<NX>(P, c, r2);
+            block_reduce(r2, bx, lds);
+            phase_linesearch_decide<NX>(P, c, r2);
+        }
+        phase_apply_update<NX>(P, c);
+        __syncthreads();
+    }
+    Red3 r3;
+    phase_eval_assemble<NX>(P, c, r3);
+    block_reduce(r3, bx, lds);
+    phase_finish<NX>(P, c, r3, n_mult, n_z);
+}
+
+template <int NX>
+__global__ void __launch_bounds__(64) k_riccati(const Params P) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < P.B) riccati_instance<NX>(P, b);
+}
+
+template <int NX>
+__global__ void __launch_bounds__(64) k_prestart(const Params P) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < P.B) prestart_instance<NX>(P, b);
+}
+
+template <int NX>
+__global__ void __launch_bounds__(64) k_output(const Params P) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < P.B) output_instance<NX>(P, b);
+}
+
+__global__ void k_count_running(const int32_t* status, int B, int32_t* counter) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int run = (b < B && status[b] == ST_RUNNING) ? 1 : 0;
+    const unsigned long long m = __ballot(run);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
+}
+
+__global__ void k_transpose_obst(const double* obst /*[B][6]*/, double* OBST /*[6][Bp]*/, int B, int Bp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) OBST[(size_t)i * Bp + b] = obst[(size_t)b * 6 + i];
+}
+
+template <int NX>
+__global__ void k_plant_step(const Params P, const double* x, const double* u, double* xn, int B, int integrator) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double xs[NX], us[2], f[NX], s, c, td;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = x[(size_t)b * NX + i];
+    us[0] = u[(size_t)b * 2];
+    us[1] = u[(size_t)b * 2 + 1];
+    const double h = P.dt;
+    if (integrator == 0) {
+        ode_eval<NX>(P, xs, us, f, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[(size_t)b * NX + i] = xs[i] + h * f[i];
+    } else {
+        double k1[NX], k2[NX], k3[NX], k4[NX], tmp[NX];
+        ode_eval<NX>(P, xs, us, k1, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = xs[i] + 0.5 * h * k1[i];
+        ode_eval<NX>(P, tmp, us, k2, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = xs[i] + 0.5 * h * k2[i];
+        ode_eval<NX>(P, tmp, us, k3, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = xs[i] + h * k3[i];
+        ode_eval<NX>(P, tmp, us, k4, s, c, td);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[(size_t)b * NX + i] = xs[i] + h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    }
+}
+
+}  // namespace
+
+// ============================================================================================== host
+struct mpc_handle {
+    HostProblem hp;
+    std::string err;
+    int device = 0;
+    // device workspace
+    size_t cap_Bp = 0;
+    double* d_ws = nullptr;
+    int32_t* d_iws = nullptr;
+    double *d_LB = nullptr, *d_UB = nullptr;
+    int32_t* d_counter = nullptr;
+    int32_t* h_counter = nullptr;      // pinned
+    // staging buffers of the host entry point
+    size_t cap_io = 0;
+    double *d_x0 = nullptr, *d_p = nullptr, *d_xout = nullptr, *d_kkt = nullptr, *d_obst = nullptr;
+    int32_t *d_status = nullptr, *d_iters = nullptr;
+    hipStream_t own_stream = nullptr;
+    // profiling
+    bool profiling = false;
+    double prof[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            char buf_[512];                                                                           \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (h)->err = buf_;                                                                          \
+            return MPC_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+static void free_ws(mpc_handle* h) {
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_iws) (void)hipFree(h->d_iws);
+    h->d_ws = nullptr; h->d_iws = nullptr; h->cap_Bp = 0;
+}
+static void free_io(mpc_handle* h) {
+    void* ptrs[] = {h->d_x0, h->d_p, h->d_xout, h->d_kkt, h->d_obst, h->d_status, h->d_iters};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->d_x0 = h->d_p = h->d_xout = h->d_kkt = h->d_obst = nullptr;
+    h->d_status = h->d_iters = nullptr;
+    h->cap_io = 0;
+}
+
+extern "C" {
+
+int mpc_abi_version(void) { return MPCGPU_ABI_VERSION; }
+
+void mpc_default_desc(mpc_problem_desc* desc, int32_t N, int32_t nx) { default_desc(desc, N, nx); }
+
+const char* mpc_last_error(const mpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
+    if (!out || !desc) { g_create_error = "null argument"; return MPC_ERR_INVALID; }
+    *out = nullptr;
+    std::string err;
+    int rc = validate_desc(*desc, err);
+    if (rc) { g_create_error = err; return rc; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e) + " (this library has no CPU path)";
+        return MPC_ERR_HIP;
+    }
+    if (desc->device < 0 || desc->device >= ndev) { g_create_error = "device ordinal out of range"; return MPC_ERR_INVALID; }
+    mpc_handle* h = new (std::nothrow) mpc_handle();
+    if (!h) { g_create_error = "out of host memory"; return MPC_ERR_INVALID; }
+    h->hp.desc = *desc;
+    h->device = desc->device;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&h->d_counter, sizeof(int32_t)) != hipSuccess || hipHostMalloc(&h->h_counter, sizeof(int32_t)) != hipSuccess) {
+        g_create_error = "HIP stream/counter allocation failed";
+        delete h;
+        return MPC_ERR_HIP;
+    }
+    rc = mpc_set_bounds(h, nullptr, nullptr, nullptr, nullptr);     // reference defaults until told otherwise
+    if (rc) { g_create_error = h->err; mpc_destroy(h); return rc; }
+    *out = h;
+    return MPC_OK;
+}
+
+int mpc_destroy(mpc_handle* h) {
+    if (!h) return MPC_OK;
+    (void)hipSetDevice(h->device);
+    free_ws(h);
+    free_io(h);
+    if (h->d_LB) (void)hipFree(h->d_LB);
+    if (h->d_UB) (void)hipFree(h->d_UB);
+    if (h->d_counter) (void)hipFree(h->d_counter);
+    if (h->h_counter) (void)hipHostFree(h->h_counter);
+    for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return MPC_OK;
+}
+
+int mpc_set_bounds(mpc_handle* h, const double* lbx, const double* ubx, const double* lbg, const double* ubg) {
+    if (!h) return MPC_ERR_INVALID;
+    int rc = set_bounds(h->hp, lbx, ubx, lbg, ubg, h->err);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = h->hp.LB.size() * sizeof(double);
+    if (!h->d_LB) { HIP_TRY(h, hipMalloc(&h->d_LB, n)); HIP_TRY(h, hipMalloc(&h->d_UB, n)); }
+    HIP_TRY(h, hipMemcpy(h->d_LB, h->hp.LB.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_UB, h->hp.UB.data(), n, hipMemcpyHostToDevice));
+    return MPC_OK;
+}
+
+int mpc_set_profiling(mpc_handle* h, int32_t enable) {
+    if (!h) return MPC_ERR_INVALID;
+    h->profiling = enable != 0;
+    return MPC_OK;
+}
+
+int mpc_get_profile(const mpc_handle* h, double out[6]) {
+    if (!h || !out) return MPC_ERR_INVALID;
+    for (int i = 0; i < 6; ++i) out[i] = h->prof[i];
+    return MPC_OK;
+}
+
+}  // extern "C"
+
+static int ensure_ws(mpc_handle* h, size_t Bp) {
+    if (Bp <= h->cap_Bp) return MPC_OK;
+    free_ws(h);
+    // workspace addressing depends on Bp, so it is (re)allocated exactly for the padded batch size
+    const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp);
+    HIP_TRY(h, hipMalloc(&h->d_ws, w.total * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_iws, w.itotal * sizeof(int32_t)));
+    h->cap_Bp = Bp;
+    return MPC_OK;
+}
+
+namespace {
+struct Prof {
+    mpc_handle* h;
+    hipStream_t s;
+    size_t used = 0;
+    std::vector<int> kinds;     // kind per (start, stop) pair
+    hipEvent_t get() {
+        if (used == h->ev_pool.size()) {
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            h->ev_pool.push_back(ev);
+        }
+        return h->ev_pool[used++];
+    }
+    void begin(int kind) { if (h->profiling) { kinds.push_back(kind); (void)hipEventRecord(get(), s); } }
+    void end() { if (h->profiling) (void)hipEventRecord(get(), s); }
+    void collect() {
+        for (int i = 0; i < 6; ++i) h->prof[i] = 0;
+        if (!h->profiling) return;
+        (void)hipStreamSynchronize(s);
+        for (size_t i = 0; i < kinds.size(); ++i) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
+            if (kinds[i] == 0) { h->prof[0] += ms; h->prof[1] += 1; }
+            else if (kinds[i] == 1) { h->prof[2] += ms; h->prof[3] += 1; }
+            else h->prof[4] += ms;
+        }
+    }
+};
+}  // namespace
+
+template <int NX>
+static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst,
+                          double* d_x_out, int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream,
+                          double* trace, int32_t trace_rows, int32_t* n_it_out) {
+    const mpc_problem_desc& d = h->hp.desc;
+    const size_t Bp = ((size_t)B + 63) / 64 * 64;
+    // the SoA stride is Bp: keep one workspace per distinct padded size (re-allocate when it changes)
+    if (Bp != h->cap_Bp) { h->cap_Bp = 0; }
+    int rc = ensure_ws(h, Bp);
+    if (rc) return rc;
+    const int bx = pick_bx(d.N, STAGE_MAX_THREADS);
+    Params P;
+    fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
+    P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
+    const WsLayout w = ws_layout(d.N, d.nx, Bp);
+    Prof prof{h, stream};
+    if (d_obst) {
+        P.per_inst_obst = 1;
+        hipLaunchKernelGGL(k_transpose_obst, dim3((B + 255) / 256), dim3(256), 0, stream, d_obst, h->d_ws + w.OBST, B, (int)Bp);
+    }
+    const int S = d.N + 1;
+    const int threads = ((S * bx + 63) / 64) * 64;
+    const int nblk = (B + bx - 1) / bx;
+    const int nw = threads / 64;
+    const size_t lds_bytes = (size_t)nw * 10 * bx * sizeof(double);
+    const int rblk = (int)(Bp / 64);
+    int32_t* d_stat_row = h->d_iws + (size_t)IS_STATUS * Bp;
+
+    prof.begin(2);
+    hipLaunchKernelGGL((k_prestart<NX>), dim3(rblk), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL((k_stage<NX, true>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+    prof.end();
+
+    const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
+    const int chunk = d.fixed_iters > 0 ? cap : 4;
+    auto record_trace = [&](int it) -> int {
+        if (!trace || it >= trace_rows) return MPC_OK;
+        static const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        for (int q = 0; q < 8; ++q)
+            HIP_TRY(h, hipMemcpy(trace + ((size_t)it * 8 + q) * B, h->d_ws + w.SC + (size_t)rows[q] * Bp, sizeof(double) * B,
+                                 hipMemcpyDeviceToHost));
+        return MPC_OK;
+    };
+    int it = 0;
+    while (it < cap) {
+        const int n = std::min(trace ? 1 : chunk, cap - it);
+        for (int j = 0; j < n; ++j, ++it) {
+            prof.begin(0);
+            hipLaunchKernelGGL((k_riccati<NX>), dim3(rblk), dim3(64), 0, stream, P);
+            prof.end();
+            prof.begin(1);
+            hipLaunchKernelGGL((k_stage<NX, false>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+            prof.end();
+            if (trace) { rc = record_trace(it); if (rc) return rc; }
+        }
+        if (d.fixed_iters > 0) break;
+        // convergence poll
+        HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_count_running, dim3((B + 255) / 256), dim3(256), 0, stream, d_stat_row, B, h->d_counter);
+        HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        if (*h->h_counter == 0) break;
+    }
+    if (trace) { rc = record_trace(it); if (rc) return rc; }
+    if (n_it_out) *n_it_out = it;
+    prof.begin(2);
+    hipLaunchKernelGGL((k_output<NX>), dim3(rblk), dim3(64), 0, stream, P);
+    prof.end();
+    HIP_TRY(h, hipGetLastError());
+    h->prof[5] = it;
+    if (d.fixed_iters <= 0 || h->profiling) HIP_TRY(h, hipStreamSynchronize(stream));
+    const double its = it;
+    prof.collect();
+    h->prof[5] = its;
+    return MPC_OK;
+}
+
+static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
+                     int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream, double* trace, int32_t trace_rows,
+                     int32_t* n_it) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !d_x0 || !d_p || !d_x_out) { h->err = "B > 0 and x0, p, x_out are required"; return MPC_ERR_INVALID; }
+    if (!h->hp.bounds_set) { h->err = "mpc_set_bounds has not been called"; return MPC_ERR_STATE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->hp.desc.nx == 5)
+        return solve_dev_impl<5>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+    return solve_dev_impl<6>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+}
+
+static int ensure_io(mpc_handle* h, size_t B) {
+    if (B <= h->cap_io) return MPC_OK;
+    free_io(h);
+    const size_t nw = h->hp.n_w();
+    HIP_TRY(h, hipMalloc(&h->d_x0, B * nw * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_p, B * nw * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_xout, B * nw * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_kkt, B * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_obst, B * 6 * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_status, B * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->d_iters, B * sizeof(int32_t)));
+    h->cap_io = B;
+    return MPC_OK;
+}
+
+static int solve_host(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst, double* x_out,
+                      int32_t* status, int32_t* iters, double* kkt, double* trace, int32_t trace_rows, int32_t* n_it) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !x0 || !p || !x_out) { h->err = "B > 0 and x0, p, x_out are required"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_io(h, (size_t)B);
+    if (rc) return rc;
+    const size_t nw = h->hp.n_w();
+    hipStream_t s = h->own_stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x0, x0, B * nw * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_p, p, B * nw * sizeof(double), hipMemcpyHostToDevice, s));
+    if (obst) HIP_TRY(h, hipMemcpyAsync(h->d_obst, obst, (size_t)B * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    rc = solve_dev(h, B, h->d_x0, h->d_p, obst ? h->d_obst : nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, s, trace,
+                   trace_rows, n_it);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_out, h->d_xout, B * nw * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, h->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (kkt) HIP_TRY(h, hipMemcpyAsync(kkt, h->d_kkt, B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MPC_OK;
+}
+
+extern "C" {
+
+int mpc_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
+                        int32_t* d_status, int32_t* d_iters, double* d_kkt, void* stream) {
+    return solve_dev(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, (hipStream_t)stream, nullptr, 0, nullptr);
+}
+
+int mpc_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst, double* x_out,
+                    int32_t* status, int32_t* iters, double* kkt) {
+    return solve_host(h, B, x0, p, obst, x_out, status, iters, kkt, nullptr, 0, nullptr);
+}
+
+int mpc_solve_batch_trace(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst, double* x_out,
+                          int32_t* status, int32_t* iters, double* kkt, double* trace, int32_t trace_rows, int32_t* n_it) {
+    return solve_host(h, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it);
+}
+
+int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x, const double* u, double* x_next) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !x || !u || !x_next || integrator < 0 || integrator > 1) { h->err = "bad plant-step arguments"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nx = h->hp.desc.nx;
+    double *dx = nullptr, *du = nullptr, *dn = nullptr;
+    HIP_TRY(h, hipMalloc(&dx, (size_t)B * nx * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&du, (size_t)B * 2 * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&dn, (size_t)B * nx * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(dx, x, (size_t)B * nx * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(du, u, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice));
+    Params P{};
+    P.dt = h->hp.desc.dt; P.wheelbase = h->hp.desc.wheelbase; P.nx = nx;
+    if (nx == 5) hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 255) / 256), dim3(256), 0, h->own_stream, P, dx, du, dn, B, integrator);
+    else hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 255) / 256), dim3(256), 0, h->own_stream, P, dx, du, dn, B, integrator);
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    HIP_TRY(h, hipMemcpy(x_next, dn, (size_t)B * nx * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
+    return MPC_OK;
+}
+
+}  // extern "C"

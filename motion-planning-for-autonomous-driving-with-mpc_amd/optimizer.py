@@ -1,0 +1,326 @@
+"""
+Host-side mirror of the reference's `MPC_Planner/optimizer.py` call surface, backed by the HIP solver.
+
+What is mirrored (same names, argument meaning, return shapes, and the behaviour-defining quirks of SURVEY.md
+App. C), so that `mpc_planner.py:301-309` works unchanged against this module:
+
+    CasadiOptimizer(configuration=, init_values=, predict_horizon=)        optimizer.py:369-371
+        .inequal_constraints() -> lbg, ubg, lbx, ubx                        optimizer.py:413-491
+        .solver() -> (sol, f)                                               optimizer.py:513-560
+              sol(x0=, p=, lbg=, lbx=, ubg=, ubx=)['x'].full()              optimizer.py:607-609
+              f(x, u).full()                                                optimizer.py:649-650
+        .optimize() -> (states[L,5], controls[L,2], solve_time[L])          optimizer.py:562-643
+        .shift_movement(...), .desired_command_and_trajectory(...)          optimizer.py:645-702
+    ForcesproOptimizer(...)  -- call surface of `solver.solve(problem)`     optimizer.py:197-366
+
+The reference rebuilds the CasADi graph and the IPOPT object on every MPC step (optimizer.py:605); here
+`solver()` returns a cached handle to the device workspace.  All NLP arithmetic runs in csrc/mpcgpu.hip through
+the C-ABI of include/mpcgpu.h; this file only packs arguments.  `ca` below is a tiny numeric stand-in for the
+three CasADi functions that `mpc_planner.py` reaches through its star import (mpc_planner.py:288-290).
+"""
+from __future__ import annotations
+
+import math
+import time
+import types
+
+import numpy as np
+
+from .solver import BatchedMPCSolver
+
+# ------------------------------------------------------------------------------------------------------------
+# numeric stand-ins for names the reference's planner pulls in via `from MPC_Planner.optimizer import *`
+# ------------------------------------------------------------------------------------------------------------
+ca = types.SimpleNamespace(
+    sqrt=np.sqrt,
+    vertcat=lambda *a: np.concatenate([np.atleast_1d(np.asarray(x, dtype=np.float64)).ravel() for x in a]).reshape(-1, 1),
+    reshape=lambda a, r, c: DMLike(np.asarray(a.full() if hasattr(a, "full") else a, dtype=np.float64).reshape((r, c), order="F")),
+    cos=np.cos, sin=np.sin, tan=np.tan,
+)
+
+
+class DMLike:
+    """the two things the reference does with a casadi.DM: `.full()` and reshaping."""
+
+    def __init__(self, a):
+        self._a = np.array(a, dtype=np.float64)
+
+    def full(self):
+        return self._a.copy()
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    @property
+    def shape(self):
+        return self._a.shape
+
+
+def find_closest_point(path_points, current_point):
+    """configuration.py:26-37."""
+    diff = np.transpose(np.transpose(path_points) - current_point.reshape(2, 1))
+    squared_dist = np.power(diff, 2)[:, 0] + np.power(diff, 2)[:, 1]
+    return np.argmin(squared_dist)
+
+
+def compute_approximating_circle_radius(ego_length, ego_width):
+    """configuration.py:40-66 (radius rounding rule included)."""
+    assert ego_length >= 0 and ego_width >= 0, "Invalid vehicle dimensions = {}".format([ego_length, ego_width])
+    if np.isclose(ego_length, 0.0) and np.isclose(ego_width, 0.0):
+        return 0.0, 0.0
+    square_length = ego_length / 3
+    diagonal_square = np.sqrt((square_length / 2) ** 2 + (ego_width / 2) ** 2)
+    if diagonal_square > round(diagonal_square, 1):
+        approx_radius = round(diagonal_square, 1) + 0.1
+    else:
+        approx_radius = round(diagonal_square, 1)
+    return approx_radius, round(square_length * 2, 1)
+
+
+def compute_centers_of_approximation_circles(x_position, y_position, v_length, v_width, orientation):
+    """configuration.py:69-93: centre, front and rear circle centres."""
+    _, disc_distance = compute_approximating_circle_radius(v_length, v_width)
+    distance_centers = disc_distance / 2
+    center = [x_position, y_position]
+    center_fw = [x_position + (distance_centers / 2) * np.cos(orientation), y_position + (distance_centers / 2) * np.sin(orientation)]
+    center_rw = [x_position - (distance_centers / 2) * np.cos(orientation), y_position - (distance_centers / 2) * np.sin(orientation)]
+    return center, center_fw, center_rw
+
+
+class VehicleDynamics:
+    """configuration.py:342-368 (kinematic single track); l = a + b of parameters_vehicle2."""
+    l = 2.5789128
+
+    @classmethod
+    def KS_casadi(cls, x, u):
+        x = np.asarray(x, dtype=np.float64).ravel()
+        u = np.asarray(u, dtype=np.float64).ravel()
+        return np.array([x[3] * math.cos(x[4]), x[3] * math.sin(x[4]), u[0], u[1], x[3] / cls.l * math.tan(x[2])])
+
+
+class _DynamicsFunction:
+    """`f = ca.Function('f', [states, controls], [rhs])` look-alike (optimizer.py:537): f(x, u).full() -> (5,1)."""
+
+    def __call__(self, x, u):
+        return DMLike(VehicleDynamics.KS_casadi(x, u).reshape(-1, 1))
+
+
+class NlpSolution(dict):
+    """what `sol(...)` returns: res['x'].full() is the optimal decision vector (optimizer.py:609)."""
+
+
+class NlpSolverHandle:
+    """`ca.nlpsol('solver', 'ipopt', nlp_prob, opts)` look-alike (optimizer.py:558): callable with the same
+    keyword arguments as optimizer.py:607.  Accepts a single instance ((n_w,1) / (n_w,)) or a batch [B, n_w]."""
+
+    def __init__(self, backend: BatchedMPCSolver):
+        self._backend = backend
+        self._stats = {}
+
+    def __call__(self, x0=None, p=None, lbg=None, lbx=None, ubg=None, ubx=None, **_unused):
+        be = self._backend
+        x0a = np.asarray(x0.full() if hasattr(x0, "full") else x0, dtype=np.float64)
+        pa = np.asarray(p.full() if hasattr(p, "full") else p, dtype=np.float64)
+        batched = x0a.ndim == 2 and x0a.shape[1] == be.n_w and x0a.shape[0] != be.n_w
+        if not batched:
+            x0a = x0a.reshape(1, -1)
+            pa = pa.reshape(1, -1)
+        if lbg is not None or lbx is not None or ubg is not None or ubx is not None:
+            be.set_bounds(lbx, ubx, lbg, ubg)
+        res = be.solve(x0a, pa)
+        self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(),
+                           success=bool(np.all(res.status == 1)),
+                           return_status="Solve_Succeeded" if np.all(res.status == 1) else "Not_Converged")
+        x = res.x if batched else res.x.reshape(-1, 1)
+        out = NlpSolution(x=DMLike(x))
+        out["status"] = res.status
+        return out
+
+    def stats(self):
+        return dict(self._stats)
+
+
+class Optimizer(object):
+    """optimizer.py:33-83 -- pulls limits, weights, obstacle circles out of the planning configuration."""
+
+    def __init__(self, configuration, init_values, predict_horizon):
+        self.configuration = configuration
+        self.delta_min = configuration.p.steering.min
+        self.delta_max = configuration.p.steering.max
+        self.deltav_min = configuration.p.steering.v_min
+        self.deltav_max = configuration.p.steering.v_max
+        self.v_min = 0
+        self.v_max = configuration.p.longitudinal.v_max
+        self.a_max = configuration.p.longitudinal.a_max
+        self.init_position, self.init_velocity, self.init_acceleration, self.init_orientation = \
+            init_values[0], init_values[1], init_values[2], init_values[3]
+        self.iter_length = configuration.iter_length
+        self.delta_t = configuration.delta_t
+        self.desired_velocity = configuration.desired_velocity
+        self.resampled_path_points = configuration.reference_path
+        self.orientation = configuration.orientation
+        self.predict_horizon = predict_horizon
+        self.weights_setting = configuration.weights_setting
+        so = configuration.static_obstacle
+        self.obstacle_circles_centers_tuple = compute_centers_of_approximation_circles(
+            so["position_x"], so["position_y"], so["length"], so["width"], so["orientation"])
+        self.radius_obstacle, _ = compute_approximating_circle_radius(so["length"], so["width"])
+        self.radius_ego, _ = compute_approximating_circle_radius(configuration.p.l, configuration.p.w)
+
+    def equal_constraints(self, *args, **kwargs):
+        pass
+
+    def inequal_constraints(self, *args, **kwargs):
+        pass
+
+    def cost_function(self, *args, **kwargs):
+        pass
+
+    def solver(self):
+        pass
+
+    def optimize(self):
+        pass
+
+
+class CasadiOptimizer(Optimizer):
+    """optimizer.py:369-702 with the NLP solved on the GPU."""
+
+    num_states = 5
+    num_controls = 2
+
+    def __init__(self, configuration, init_values, predict_horizon, device=0):
+        super(CasadiOptimizer, self).__init__(configuration, init_values, predict_horizon)
+        self._device = device
+        self._sol = None
+        self._f = _DynamicsFunction()
+
+    # -- bounds: optimizer.py:413-491 ---------------------------------------------------------------------------
+    def inequal_constraints(self):
+        N = self.predict_horizon
+        lbg = [0.0]
+        ubg = [self.a_max]
+        for _ in range(N + 1):
+            lbg += [0.0] * 5
+            ubg += [0.0] * 5
+        for _ in range(N + 1):
+            lbg += [(self.radius_ego + self.radius_obstacle)] * 9
+            ubg += [np.inf] * 9
+        lbx, ubx = [], []
+        for _ in range(N):
+            lbx += [self.deltav_min, -np.inf]
+            ubx += [self.deltav_max, self.a_max]
+        for _ in range(N + 1):
+            lbx += [-np.inf, -np.inf, self.delta_min, self.v_min, -np.inf]
+            ubx += [np.inf, np.inf, self.delta_max, self.v_max, np.inf]
+        return lbg, ubg, lbx, ubx
+
+    # -- solver object: optimizer.py:513-560 ---------------------------------------------------------------------
+    def solver(self):
+        if self._sol is None:
+            w = self.weights_setting
+            Q = [w["weight_x"], w["weight_y"], w["weight_steering_angle"], w["weight_velocity"], w["weight_heading_angle"]]
+            R = [w["weight_velocity_steering_angle"], w["weight_long_acceleration"]]
+            Pt = [w["weight_x_terminate"], w["weight_y_terminate"], w["weight_steering_angle_terminate"],
+                  w["weight_velocity_terminate"], w["weight_heading_angle_terminate"]]
+            _, disc_distance = compute_approximating_circle_radius(self.configuration.p.l, self.configuration.p.w)
+            centers = np.array(self.obstacle_circles_centers_tuple, dtype=np.float64)
+            backend = BatchedMPCSolver(self.predict_horizon, 5, dt=self.delta_t, Q=Q, R=R, P=Pt, obstacle_centers=centers,
+                                       ego_offset=(disc_distance / 2) / 2, max_iter=100, tol=1e-8, device=self._device)
+            self._sol = NlpSolverHandle(backend)
+        return self._sol, self._f
+
+    # -- closed loop: optimizer.py:562-643 -----------------------------------------------------------------------
+    def optimize(self):
+        num_states, num_controls, N = 5, 2, self.predict_horizon
+        lbg, ubg, lbx, ubx = self.inequal_constraints()
+        t0 = 0.0
+        init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation]).reshape(-1, 1)
+        current_state = init_state.copy()
+        u0 = np.array([0.0, 0.0] * N).reshape(-1, 2).T
+        next_trajectories = np.tile(current_state.reshape(1, -1), N + 1).reshape(N + 1, -1)
+        next_states = next_trajectories.copy()
+        next_controls = np.zeros((N, 2))
+        u_c, traj, index_t = [], [], []
+        for i in range(self.iter_length):
+            c_p = np.concatenate((next_controls.reshape(-1, 1), next_trajectories.reshape(-1, 1)))
+            # (the reference's warm-start layouts, including their transposition quirks: optimizer.py:602)
+            init_control = np.concatenate((u0.T.reshape(-1, 1), next_states.T.reshape(-1, 1)))
+            t_ = time.time()
+            sol, f = self.solver()
+            res = sol(x0=init_control, p=c_p, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)
+            index_t.append(time.time() - t_)
+            estimated_opt = res["x"].full()
+            u0 = estimated_opt[:int(num_controls * N)].reshape(N, num_controls).T
+            if self.configuration.noised:
+                # optimizer.py:611-615 draws 20 samples (N = 10); generalised to 2 N samples for other horizons
+                sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05
+                u0 = u0 + np.random.normal(0, sigma, 2 * N).reshape(num_controls, N)
+            x_m = estimated_opt[int(num_controls * N):].reshape(N + 1, num_states).T
+            u_c.append(u0[:, 0])
+            t0, current_state, u0, next_states = self.shift_movement(t0, current_state, u0, x_m, f)
+            current_state = ca.reshape(current_state, -1, 1).full()
+            next_trajectories, next_controls = self.desired_command_and_trajectory(i, current_state, N)
+            traj.append(current_state)
+        t_v = np.array(index_t)
+        u = np.array(u_c)
+        traj_s = np.array(np.squeeze(traj))
+        traj_s = np.insert(traj_s, 0, init_state.T, axis=0)
+        traj_s = np.delete(traj_s, -1, axis=0)
+        return traj_s, u, t_v
+
+    def shift_movement(self, t0, x0, u, x_f, f):
+        """optimizer.py:645-655."""
+        f_value = f(x0, u[:, 0])
+        st = x0 + self.delta_t * f_value.full()
+        t = t0 + self.delta_t
+        u_end = np.concatenate((u[:, 1:], u[:, -1:]), axis=1)
+        x_f = np.concatenate((x_f[:, 1:], x_f[:, -1:]), axis=1)
+        return t, st, u_end.T, x_f
+
+    def desired_command_and_trajectory(self, i, x0_, N_):
+        """optimizer.py:657-702: reference window, frozen to the last N path points once i >= L - N."""
+        x_ = x0_.reshape(1, -1).tolist()[0]
+        u_ = []
+        L = self.iter_length
+        for k in range(N_):
+            idx = i + k + 1
+            if i >= L - self.predict_horizon:
+                idx = i + k + 1 - (i - (L - self.predict_horizon) + 1)
+            x_ += [self.resampled_path_points[idx, 0], self.resampled_path_points[idx, 1], 0.0, self.desired_velocity,
+                   self.orientation[idx]]
+            u_ += [0, 0]
+        return np.array(x_).reshape(N_ + 1, -1), np.array(u_).reshape(N_, -1)
+
+
+class ForcesproOptimizer(Optimizer):
+    """Call-surface twin of optimizer.py:86-366 (`model, solver = self.solver(); solver.solve(problem)`).
+
+    The FORCESPRO formulation (RK4 shooting, per-stage friction circle, 3x3 squared circle distances, terminal
+    weights, SQP with BFGS) is row f3 of the scope table -- scheduled after the CasADi path; its
+    numerics in the reference live in a closed, licence-expired binary (FORCESNLPsolver.h:209-210), so there is
+    nothing to be bit-compatible with.  Until the FORCES-mode kernels land, `solver()` raises instead of silently
+    substituting the Euler formulation."""
+
+    def __init__(self, configuration, init_values, predict_horizon):
+        super(ForcesproOptimizer, self).__init__(configuration, init_values, predict_horizon)
+
+    def inequal_constraint(self):
+        """optimizer.py:100-119."""
+        z_low_bound = np.array([self.deltav_min, -self.a_max, -np.inf, -np.inf, self.delta_min, self.v_min, -np.inf])
+        z_upper_bound = np.array([self.deltav_max, self.a_max, np.inf, np.inf, self.delta_max, self.v_max, np.inf])
+        lo = np.concatenate((np.array([0]), np.tile(np.array([(self.radius_ego + self.radius_obstacle) ** 2]), 9)))
+        hi = np.concatenate((np.array([self.a_max ** 2]), np.tile(np.array([np.inf]), 9)))
+        return z_low_bound, z_upper_bound, lo, hi
+
+    def solver(self):
+        raise NotImplementedError(
+            "ForcesproOptimizer: the FORCES (RK4 / SQP) formulation is not built yet (scope row f3); "
+            "use CasadiOptimizer (framework_name: casadi).")
+
+    def optimize(self):
+        self.solver()
+
+
+__all__ = ["CasadiOptimizer", "ForcesproOptimizer", "Optimizer", "NlpSolverHandle", "DMLike", "VehicleDynamics", "ca", "np",
+           "find_closest_point", "compute_approximating_circle_radius", "compute_centers_of_approximation_circles"]

@@ -1,0 +1,163 @@
+"""
+BatchedMPCSolver -- thin Python owner of an `mpc_handle` (include/mpcgpu.h).
+
+One handle = one problem template (horizon, weights, obstacle, bounds) + its device workspace; it solves B
+independent instances of the NLP of MPC_Planner/optimizer.py:373-558 per call, i.e. B times the reference's
+`sol(x0=..., p=..., lbg=..., lbx=..., ubg=..., ubx=...)` (optimizer.py:607).
+
+All arithmetic happens in the HIP kernels of csrc/mpcgpu.hip.  No CPU fallback exists: constructing a solver
+without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi
+from ._abi import MpcLibraryError, MpcProblemDesc
+
+
+class MpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mpcgpu error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class SolveResult:
+    x: np.ndarray          # [B, n_w] rows in the reference's decision-vector order (optimizer.py:550)
+    status: np.ndarray     # [B] int32, 1 converged / 0 max-iter / -6 NaN / -7 no progress
+    iters: np.ndarray      # [B] int32
+    kkt: np.ndarray        # [B] scaled KKT error at exit
+
+
+class BatchedMPCSolver:
+    def __init__(self, N, nx=5, *, dt=0.1, Q=None, R=None, P=None, obstacle_centers=None, wheelbase=2.5789128,
+                 friction_div=2.578, ego_offset=0.75, max_iter=100, tol=1e-8, fixed_iters=0, obst_mult=3, device=0,
+                 lib_path=None):
+        self._lib = _abi.load_library(lib_path)
+        d = MpcProblemDesc()
+        self._lib.mpc_default_desc(C.byref(d), int(N), int(nx))
+        d.dt, d.wheelbase, d.friction_div, d.ego_offset = float(dt), float(wheelbase), float(friction_div), float(ego_offset)
+        d.max_iter, d.fixed_iters, d.obst_mult, d.device, d.tol = int(max_iter), int(fixed_iters), int(obst_mult), int(device), float(tol)
+        if Q is not None:
+            for i in range(8):
+                d.Q[i] = float(Q[i]) if i < len(Q) else 0.0
+        if R is not None:
+            d.R[0], d.R[1] = float(R[0]), float(R[1])
+        if P is not None:
+            for i in range(8):
+                d.P[i] = float(P[i]) if i < len(P) else 0.0
+        if obstacle_centers is not None:
+            oc = np.asarray(obstacle_centers, dtype=np.float64).ravel()
+            assert oc.size == 6
+            for i in range(6):
+                d.obstacle[i] = oc[i]
+        self.desc = d
+        self.N, self.nx = int(N), int(nx)
+        self.n_w = 2 * self.N + self.nx * (self.N + 1)
+        self.n_g = 1 + self.nx * (self.N + 1) + 9 * (self.N + 1)
+        self._h = C.c_void_p()
+        rc = self._lib.mpc_create(C.byref(self._h), C.byref(d))
+        if rc != _abi.MPC_OK:
+            raise MpcError(rc, self._lib.mpc_last_error(None).decode())
+        self._bounds_key = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _abi.MPC_OK:
+            raise MpcError(rc, self._lib.mpc_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    def set_bounds(self, lbx=None, ubx=None, lbg=None, ubg=None):
+        """the four lists of `inequal_constraints()` (optimizer.py:413-491); all None = reference defaults."""
+        if lbx is None and ubx is None and lbg is None and ubg is None:
+            self._check(self._lib.mpc_set_bounds(self._h, None, None, None, None))
+            self._bounds_key = None
+            return
+        arrs = [_abi.f64(a).ravel() for a in (lbx, ubx, lbg, ubg)]
+        if arrs[0].size != self.n_w or arrs[1].size != self.n_w or arrs[2].size != self.n_g or arrs[3].size != self.n_g:
+            raise MpcError(_abi.MPC_ERR_BOUNDS, f"expected lbx/ubx of {self.n_w} and lbg/ubg of {self.n_g} entries")
+        key = tuple(a.tobytes() for a in arrs)
+        if key == self._bounds_key:
+            return
+        self._check(self._lib.mpc_set_bounds(self._h, *[_abi.as_dp(a) for a in arrs]))
+        self._bounds_key = key
+
+    def solve(self, x0, p, obst=None) -> SolveResult:
+        x0 = _abi.f64(x0)
+        p = _abi.f64(p)
+        if x0.ndim == 1:
+            x0 = x0[None]
+        if p.ndim == 1:
+            p = p[None]
+        B = x0.shape[0]
+        if x0.shape != (B, self.n_w) or p.shape != (B, self.n_w):
+            raise MpcError(_abi.MPC_ERR_INVALID, f"x0/p must be [B, {self.n_w}]")
+        if obst is not None:
+            obst = _abi.f64(obst, (B, 6))
+        out = np.empty_like(x0)
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        kkt = np.empty(B, np.float64)
+        self._check(self._lib.mpc_solve_batch(self._h, B, _abi.as_dp(x0), _abi.as_dp(p), _abi.as_dp(obst), _abi.as_dp(out),
+                                              _abi.as_ip(status), _abi.as_ip(iters), _abi.as_dp(kkt)))
+        return SolveResult(out, status, iters, kkt)
+
+    def solve_trace(self, x0, p, obst=None):
+        x0 = _abi.f64(x0)
+        p = _abi.f64(p)
+        B = x0.shape[0]
+        out = np.empty_like(x0)
+        status, iters, kkt = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B)
+        rows = int(self.desc.max_iter) + 1
+        trace = np.zeros((rows, 8, B))
+        n_it = np.zeros(1, np.int32)
+        if obst is not None:
+            obst = _abi.f64(obst, (B, 6))
+        self._check(self._lib.mpc_solve_batch_trace(self._h, B, _abi.as_dp(x0), _abi.as_dp(p), _abi.as_dp(obst), _abi.as_dp(out),
+                                                    _abi.as_ip(status), _abi.as_ip(iters), _abi.as_dp(kkt), _abi.as_dp(trace), rows,
+                                                    _abi.as_ip(n_it)))
+        return SolveResult(out, status, iters, kkt), trace[: int(n_it[0]) + 1]
+
+    def solve_device(self, B, d_x0, d_p, d_x_out, d_status=0, d_iters=0, d_kkt=0, d_obst=0, stream=0):
+        """device pointers (ints, e.g. torch.Tensor.data_ptr()) and a hipStream_t handle (int, 0 = default)."""
+        vp = C.c_void_p
+        self._check(self._lib.mpc_solve_batch_dev(self._h, int(B), vp(d_x0), vp(d_p), vp(d_obst or None), vp(d_x_out),
+                                                  vp(d_status or None), vp(d_iters or None), vp(d_kkt or None), vp(stream or None)))
+
+    def plant_step(self, x, u, integrator="euler"):
+        x = _abi.f64(x)
+        u = _abi.f64(u)
+        single = x.ndim == 1
+        x2 = x.reshape(-1, self.nx)
+        u2 = u.reshape(-1, 2)
+        out = np.empty_like(x2)
+        self._check(self._lib.mpc_plant_step(self._h, x2.shape[0], 0 if integrator == "euler" else 1, _abi.as_dp(x2), _abi.as_dp(u2),
+                                             _abi.as_dp(out)))
+        return out[0] if single else out
+
+    def set_profiling(self, enable=True):
+        self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
+
+    def get_profile(self):
+        out = np.zeros(6)
+        self._check(self._lib.mpc_get_profile(self._h, _abi.as_dp(out)))
+        return dict(riccati_ms=out[0], riccati_launches=int(out[1]), stage_ms=out[2], stage_launches=int(out[3]),
+                    other_ms=out[4], iterations=int(out[5]))
+
+
+__all__ = ["BatchedMPCSolver", "SolveResult", "MpcError", "MpcLibraryError"]

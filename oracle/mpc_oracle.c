@@ -49,6 +49,7 @@ static const double GAMMA_THETA = 1e-5, GAMMA_PHI = 1e-8, LS_DELTA = 1.0, S_THET
 static const double ETA_PHI = 1e-8, GAMMA_ALPHA = 0.05;
 static const double DW_MIN = 1e-20, DW_0 = 1e-4, DW_MAX = 1e40, KW_MINUS = 1.0 / 3.0, KW_PLUS = 8.0, KW_PLUS_BAR = 100.0;
 static const double SCALING_MAX_GRAD = 100.0;
+static const double ROLLOUT_FACTOR = 10.0;
 
 typedef struct {
     double u[NS][NU], x[NS][NX];
@@ -358,10 +359,44 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
 
     iterate_t* it = &W->it;
     eval_t* ev = &W->ev;
-    /* objective scaling at the user's start point */
+    /* start-point safeguard: the caller's state guess is replaced by a forward rollout of the (bound-projected)
+     * control guess when its dynamics defect is more than ROLLOUT_FACTOR x worse (the reference's first MPC
+     * step passes a transposed state guess, SURVEY.md App. C-6, from which an interior-point method jams) */
+    double* xs = (double*)malloc(sizeof(double) * (size_t)(N + 1) * NX);
+    {
+        double xg[NX], xr[NX], f[NX], fr[NX], u[NU], th_g = 0.0, th_r = 0.0;
+        double* roll = (double*)malloc(sizeof(double) * (size_t)(N + 1) * NX);
+        for (int i = 0; i < nx; ++i) {
+            xg[i] = push_in(x0[2 * N + i], pb->lbx[0][i], pb->ubx[0][i]);
+            xr[i] = push_in(pb->r[i], pb->lbx[0][i], pb->ubx[0][i]);
+            th_g += fabs(xg[i] - pb->r[i]);
+            th_r += fabs(xr[i] - pb->r[i]);
+            roll[i] = xr[i];
+        }
+        for (int k = 0; k < N; ++k) {
+            for (int i = 0; i < NU; ++i) u[i] = push_in(x0[2 * k + i], pb->lbu[k][i], pb->ubu[k][i]);
+            mpco_ode(d, xg, u, f);
+            mpco_ode(d, xr, u, fr);
+            for (int i = 0; i < nx; ++i) {
+                const double gn = push_in(x0[2 * N + nx * (k + 1) + i], pb->lbx[k + 1][i], pb->ubx[k + 1][i]);
+                th_g += fabs(gn - (f[i] * d->dt + xg[i]));
+                xg[i] = gn;
+                const double rraw = fr[i] * d->dt + xr[i];
+                const double rn = push_in(rraw, pb->lbx[k + 1][i], pb->ubx[k + 1][i]);
+                th_r += fabs(rn - rraw);
+                xr[i] = rn;
+                roll[(size_t)(k + 1) * NX + i] = rn;
+            }
+        }
+        const int use = !(th_g <= ROLLOUT_FACTOR * fmax(1.0, th_r));
+        for (int k = 0; k <= N; ++k)
+            for (int i = 0; i < nx; ++i) xs[(size_t)k * NX + i] = use ? roll[(size_t)k * NX + i] : x0[2 * N + nx * k + i];
+        free(roll);
+    }
+    /* objective scaling at the start point */
     double gmax = 0.0;
     for (int k = 0; k < N; ++k) {
-        for (int i = 0; i < nx; ++i) gmax = fmax(gmax, fabs(2 * d->Q[i] * (x0[2 * N + nx * k + i] - pb->r[(k + 1) * nx + i])));
+        for (int i = 0; i < nx; ++i) gmax = fmax(gmax, fabs(2 * d->Q[i] * (xs[(size_t)k * NX + i] - pb->r[(k + 1) * nx + i])));
         for (int i = 0; i < NU; ++i) gmax = fmax(gmax, fabs(2 * d->R[i] * x0[2 * k + i]));
     }
     const double df = gmax > SCALING_MAX_GRAD ? SCALING_MAX_GRAD / gmax : 1.0;
@@ -374,11 +409,12 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
                 it->zuu[k][i] = fin(pb->ubu[k][i]) ? 1.0 : 0.0;
             }
         for (int i = 0; i < nx; ++i) {
-            it->x[k][i] = push_in(x0[2 * N + nx * k + i], pb->lbx[k][i], pb->ubx[k][i]);
+            it->x[k][i] = push_in(xs[(size_t)k * NX + i], pb->lbx[k][i], pb->ubx[k][i]);
             it->zlx[k][i] = fin(pb->lbx[k][i]) ? 1.0 : 0.0;
             it->zux[k][i] = fin(pb->ubx[k][i]) ? 1.0 : 0.0;
         }
     }
+    free(xs);
     eval_point(pb, it, ev, 0);
     for (int k = 0; k <= N; ++k)
         for (int j = 0; j < 3; ++j) {
@@ -394,7 +430,7 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
     double filt_th[FILTER_MAX], filt_ph[FILTER_MAX];
     int nfilt = 0;
     double delta_last = 0.0, theta_max = 0, theta_min = 0;
-    int have_theta0 = 0, iter = 0, status = MPCO_MAXITER;
+    int have_theta0 = 0, iter = 0, status = MPCO_MAXITER, conv_seen = 0;
     double E0 = NAN;
     const int iter_cap = d->fixed_iters > 0 ? d->fixed_iters : d->max_iter;
 
@@ -468,6 +504,7 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
         E0 = EMU(0.0);
         if (nanflag || !fin(E0)) { status = MPCO_NAN; break; }
         if (d->fixed_iters <= 0 && E0 <= d->tol) { status = MPCO_CONVERGED; break; }
+        if (d->fixed_iters > 0 && E0 <= d->tol) conv_seen = 1;   /* benchmark mode: keep stepping, accept what comes */
         if (iter >= iter_cap) { status = d->fixed_iters > 0 ? MPCO_CONVERGED : MPCO_MAXITER; break; }
         /* ---------------- barrier parameter */
         int mu_changed = 0;
@@ -721,6 +758,7 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
         else
             a_min = GAMMA_THETA;
         a_min *= GAMMA_ALPHA;
+        if (conv_seen) a_min = 0.0;
         double alpha = a_pr;
         int accepted = 0, ftype = 0, ntrial = 0;
         iterate_t* tr = &W->trial;
@@ -738,7 +776,9 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
             int good = fin(th_t) && fin(ph_t) && th_t <= theta_max;
             for (int q = 0; q < nfilt && good; ++q)
                 if (!(th_t < filt_th[q] || ph_t < filt_ph[q])) good = 0;
-            if (good) {
+            if (good && conv_seen) {
+                accepted = 1; ftype = 1;
+            } else if (good) {
                 const int sw = theta <= theta_min && dphi < 0 && alpha * pow(-dphi, S_PHI) > LS_DELTA * pow(theta, S_THETA);
                 if (sw) {
                     if (ph_t <= phi + ETA_PHI * alpha * dphi) { accepted = 1; ftype = 1; }
@@ -748,6 +788,7 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
             }
             if (accepted) break;
             alpha *= 0.5;
+            if (ntrial >= 64) break;
         }
         if (trace && iter < trace_cap) {
             double* t = trace + (size_t)iter * 8;

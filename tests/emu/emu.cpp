@@ -1,0 +1,138 @@
+// tests/emu/emu.cpp -- CPU emulation harness for the HIP kernels (TEST INFRASTRUCTURE, not shipped).
+//
+// The build container has no GPU.  The per-thread phase functions of the kernels live in
+// <package>/csrc/mpc_stage_math.h as __host__ __device__ code; this harness steps them thread by thread in
+// the same order, with the same block shape, reductions and barriers as mpc_kernels.hip, so that the kernel
+// math can be checked against the oracle in the `-m "not gpu"` test suite.  It is compiled into
+// tests/emu/libmpc_emu.so by tests/emu/build.py and is never loaded by the product package.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../motion-planning-for-autonomous-driving-with-mpc_amd/csrc/mpc_host_common.h"
+
+using namespace mpc;
+
+template <typename R>
+static void reduce_block(std::vector<R>& part, int bx, int S) {
+    // part[k*bx + bl] -> every thread of instance bl gets the combination over k (k ascending, like the
+    // order-independent max/min and the fixed-order sums of the GPU reduction up to rounding)
+    for (int bl = 0; bl < bx; ++bl) {
+        R acc = part[bl];
+        for (int k = 1; k < S; ++k) red_combine(acc, part[(size_t)k * bx + bl]);
+        for (int k = 0; k < S; ++k) part[(size_t)k * bx + bl] = acc;
+    }
+}
+
+template <int NX>
+static int run(const HostProblem& hp, int B, const double* x0, const double* p, const double* obst, double* x_out,
+               int32_t* status, int32_t* iters, double* kkt, double* trace, int trace_rows, int* n_it, int bx_req) {
+    const mpc_problem_desc& d = hp.desc;
+    const int N = d.N, S = N + 1;
+    const size_t Bp = ((size_t)B + 63) / 64 * 64;
+    const int bx = bx_req > 0 ? bx_req : pick_bx(N, 512);
+    const WsLayout w = ws_layout(N, NX, Bp);
+    std::vector<double> ws(w.total, 0.0);
+    std::vector<int32_t> iws(w.itotal, 0);
+    Params P;
+    fill_params(P, hp, B, Bp, bx, ws.data(), iws.data(), hp.LB.data(), hp.UB.data());
+    P.x0 = x0; P.p = p; P.x_out = x_out; P.status_out = status; P.iters_out = iters; P.kkt_out = kkt;
+    if (obst) {
+        P.per_inst_obst = 1;
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < 6; ++i) ws[w.OBST + (size_t)i * Bp + b] = obst[(size_t)b * 6 + i];
+    }
+    const int nblocks = (int)((B + bx - 1) / bx);
+    const int nthreads = S * bx;
+    std::vector<Ctx<NX>> ctx(nthreads);
+    std::vector<Red0> r0(nthreads);
+    std::vector<Red1> r1(nthreads);
+    std::vector<Red2> r2(nthreads);
+    std::vector<Red3> r3(nthreads);
+
+    auto setup = [&](int blk) {
+        for (int t = 0; t < nthreads; ++t) {
+            Ctx<NX>& c = ctx[t];
+            c = Ctx<NX>{};
+            c.k = t / bx;
+            c.b = blk * bx + t % bx;
+            c.valid = c.b < B;
+            if (!c.valid) c.b = (int)Bp - 1;       // padding threads never touch memory (valid == false)
+            c.active = false;
+        }
+    };
+    auto eval_finish = [&]() {
+        for (int t = 0; t < nthreads; ++t) phase_eval_assemble<NX>(P, ctx[t], r3[t]);
+        reduce_block(r3, bx, S);
+        for (int t = 0; t < nthreads; ++t) phase_finish<NX>(P, ctx[t], r3[t], hp.n_mult, hp.n_z);
+    };
+    // ---- start-point safeguard kernel: one instance per thread
+    for (int b = 0; b < B; ++b) prestart_instance<NX>(P, b);
+    // ---- init kernel
+    for (int blk = 0; blk < nblocks; ++blk) {
+        setup(blk);
+        for (int t = 0; t < nthreads; ++t) phase_init_point<NX>(P, ctx[t], r0[t]);
+        reduce_block(r0, bx, S);
+        for (int t = 0; t < nthreads; ++t) phase_init_scalars<NX>(P, ctx[t], r0[t]);
+        eval_finish();
+    }
+    auto record = [&](int it) {
+        if (!trace || it >= trace_rows) return;
+        double* tr = trace + (size_t)it * 8 * B;
+        const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
+        for (int q = 0; q < 8; ++q)
+            for (int b = 0; b < B; ++b) tr[(size_t)q * B + b] = ws[w.SC + (size_t)rows[q] * Bp + b];
+    };
+    int it = 0;
+    const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
+    for (; it < cap; ++it) {
+        int running = 0;
+        for (int b = 0; b < B; ++b) running += iws[(size_t)IS_STATUS * Bp + b] == ST_RUNNING;
+        if (!running) break;
+        // ---- Riccati kernel: one instance per thread
+        for (int b = 0; b < B; ++b) riccati_instance<NX>(P, b);
+        // ---- stage kernel
+        for (int blk = 0; blk < nblocks; ++blk) {
+            setup(blk);
+            bool any = false;
+            for (int t = 0; t < nthreads; ++t) { phase_load_scalars<NX>(P, ctx[t]); any |= ctx[t].active; }
+            if (!any) continue;
+            for (int t = 0; t < nthreads; ++t) phase_step_candidates<NX>(P, ctx[t], r1[t]);
+            reduce_block(r1, bx, S);
+            for (int t = 0; t < nthreads; ++t) phase_linesearch_begin<NX>(P, ctx[t], r1[t]);
+            for (;;) {
+                bool searching = false;
+                for (int t = 0; t < nthreads; ++t) searching |= (ctx[t].active && ctx[t].searching);
+                if (!searching) break;
+                for (int t = 0; t < nthreads; ++t) phase_trial_eval<NX>(P, ctx[t], r2[t]);
+                reduce_block(r2, bx, S);
+                for (int t = 0; t < nthreads; ++t) phase_linesearch_decide<NX>(P, ctx[t], r2[t]);
+            }
+            for (int t = 0; t < nthreads; ++t) phase_apply_update<NX>(P, ctx[t]);
+            eval_finish();
+        }
+        record(it);
+    }
+    record(it);
+    if (n_it) *n_it = it;
+    for (int b = 0; b < B; ++b) output_instance<NX>(P, b);
+    return MPC_OK;
+}
+
+extern "C" int emu_solve_batch(const mpc_problem_desc* desc, const double* lbx, const double* ubx, const double* lbg,
+                               const double* ubg, int32_t B, const double* x0, const double* p, const double* obst,
+                               double* x_out, int32_t* status, int32_t* iters, double* kkt, double* trace,
+                               int32_t trace_rows, int32_t* n_it, int32_t bx) {
+    HostProblem hp;
+    hp.desc = *desc;
+    std::string err;
+    int rc = validate_desc(hp.desc, err);
+    if (rc) return rc;
+    rc = set_bounds(hp, lbx, ubx, lbg, ubg, err);
+    if (rc) return rc;
+    if (desc->nx == 5) return run<5>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
+    return run<6>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
+}
+
+extern "C" void emu_default_desc(mpc_problem_desc* d, int32_t N, int32_t nx) { default_desc(d, N, nx); }

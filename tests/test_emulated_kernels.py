@@ -1,0 +1,85 @@
+"""CPU: the per-thread phase functions of the HIP kernels (csrc/mpc_stage_math.h), stepped by the emulation
+harness tests/emu with the kernels' block shape / reductions, against the oracle and the golden optima."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CA_CFG, FAMILIES, ca_batch, cfg_from_golden, emu_solve
+from oracle.binding import OracleSolver
+from oracle.nlp_numpy import BicycleNLP, synthetic_batch
+
+
+@pytest.mark.parametrize("fam", list(FAMILIES))
+def test_emulated_kernels_match_oracle(fam):
+    cfg, kw = FAMILIES[fam]
+    x0, p = synthetic_batch(cfg, 48, **kw)
+    re = emu_solve(cfg, x0, p)
+    ro = OracleSolver(cfg).solve_batch(x0, p)
+    assert np.all(re["status"] == 1) and np.all(ro["status"] == 1)
+    assert np.array_equal(re["iters"], ro["iters"])
+    assert np.abs(re["x"] - ro["x"]).max() < 1e-11
+    assert re["kkt"].max() <= 1e-8
+
+
+@pytest.mark.parametrize("bx", [8, 16, 32, 64])
+def test_block_shape_invariance(bx):
+    """instances-per-workgroup only changes how the stage reductions are grouped"""
+    cfg, kw = FAMILIES["zamlf_n10_nx5"]
+    x0, p = synthetic_batch(cfg, 70, **kw)     # ragged: not a multiple of any bx
+    ref = emu_solve(cfg, x0, p, bx=16)
+    r = emu_solve(cfg, x0, p, bx=bx)
+    assert np.array_equal(r["iters"], ref["iters"])
+    assert np.abs(r["x"] - ref["x"]).max() < 1e-12
+
+
+def test_emulated_kernels_match_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nlp_optima.npz"))
+    for fam in ("zamlf_n30_nx6", "first_n10_nx5", "usalf_n50_nx5"):
+        cfg = cfg_from_golden(g[f"{fam}__cfg"])
+        r = emu_solve(cfg, g[f"{fam}__x0"], g[f"{fam}__p"])
+        assert np.all(r["status"] == 1)
+        assert np.abs(r["x"] - g[f"{fam}__w"]).max() < 2e-6
+
+
+def test_fixed_iteration_mode():
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 32, **kw)
+    rf = emu_solve(cfg, x0, p, fixed_iters=20)
+    rc = emu_solve(cfg, x0, p)
+    assert np.all(rf["iters"] == 20) and np.all(rf["status"] == 1)
+    assert np.abs(rf["x"] - rc["x"]).max() < 1e-5
+
+
+def test_collision_avoidance_family():
+    x0, p = ca_batch(CA_CFG, 16)
+    re = emu_solve(CA_CFG, x0, p)
+    ro = OracleSolver(CA_CFG).solve_batch(x0, p)
+    both = (re["status"] == 1) & (ro["status"] == 1)
+    assert both.mean() >= 0.8
+    assert np.abs(re["x"][both] - ro["x"][both]).max() < 1e-4
+    # every converged trajectory keeps the three circle pairs apart
+    nlp = BicycleNLP(CA_CFG)
+    for w in re["x"][re["status"] == 1]:
+        _, X = nlp.split(w)
+        assert min(nlp.obstacle_rows(x)[0].min() for x in X) >= CA_CFG.r_sum - 1e-6
+
+
+def test_per_instance_obstacles_equal_shared():
+    x0, p = ca_batch(CA_CFG, 8)
+    shared = emu_solve(CA_CFG, x0, p)
+    obst = np.tile(CA_CFG.obstacle_centers.ravel(), (8, 1))
+    per = emu_solve(CA_CFG, x0, p, obst=obst)
+    assert np.array_equal(shared["x"], per["x"])
+
+
+def test_trace_matches_oracle_trace():
+    cfg, kw = FAMILIES["zamlf_n30_nx5"]
+    x0, p = synthetic_batch(cfg, 4, **kw)
+    re = emu_solve(cfg, x0, p)
+    for b in range(4):
+        ro = OracleSolver(cfg).solve(x0[b], p[b], trace=True)
+        n = ro["iters"]
+        # rows: mu, theta, phi, alpha, alpha_dual, delta_w, E0, n_trials
+        assert np.allclose(re["trace"][:n, 3, b], ro["trace"][:n, 3], rtol=1e-9, atol=1e-12)   # alpha
+        assert np.allclose(re["trace"][:n, 4, b], ro["trace"][:n, 4], rtol=1e-9, atol=1e-12)   # alpha_dual
