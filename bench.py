@@ -164,10 +164,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.binding import OracleSolver
         osol = OracleSolver(cfg)
-        cores = os.cpu_count() or 1
-        xs, ps = synthetic_batch(cfg, 2048)
-        osol.solve_batch(xs[:64], ps[:64], nthreads=cores)                # warm the thread pool
-        reps = 6
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        xs, ps = synthetic_batch(cfg, 4096)
+        best = None
+        for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances; keep the best count
+            osol.solve_batch(xs[:256], ps[:256], nthreads=cores)          # warm the thread pool
+            t0 = time.perf_counter()
+            ro = osol.solve_batch(xs, ps, nthreads=cores)
+            t = time.perf_counter() - t0
+            if best is None or t < best[1]:
+                best = (cores, t)
+        cores = best[0]
+        reps = max(1, int(round(3.0 / best[1])))                            # ~3 s wall on the chosen thread count
         t0 = time.perf_counter()
         for _ in range(reps):
             ro = osol.solve_batch(xs, ps, nthreads=cores)
@@ -182,9 +190,9 @@ def main():
         except Exception:
             pass
         cpu_baseline = dict(value=reps * len(xs) / t_all, unit="MPC steps/s", cores=cores, kind="port",
-                            sample=f"{reps} x 2048 instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
+                            sample=f"{reps} x 4096 instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
                                    f"OpenMP over instances, all converged={bool((ro['status'] == 1).all())}",
-                            single_thread_value=1024 / t_one, cpu_model=model,
+                            single_thread_value=1024 / t_one, cpu_model=model, host_cpus=avail,
                             published_casadi_ipopt="25.1 steps/s (N=10, 1 instance, unknown CPU; BASELINE.md section 1)")
 
     if rank == 0:

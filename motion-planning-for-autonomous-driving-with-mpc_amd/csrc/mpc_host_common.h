@@ -83,7 +83,7 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
             if (lo == hi) { snprintf(buf, sizeof buf, "lbx == ubx at %zu: fixed variables are not supported", src); err = buf; return MPC_ERR_BOUNDS; }
             hp.LB[(size_t)k * NZ + i] = relax_lo(lo);
             hp.UB[(size_t)k * NZ + i] = relax_hi(hi);
-            nb += (int)std::isfinite(lo) + (int)std::isfinite(hi);
+            if (!(k == 0 && i == 1)) nb += (int)std::isfinite(lo) + (int)std::isfinite(hi);   // a_0: counted per instance
         }
     // g rows: [friction | nx(N+1) equalities | 9(N+1) obstacle rows]  (optimizer.py:421-469)
     const double flo = lbg[0], fhi = ubg[0];
@@ -101,8 +101,9 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
     hp.has_ol = std::isfinite(olo); hp.has_ou = std::isfinite(ohi);
     hp.ol = relax_lo(olo); hp.ou = relax_hi(ohi);
     const int m = d.obst_mult;
-    hp.n_mult = nx * (N + 1) + 3 * m * (N + 1) + 1;
-    hp.n_z = nb + 3 * m * (N + 1) * (hp.has_ol + hp.has_ou) + hp.has_fl + hp.has_fu;
+    // per-instance parts (friction row or its presolved bound on a_0) are added in phase_finish()
+    hp.n_mult = nx * (N + 1) + 3 * m * (N + 1);
+    hp.n_z = nb + 3 * m * (N + 1) * (hp.has_ol + hp.has_ou);
     hp.bounds_set = true;
     return MPC_OK;
 }

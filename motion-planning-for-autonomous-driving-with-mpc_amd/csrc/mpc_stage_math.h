@@ -41,6 +41,11 @@ constexpr int FILTER_MAX = 32;
 constexpr int ST_RUNNING = 99;          // internal status while iterating
 constexpr double BIG = 1e300;
 constexpr double ROLLOUT_FACTOR = 10.0;   // start-point safeguard, see prestart_instance()
+// constraint violations (1-norm) below this are round-off, two orders under the 1e-8 feasibility tolerance: the
+// theta comparisons of the filter line search clamp at this floor (noise ~1e-12 would otherwise reject the last
+// Newton steps, which only reduce the dual infeasibility)
+constexpr double THETA_FLOOR = 1e-10;
+constexpr double EPS10 = 10.0 * 2.220446049250313e-16;
 
 // ---- per-instance scalar rows ----------------------------------------------------------------------------
 enum ScRow {
@@ -48,9 +53,10 @@ enum ScRow {
     SC_SF, SC_NUF, SC_ZLF, SC_ZUF, SC_DFRIC, SC_GFR0, SC_GFR1, SC_GFR2, SC_HUX0, SC_HUX1,
     SC_C0,                       // 6 rows: c_0 = x_0 - r_0
     SC_ALPHA = SC_C0 + 6, SC_ADU, SC_PHI, SC_NTRIAL,
+    SC_A0LB, SC_A0UB,            // per-instance bounds of a_0 (stage-0 friction row presolved into a bound)
     SC_COUNT
 };
-enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_COUNT };
+enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW, IS_COUNT };
 
 struct Params {
     int32_t B, Bp, N, nx, bx;    // instances, padded instances (multiple of 64), horizon, states, instances/block
@@ -136,6 +142,9 @@ MPC_HD double push_in(double v, double lo, double hi) {
     return v;
 }
 
+// IPOPT's Compare_le (IpUtils.cpp): lhs <= rhs up to 10 machine epsilons of a reference magnitude
+MPC_HD bool cmp_le(double lhs, double rhs, double base) { return lhs - rhs <= EPS10 * fabs(base); }
+
 MPC_HD double zreset(double z, double gap, double mu) {
     const double lo = mu / (KAPPA_SIGMA * gap), hi = KAPPA_SIGMA * mu / gap;
     return fmin(fmax(z, lo), hi);
@@ -161,12 +170,18 @@ struct Ctx {
     double a_pr, a_du, dphi, alpha, a_min;
     int nfilt, ntrial, iters, status;
     bool searching, accepted, ftype;
+    bool fric_row;   // stage-0 friction row kept as a row (false: presolved into the bounds a0lb/a0ub of a_0)
+    double a0lb, a0ub;
     bool conv;       // fixed-iteration (benchmark) mode: tolerance already reached, steps are accepted as they come
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
 
 #define MPC_AT(ptr, row) (ptr)[(size_t)(row) * (size_t)P.Bp + (size_t)c.b]
+// bounds of variable i of stage k; a_0 (k = 0, i = 1) carries the per-instance presolved friction bound
+#define MPC_BOUNDS(k, i, lb, ub)                                    \
+    double lb = P.LB[(k) * NZ + (i)], ub = P.UB[(k) * NZ + (i)];    \
+    if ((k) == 0 && (i) == 1) { lb = c.a0lb; ub = c.a0ub; }
 
 // ---- model pieces ----------------------------------------------------------------------------------------
 // kinematic single-track ODE, configuration.py:353-368
@@ -257,6 +272,26 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
     const double* x0b = P.x0 + bb * nw;
     const double* pb = P.p + bb * nw;
+    // presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
+    // by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
+    // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
+    // start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
+    double a0lb = P.LB[1], a0ub = P.UB[1];
+    int frow = 1;
+    if (!P.has_fl && P.has_fu) {
+        const double dl0 = pb[2 * N + 2], v0 = pb[2 * N + 3];
+        const double cf = v0 * (tan(dl0) * v0 / P.friction_div);
+        const double Rhi = P.fu - cf, Rlo = -P.fu - cf;
+        if (Rhi > 0.0 && Rlo <= 0.0) {
+            const double amax = sqrt(Rhi);
+            a0lb = fmax(a0lb, -amax);
+            a0ub = fmin(a0ub, amax);
+            frow = 0;
+        }
+    }
+    P.SC[(size_t)SC_A0LB * Bp + bb] = a0lb;
+    P.SC[(size_t)SC_A0UB * Bp + bb] = a0ub;
+    P.ISC[(size_t)IS_FROW * Bp + bb] = frow;
     double xg[NX], xr[NX], f[NX], u[2], s, c, td;
     double th_g = 0.0, th_r = 0.0;
 #pragma unroll
@@ -270,7 +305,7 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     }
     for (int k = 0; k < N; ++k) {
         u[0] = push_in(x0b[2 * k], P.LB[k * NZ], P.UB[k * NZ]);
-        u[1] = push_in(x0b[2 * k + 1], P.LB[k * NZ + 1], P.UB[k * NZ + 1]);
+        u[1] = push_in(x0b[2 * k + 1], (k == 0) ? a0lb : P.LB[k * NZ + 1], (k == 0) ? a0ub : P.UB[k * NZ + 1]);
         double fr[NX];
         ode_eval<NX>(P, xg, u, f, s, c, td);
         ode_eval<NX>(P, xr, u, fr, s, c, td);
@@ -305,6 +340,9 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     const double* x0b = P.x0 + (size_t)c.b * nw;
     const double* pb = P.p + (size_t)c.b * nw;
     load_obst(P, c);
+    c.fric_row = MPC_AT(P.ISC, IS_FROW) != 0;
+    c.a0lb = MPC_AT(P.SC, SC_A0LB);
+    c.a0ub = MPC_AT(P.SC, SC_A0UB);
     const bool roll = MPC_AT(P.ISC, IS_ROLL) != 0;
     double gmax = 0.0;
 #pragma unroll
@@ -315,6 +353,7 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
             raw = isu ? x0b[2 * k + i] : (roll ? MPC_AT(P.ROLL, k * NX + (i - 2)) : x0b[2 * N + NX * k + (i - 2)]);
             lb = P.LB[k * NZ + i];
             ub = P.UB[k * NZ + i];
+            if (k == 0 && i == 1) { lb = c.a0lb; ub = c.a0ub; }
         }
         if (k < N) {
             // |grad f| at the user's start point (objective scaling, IPOPT section 3.8)
@@ -353,12 +392,18 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     }
     if (k == 0) {
         const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
-        const double dfr = friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false);
-        c.sf = push_in(dfr, fl, fu);
+        const double dfr = c.fric_row ? friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false) : 0.0;
+        c.sf = c.fric_row ? push_in(dfr, fl, fu) : 0.0;
         MPC_AT(P.SC, SC_SF) = c.sf;
         MPC_AT(P.SC, SC_NUF) = 0.0;
-        MPC_AT(P.SC, SC_ZLF) = P.has_fl ? 1.0 : 0.0;
-        MPC_AT(P.SC, SC_ZUF) = P.has_fu ? 1.0 : 0.0;
+        MPC_AT(P.SC, SC_ZLF) = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
+        MPC_AT(P.SC, SC_ZUF) = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
+        MPC_AT(P.SC, SC_DFRIC) = 0.0;
+        MPC_AT(P.SC, SC_GFR0) = 0.0;
+        MPC_AT(P.SC, SC_GFR1) = 0.0;
+        MPC_AT(P.SC, SC_GFR2) = 0.0;
+        MPC_AT(P.SC, SC_HUX0) = 0.0;
+        MPC_AT(P.SC, SC_HUX1) = 0.0;
     }
     red.gmax = gmax;
 }
@@ -411,6 +456,9 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
     c.nfilt = MPC_AT(P.ISC, IS_NFILT);
     c.iters = MPC_AT(P.ISC, IS_ITERS);
     c.conv = P.fixed_iters > 0 && MPC_AT(P.ISC, IS_CONV) != 0;
+    c.fric_row = MPC_AT(P.ISC, IS_FROW) != 0;
+    c.a0lb = MPC_AT(P.SC, SC_A0LB);
+    c.a0ub = MPC_AT(P.SC, SC_A0UB);
     if (!MPC_AT(P.ISC, IS_HAVETH0)) {      // first iteration: theta_max / theta_min from theta(w_0)
         c.thmax = 1e4 * fmax(1.0, c.theta);
         c.thmin = 1e-4 * fmax(1.0, c.theta);
@@ -437,7 +485,7 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         c.z[i] = zi;
         c.dz[i] = dv;
         if (isu && k == N) continue;
-        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        MPC_BOUNDS(k, i, lb, ub);
         double gradf = 0.0;
         if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
         double gb = 0.0;
@@ -491,7 +539,7 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     }
     c.sf = 0.0;
     c.dsf = 0.0;
-    if (k == 0) {
+    if (k == 0 && c.fric_row) {
         const double s = MPC_AT(P.SC, SC_SF);
         const double ds = MPC_AT(P.SC, SC_DFRIC) - s + MPC_AT(P.SC, SC_GFR0) * c.dz[1] + MPC_AT(P.SC, SC_GFR1) * c.dz[2 + 2] +
                           MPC_AT(P.SC, SC_GFR2) * c.dz[2 + 3];
@@ -561,7 +609,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         const double v = c.z[i] + al * c.dz[i];
         c.zt[i] = v;
         if (isu && k == N) continue;
-        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        MPC_BOUNDS(k, i, lb, ub);
         if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else ls += log(gap); }
         if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else ls += log(gap); }
         if (k < N) {
@@ -592,7 +640,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
         if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
     }
-    if (k == 0) {
+    c.sft = 0.0;
+    if (k == 0 && c.fric_row) {
         const double s = c.sf + al * c.dsf;
         c.sft = s;
         const double dfr = friction_eval(P, c.zt[1], c.zt[2 + 2], c.zt[2 + 3], nullptr, nullptr, false);
@@ -616,7 +665,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
     bool good = isfinite(th_t) && isfinite(ph_t) && th_t <= c.thmax;
     for (int q = 0; q < c.nfilt && good; ++q) {
         const double tf = MPC_AT(P.FILT, 2 * q), pf = MPC_AT(P.FILT, 2 * q + 1);
-        if (!(th_t < tf || ph_t < pf)) good = false;
+        if (!(cmp_le(fmax(th_t, THETA_FLOOR), fmax(tf, THETA_FLOOR), tf) || cmp_le(ph_t, pf, pf))) good = false;
     }
     if (good && c.conv) {
         c.accepted = true;
@@ -624,8 +673,9 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
     } else if (good) {
         const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha * pow(-c.dphi, S_PHI) > LS_DELTA * pow(c.theta, S_THETA);
         if (sw) {
-            if (ph_t <= c.phi + ETA_PHI * c.alpha * c.dphi) { c.accepted = true; c.ftype = true; }
-        } else if (th_t <= (1 - GAMMA_THETA) * c.theta || ph_t <= c.phi - GAMMA_PHI * c.theta) {
+            if (cmp_le(ph_t - c.phi, ETA_PHI * c.alpha * c.dphi, c.phi)) { c.accepted = true; c.ftype = true; }
+        } else if (cmp_le(fmax(th_t, THETA_FLOOR), fmax((1 - GAMMA_THETA) * c.theta, THETA_FLOOR), c.theta) ||
+                   cmp_le(ph_t - c.phi, -GAMMA_PHI * c.theta, c.phi)) {
             c.accepted = true;
         }
     }
@@ -655,7 +705,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         if (i < 2 && k == N) continue;
-        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
         MPC_AT(P.Z, k * NZ + i) = zn;
         if (has_lo(lb)) {
@@ -703,7 +753,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         MPC_AT(P.SO, k * 3 + j) = sn;
         c.so[j] = sn;
     }
-    if (k == 0) {
+    if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
@@ -722,6 +772,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         MPC_AT(P.SC, SC_NUF) = nu + al * (gb - nu + sg * ds);
         MPC_AT(P.SC, SC_SF) = sn;
         c.sf = sn;
+    }
+    if (k == 0) {
         // filter augmentation (h-type iteration) and bookkeeping
         if (!c.ftype) {
             int nf = c.nfilt;
@@ -841,7 +893,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
         if (isu && k == N) continue;
-        const double lb = P.LB[k * NZ + i], ub = P.UB[k * NZ + i];
+        MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i];
         double sg = 0.0, gbb = 0.0, rz = 0.0;
         if (has_lo(lb)) {
@@ -901,8 +953,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
             for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += m * (nu * Ho[6 * j + q] + sg * ja * J[3 * j + bq]);
         }
     }
-    // friction row (stage 0)
-    if (k == 0) {
+    // friction row (stage 0), unless presolved into the bounds of a_0
+    if (k == 0 && c.fric_row) {
         double g[3], h[4];
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
         const double s = c.sf, nu = MPC_AT(P.SC, SC_NUF);
@@ -976,6 +1028,9 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
     using D = Dim<NX>;
     if (!c.active) return;
     const int k = c.k;
+    // host counts exclude the friction row and the bounds of a_0, which are per instance
+    n_mult += c.fric_row ? 1 : 0;
+    n_z += (has_lo(c.a0lb) ? 1 : 0) + (has_hi(c.a0ub) ? 1 : 0) + (c.fric_row ? (P.has_fl + P.has_fu) : 0);
     const int nden = n_mult + n_z;
     const double s_d = fmax(S_MAX, (red.sum_mult + red.sum_z) / (nden > 0 ? nden : 1)) / S_MAX;
     const double s_c = fmax(S_MAX, red.sum_z / (n_z > 0 ? n_z : 1)) / S_MAX;

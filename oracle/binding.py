@@ -75,9 +75,10 @@ def _pi(a):
     return a.ctypes.data_as(_ip)
 
 
-def make_desc(cfg: NLPConfig, max_iter=100, tol=1e-8, fixed_iters=0, obst_mult=3) -> MpcoDesc:
+def make_desc(cfg: NLPConfig, max_iter=100, tol=1e-8, fixed_iters=0, obst_mult=3, literal_friction_row=False) -> MpcoDesc:
     d = MpcoDesc()
     d.N, d.nx, d.obst_mult, d.max_iter, d.fixed_iters = cfg.N, cfg.nx, obst_mult, max_iter, fixed_iters
+    d.reserved = 1 if literal_friction_row else 0
     d.dt, d.wheelbase, d.friction_div, d.ego_offset = cfg.dt, cfg.wheelbase, cfg.friction_div, cfg.ego_offset
     for i, q in enumerate(cfg.Qdiag):
         d.Q[i] = q

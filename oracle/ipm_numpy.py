@@ -47,6 +47,14 @@ STATUS_MAXITER = 0
 STATUS_NAN = -6
 STATUS_NOPROGRESS = -7
 
+_EPS10 = 10.0 * np.finfo(np.float64).eps
+THETA_FLOOR = 1e-10     # constraint violation below this is round-off (see oracle/mpc_oracle.c)
+
+
+def _cmp_le(lhs, rhs, base):
+    """IPOPT's Compare_le (IpUtils.cpp): lhs <= rhs up to 10 eps of a reference magnitude"""
+    return lhs - rhs <= _EPS10 * abs(base)
+
 
 def _push(x, lo, hi, k1, k2):
     """IPOPT section 3.6: project the start point into the interior of its bounds."""
@@ -257,17 +265,18 @@ class DenseIPM:
                 good = np.isfinite(th_t) and np.isfinite(ph_t) and th_t <= theta_max
                 if good:
                     for (tf, pf) in filt:
-                        if not (th_t < tf or ph_t < pf):
+                        if not (_cmp_le(max(th_t, THETA_FLOOR), max(tf, THETA_FLOOR), tf) or _cmp_le(ph_t, pf, pf)):
                             good = False
                             break
                 if good:
                     switching = (theta <= theta_min and dphi < 0 and
                                  alpha * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"])
                     if switching:
-                        if ph_t <= phi + o["eta_phi"] * alpha * dphi:
+                        if _cmp_le(ph_t - phi, o["eta_phi"] * alpha * dphi, phi):
                             accepted, ftype = True, True
                     else:
-                        if th_t <= (1 - o["gamma_theta"]) * theta or ph_t <= phi - o["gamma_phi"] * theta:
+                        if (_cmp_le(max(th_t, THETA_FLOOR), max((1 - o["gamma_theta"]) * theta, THETA_FLOOR), theta)
+                                or _cmp_le(ph_t - phi, -o["gamma_phi"] * theta, phi)):
                             accepted = True
                 if accepted:
                     break

@@ -30,6 +30,7 @@
  */
 #include "mpc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,6 +51,10 @@ static const double ETA_PHI = 1e-8, GAMMA_ALPHA = 0.05;
 static const double DW_MIN = 1e-20, DW_0 = 1e-4, DW_MAX = 1e40, KW_MINUS = 1.0 / 3.0, KW_PLUS = 8.0, KW_PLUS_BAR = 100.0;
 static const double SCALING_MAX_GRAD = 100.0;
 static const double ROLLOUT_FACTOR = 10.0;
+/* constraint violations (1-norm) below this are round-off: two orders under the 1e-8 feasibility tolerance.  The
+ * theta-comparisons of the filter line search clamp at this floor, otherwise noise in theta ~ 1e-12 rejects
+ * the last Newton steps that only reduce the dual infeasibility. */
+static const double THETA_FLOOR = 1e-10;
 
 typedef struct {
     double u[NS][NU], x[NS][NX];
@@ -76,6 +81,7 @@ typedef struct {
     int N, nx;
     double lbu[NS][NU], ubu[NS][NU], lbx[NS][NX], ubx[NS][NX];
     int has_fl, has_fu, has_ol, has_ou;
+    int fric_row;              /* 0: the stage-0 friction row was presolved into bounds on a_0 */
     double fl, fu, ol, ou;
     const double* r;           /* X_ref, [N+1][nx] */
     const mpco_desc* d;
@@ -92,6 +98,9 @@ typedef struct {
 } work_t;
 
 static inline int fin(double v) { return isfinite(v); }
+/* IPOPT's Compare_le: lhs <= rhs up to 10 machine epsilons of a reference magnitude (round-off safeguard
+ * of the acceptance tests, IpUtils.cpp) */
+static inline int cmp_le(double lhs, double rhs, double base) { return lhs - rhs <= 10.0 * DBL_EPSILON * fabs(base); }
 
 /* ------------------------------------------------------------------------------------------------ model */
 void mpco_ode(const mpco_desc* d, const double* x, const double* u, double* f) {
@@ -211,7 +220,13 @@ static void eval_point(const prob_t* pb, const iterate_t* it, eval_t* ev, int de
         if (derivs) ode_jac(d, it->x[k], ev->fx[k]);
     }
     for (int k = 0; k <= N; ++k) obstacle_eval(d, it->x[k], ev->dobs[k], ev->jo[k], ev->ho[k], derivs);
-    ev->dfric = friction_eval(d, it->u[0], it->x[0], ev->gfr, ev->hfr, derivs);
+    if (pb->fric_row) {
+        ev->dfric = friction_eval(d, it->u[0], it->x[0], ev->gfr, ev->hfr, derivs);
+    } else {
+        ev->dfric = 0.0;
+        memset(ev->gfr, 0, sizeof(ev->gfr));
+        memset(ev->hfr, 0, sizeof(ev->hfr));
+    }
     ev->fcost = fc;
 }
 
@@ -352,6 +367,22 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
     pb->has_fl = fin(d->fric_lo) && d->fric_lo > 0.0;      /* |y| >= lo <= 0 is vacuous */
     pb->has_fu = fin(d->fric_hi);
     pb->fl = relax_lo(d->fric_lo); pb->fu = relax_hi(d->fric_hi);
+    pb->fric_row = 1;
+    if (!d->reserved && !pb->has_fl && pb->has_fu) {
+        /* presolve: x_0 is pinned to r_0 by the equality rows, so |a_0^2 + c| <= fu with c = v_0^2 tan(delta_0)/kappa
+         * evaluated at r_0 is the simple bound a_0^2 <= fu - c (valid when also -fu - c <= 0, i.e. the lower branch
+         * of the absolute value cannot bind).  The row has zero gradient at the usual warm start a_0 = 0, which
+         * an SQP/IPM linearisation cannot see; the bound form is exact and has the same KKT points. */
+        const double cf = pb->r[3] * (tan(pb->r[2]) * pb->r[3] / d->friction_div);
+        const double Rhi = pb->fu - cf, Rlo = -pb->fu - cf;
+        if (Rhi > 0.0 && Rlo <= 0.0) {
+            const double amax = sqrt(Rhi);
+            pb->lbu[0][1] = fmax(pb->lbu[0][1], -amax);
+            pb->ubu[0][1] = fmin(pb->ubu[0][1], amax);
+            pb->fric_row = 0;
+            pb->has_fu = 0;
+        }
+    }
     pb->has_ol = fin(d->obst_lo); pb->has_ou = fin(d->obst_hi);
     pb->ol = relax_lo(d->obst_lo); pb->ou = relax_hi(d->obst_hi);
     const double fsl = pb->has_fl ? pb->fl : -INFINITY, fsu = pb->has_fu ? pb->fu : INFINITY;
@@ -495,7 +526,7 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
         kk.dual_inf = fmax(kk.dual_inf, fabs(-it->nuf - it->zlf + it->zuf));
         kk.prim_inf = fmax(kk.prim_inf, fabs(ev->dfric - it->sf));
         kk.sum_mult += fabs(it->nuf);
-        kk.n_mult += 1;
+        kk.n_mult += pb->fric_row;
         FOR_BOUND(it->sf, fsl, fsu, it->zlf, it->zuf, acc_compl(&kk, gap, z, 1), acc_compl(&kk, gap, z, 1));
         const int nden = kk.n_mult + kk.n_z;
         const double s_d = fmax(S_MAX, (kk.sum_mult + kk.sum_z) / (nden > 0 ? nden : 1)) / S_MAX;
@@ -775,14 +806,15 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
             ++ntrial;
             int good = fin(th_t) && fin(ph_t) && th_t <= theta_max;
             for (int q = 0; q < nfilt && good; ++q)
-                if (!(th_t < filt_th[q] || ph_t < filt_ph[q])) good = 0;
+                if (!(cmp_le(fmax(th_t, THETA_FLOOR), fmax(filt_th[q], THETA_FLOOR), filt_th[q]) || cmp_le(ph_t, filt_ph[q], filt_ph[q]))) good = 0;
             if (good && conv_seen) {
                 accepted = 1; ftype = 1;
             } else if (good) {
                 const int sw = theta <= theta_min && dphi < 0 && alpha * pow(-dphi, S_PHI) > LS_DELTA * pow(theta, S_THETA);
                 if (sw) {
-                    if (ph_t <= phi + ETA_PHI * alpha * dphi) { accepted = 1; ftype = 1; }
-                } else if (th_t <= (1 - GAMMA_THETA) * theta || ph_t <= phi - GAMMA_PHI * theta) {
+                    if (cmp_le(ph_t - phi, ETA_PHI * alpha * dphi, phi)) { accepted = 1; ftype = 1; }
+                } else if (cmp_le(fmax(th_t, THETA_FLOOR), fmax((1 - GAMMA_THETA) * theta, THETA_FLOOR), theta) ||
+                           cmp_le(ph_t - phi, -GAMMA_PHI * theta, phi)) {
                     accepted = 1;
                 }
             }

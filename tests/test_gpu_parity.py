@@ -45,7 +45,8 @@ def test_matches_golden_optima(golden_dir, fam):
     set_cfg_bounds(s, cfg)
     r = s.solve(g[f"{fam}__x0"], g[f"{fam}__p"])
     assert np.all(r.status == 1)
-    assert np.abs(r.x - g[f"{fam}__w"]).max() < TOL_GOLDEN
+    tol = np.maximum(TOL_GOLDEN, 2 * g[f"{fam}__dtc"])[:, None]      # scipy's own accuracy per instance
+    assert np.all(np.abs(r.x - g[f"{fam}__w"]) <= tol)
 
 
 @pytest.mark.parametrize("B", [1, 2, 15, 16, 17, 63, 64, 65, 130])
@@ -77,8 +78,10 @@ def test_full_size_batch_properties():
     lbg, ubg, lbx, ubx = BicycleNLP(cfg).bounds()
     for b in range(0, B, 97):
         g = o.constraints(r.x[b], p[b])
-        assert np.all(g >= lbg - 1e-7) and np.all(g <= ubg + 1e-7)
-        assert np.all(r.x[b] >= lbx - 1e-7) and np.all(r.x[b] <= ubx + 1e-7)
+        # IPOPT relaxes every bound by 1e-8 * max(1, |bound|) (bound_relax_factor); allow that plus round-off
+        tol_g = 2e-8 * np.maximum(1.0, np.abs(np.where(np.isfinite(ubg), ubg, lbg))) + 1e-9
+        assert np.all(g >= lbg - tol_g) and np.all(g <= ubg + tol_g)
+        assert np.all(r.x[b] >= lbx - 1e-6) and np.all(r.x[b] <= ubx + 1e-6)
     ro = o.solve_batch(x0[::64], p[::64], nthreads=8)
     assert np.abs(r.x[::64] - ro["x"]).max() < TOL_ORACLE
 
@@ -131,7 +134,7 @@ def test_trace_matches_oracle():
         ro = OracleSolver(cfg).solve(x0[b], p[b], trace=True)
         n = ro["iters"]
         assert np.allclose(tr[:n, 3, b], ro["trace"][:n, 3], rtol=1e-9, atol=1e-12)      # primal step lengths
-        assert np.allclose(tr[:n, 0, b][1:], ro["trace"][1:n, 0], rtol=1e-12)           # barrier parameter
+        assert np.allclose(tr[:n - 1, 0, b], ro["trace"][1:n, 0], rtol=1e-12)          # barrier parameter (row it = mu of it+1)
 
 
 def test_bounds_errors_and_last_error():

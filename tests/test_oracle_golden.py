@@ -25,12 +25,13 @@ def test_oracle_matches_scipy_optima(optima, fam):
     osol = OracleSolver(cfg)
     X0, P, W, F, DTC = (optima[f"{fam}__{k}"] for k in ("x0", "p", "w", "f", "dtc"))
     assert DTC.max() < 5e-5, "the two scipy solvers must agree with each other"
-    for x0, p, w, f in zip(X0, P, W, F):
+    for x0, p, w, f, dtc in zip(X0, P, W, F, DTC):
         r = osol.solve(x0, p)
         assert r["status"] == 1
         assert r["kkt"] <= 1e-8
         assert abs(r["f"] - f) <= 1e-7 * max(1.0, abs(f))
-        assert np.abs(r["x"] - w).max() <= 2e-6
+        # scipy's own accuracy: the two scipy solvers differ from each other by `dtc` on this instance
+        assert np.abs(r["x"] - w).max() <= max(2e-6, 2 * dtc)
 
 
 def test_first_step_brakes_at_friction_cap(optima):
@@ -49,7 +50,7 @@ def test_dense_literal_ipm_equals_riccati_oracle():
     for b in range(3):
         x0, p = synthetic_instance(cfg, b)
         rd = DenseIPM(nlp).solve(x0, p, lbg=lbg)
-        rc = OracleSolver(cfg).solve(x0, p)
+        rc = OracleSolver(cfg, literal_friction_row=True).solve(x0, p)
         assert rd["status"] == 1 and rc["status"] == 1 and rd["iters"] == rc["iters"]
         assert np.abs(rd["x"] - rc["x"]).max() < 1e-11
 
