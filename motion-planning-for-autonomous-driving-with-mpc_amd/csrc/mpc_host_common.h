@@ -108,10 +108,15 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
     return MPC_OK;
 }
 
-// ---- workspace: one allocation of doubles + one of int32 -------------------------------------------------
+// ---- workspace: one allocation of doubles + one of int32, tile-major [tile of 64 instances][row][64 lanes] --------
+// WsLayout members are ROW offsets inside a tile; element(row, b) = (b >> 6) * tile_elems + row * 64 + (b & 63).
 struct WsLayout {
-    size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, EV, ROLL, SC, FILT, OBST, total;
-    size_t itotal;
+    size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, EV, ROLL, SC, FILT, OBST;
+    size_t rows, irows;          // rows per tile (double / int32 workspace)
+    size_t tile_elems, itile_elems, ntiles;
+    size_t total, itotal;        // elements to allocate
+    size_t elem(size_t row0, size_t row, size_t b) const { return (b >> 6) * tile_elems + (row0 + row) * 64 + (b & 63); }
+    size_t ielem(size_t row, size_t b) const { return (b >> 6) * itile_elems + row * 64 + (b & 63); }
 };
 
 inline WsLayout ws_layout(int N, int nx, size_t Bp) {
@@ -119,14 +124,19 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     const size_t NBLK = NS + 10 + 2 * nx, NPK = NS + nx, NKK = 2 * nx + 2;
     WsLayout w{};
     size_t off = 0;
-    auto take = [&](size_t rows) { const size_t o = off; off += rows * Bp; return o; };
+    auto take = [&](size_t rows) { const size_t o = off; off += rows; return o; };
     w.Z = take(S * NZ); w.ZL = take(S * NZ); w.ZU = take(S * NZ);
     w.SO = take(S * 3); w.NUO = take(S * 3); w.ZLO = take(S * 3); w.ZUO = take(S * 3);
     w.LAM = take(S * nx); w.REF = take(S * nx); w.DZ = take(S * NZ);
     w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.EV = take(S * 12); w.ROLL = take(S * nx);
     w.SC = take(SC_COUNT); w.FILT = take(2 * FILTER_MAX); w.OBST = take(6);
-    w.total = off;
-    w.itotal = (size_t)IS_COUNT * Bp;
+    w.rows = off;
+    w.irows = IS_COUNT;
+    w.tile_elems = w.rows * 64;
+    w.itile_elems = w.irows * 64;
+    w.ntiles = Bp / 64;
+    w.total = w.ntiles * w.tile_elems;
+    w.itotal = w.ntiles * w.itile_elems;
     return w;
 }
 
@@ -149,11 +159,16 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     for (int i = 0; i < 6; ++i) P.obst[i] = d.obstacle[i];
     P.fl = hp.fl; P.fu = hp.fu; P.ol = hp.ol; P.ou = hp.ou;
     P.x0 = nullptr; P.p = nullptr; P.LB = dLB; P.UB = dUB;
-    P.Z = base + w.Z; P.ZL = base + w.ZL; P.ZU = base + w.ZU;
-    P.SO = base + w.SO; P.NUO = base + w.NUO; P.ZLO = base + w.ZLO; P.ZUO = base + w.ZUO;
-    P.LAM = base + w.LAM; P.REF = base + w.REF; P.DZ = base + w.DZ; P.PK = base + w.PK; P.KK = base + w.KK;
-    P.BLK = base + w.BLK; P.EV = base + w.EV; P.ROLL = base + w.ROLL; P.SC = base + w.SC; P.FILT = base + w.FILT; P.OBST = base + w.OBST;
+    // every array pointer addresses its first row inside tile 0
+    P.Z = base + w.Z * 64; P.ZL = base + w.ZL * 64; P.ZU = base + w.ZU * 64;
+    P.SO = base + w.SO * 64; P.NUO = base + w.NUO * 64; P.ZLO = base + w.ZLO * 64; P.ZUO = base + w.ZUO * 64;
+    P.LAM = base + w.LAM * 64; P.REF = base + w.REF * 64; P.DZ = base + w.DZ * 64; P.PK = base + w.PK * 64; P.KK = base + w.KK * 64;
+    P.BLK = base + w.BLK * 64; P.EV = base + w.EV * 64; P.ROLL = base + w.ROLL * 64; P.SC = base + w.SC * 64;
+    P.FILT = base + w.FILT * 64; P.OBST = base + w.OBST * 64;
+    P.tile_elems = (uint32_t)w.tile_elems; P.itile_elems = (uint32_t)w.itile_elems;
     P.ISC = ibase;
+    P.WS = base; P.IWS = ibase;
+    P.ws_bytes = (uint32_t)(w.total * sizeof(double)); P.iws_bytes = (uint32_t)(w.itotal * sizeof(int32_t));
     P.x_out = nullptr; P.status_out = nullptr; P.iters_out = nullptr; P.kkt_out = nullptr;
 }
 

@@ -28,6 +28,22 @@
 #define MPC_HD inline
 #endif
 
+// Device code addresses the SoA workspace through ONE buffer resource descriptor (SRSRC, 4 SGPRs) with
+//   soffset (SGPR)  = byte offset of the array inside the workspace (uniform),
+//   voffset (VGPR)  = 8 * (row * Bp + b), a 32-bit per-lane byte offset,
+// i.e. buffer_load_dwordx2 / buffer_store_dwordx2 instead of flat accesses with 64-bit VGPR addresses: kernel-argument
+// pointers that arrive inside a by-value struct are otherwise treated as generic pointers (2-3 VALU of 64-bit
+// address arithmetic per access, no scalar-base addressing).  The workspace is < 4 GiB (checked on the host);
+// out-of-range accesses are dropped by the hardware bounds check.  On the host (emulation harness) the same macros
+// are plain array indexing.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define MPC_GLOBAL_AS
+#endif
+// plain global-pointer access (small tables and the caller's row-major buffers)
+#define MPC_GP(ptr, idx) (((MPC_GLOBAL_AS __typeof__(*(ptr))*)(ptr))[(uint32_t)(idx)])
+
 namespace mpc {
 
 // ---- IPOPT default constants (Waechter & Biegler 2006) -------------------------------------------------
@@ -83,11 +99,74 @@ struct Params {
     double *FILT;                // [2*FILTER_MAX][Bp]
     const double* OBST;          // [6][Bp] per-instance obstacle centres (optional)
     int32_t* ISC;                // [IS_COUNT][Bp]
+    double* WS;                  // base of the double workspace (all arrays above live inside it)
+    int32_t* IWS;                // base of the int32 workspace
+    uint32_t ws_bytes, iws_bytes;
+    uint32_t tile_elems, itile_elems;   // elements per 64-instance tile of the double / int32 workspace
     double* x_out;               // [B][n_w] row-major (ABI output)
     int32_t* status_out;
     int32_t* iters_out;
     double* kkt_out;
 };
+
+// element index of (row, instance b) relative to the first row of an array, tile-major layout
+MPC_HD uint32_t ws_index(const Params& P, const double*, uint32_t row, uint32_t b) { return (b >> 6) * P.tile_elems + row * 64u + (b & 63u); }
+MPC_HD uint32_t ws_index(const Params& P, const int32_t*, uint32_t row, uint32_t b) { return (b >> 6) * P.itile_elems + row * 64u + (b & 63u); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int mpc_v2u __attribute__((ext_vector_type(2)));
+struct WsRefD {          // element of the double workspace: converts to double (load) / assigns from double (store)
+    const Params& P;
+    uint32_t aoff, uoff, voff;     // array offset (uniform), uniform row offset, per-lane offset; bytes
+    __device__ __forceinline__ operator double() const {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.WS, 0, (int)P.ws_bytes, 0x00020000);
+        const mpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)(aoff + uoff), 0);
+        return __builtin_bit_cast(double, v);
+    }
+    __device__ __forceinline__ double operator=(double x) const {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.WS, 0, (int)P.ws_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, (int)(aoff + uoff), 0);
+        return x;
+    }
+    __device__ __forceinline__ double operator=(const WsRefD& o) const { return (*this = (double)o); }
+};
+struct WsRefI {          // element of the int32 workspace
+    const Params& P;
+    uint32_t soff, voff;
+    __device__ __forceinline__ operator int32_t() const {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.IWS, 0, (int)P.iws_bytes, 0x00020000);
+        return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+    }
+    __device__ __forceinline__ int32_t operator=(int32_t x) const {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.IWS, 0, (int)P.iws_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)x, r, (int)voff, (int)soff, 0);
+        return x;
+    }
+};
+// uni: uniform element offset (-> scalar/immediate offset), b: instance, extra: further per-lane elements
+__device__ __forceinline__ WsRefD ws_ref3(const Params& P, const double* arr, uint32_t uni, uint32_t b, uint32_t extra) {
+    return WsRefD{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.WS, uni * 8u, ((b >> 6) * P.tile_elems + (b & 63u) + extra) * 8u};
+}
+__device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, uint32_t uni, uint32_t b, uint32_t extra) {
+    return WsRefI{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.IWS + uni * 4u, ((b >> 6) * P.itile_elems + (b & 63u) + extra) * 4u};
+}
+// accessors: (array, uniform element offset -> SGPR soffset / immediate, per-lane element offset -> VGPR voffset)
+//   MPC_K(arr, R, dk, e)  stage kernel: row (k + dk) * R + e of thread c (k per lane, e and dk uniform)
+//   MPC_S(arr, row)       per-instance scalar row (row uniform) of thread c
+//   MPC_SD(arr, row)      same, row may differ between lanes
+//   MPC_U(arr, row)       instance-per-thread kernels (a wavefront = one tile): uniform row, instance `bb` in scope
+#define MPC_K(ptr, R, dk, e) ws_ref3(P, (ptr), ((uint32_t)(dk) * (uint32_t)(R) + (uint32_t)(e)) * 64u, (uint32_t)c.b, (uint32_t)c.k * ((uint32_t)(R) * 64u))
+#define MPC_S(ptr, row) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)c.b, 0u)
+#define MPC_SD(ptr, row) ws_ref3(P, (ptr), 0u, (uint32_t)c.b, (uint32_t)(row) * 64u)
+#define MPC_U(ptr, row) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)bb, 0u)
+#define MPC_UB(ptr, row, b_) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)(b_), 0u)
+#else
+#define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k * (uint32_t)(R) + (uint32_t)(dk) * (uint32_t)(R) + (uint32_t)(e)), (uint32_t)c.b)])
+#define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
+#define MPC_SD(ptr, row) MPC_S(ptr, row)
+#define MPC_U(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)bb)])
+#define MPC_UB(ptr, row, b_) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)(b_))])
+#endif
 
 template <int NX>
 struct Dim {
@@ -160,6 +239,7 @@ struct Ctx {
     // --- iterate pieces live across the line search
     double z[NZ], dz[NZ];
     double xn[NX], dxn[NX];          // x_{k+1} and its step (k < N)
+    double lam[NX], lamn[NX];        // equality multipliers of stage k and k+1 at the new iterate (exchanged through LDS)
     double rn[NX];                   // r_{k+1} (k < N)
     double so[3], dso[3];
     double sf, dsf;                  // friction slack (k == 0)
@@ -177,10 +257,9 @@ struct Ctx {
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
 
-#define MPC_AT(ptr, row) (ptr)[(size_t)(row) * (size_t)P.Bp + (size_t)c.b]
 // bounds of variable i of stage k; a_0 (k = 0, i = 1) carries the per-instance presolved friction bound
 #define MPC_BOUNDS(k, i, lb, ub)                                    \
-    double lb = P.LB[(k) * NZ + (i)], ub = P.UB[(k) * NZ + (i)];    \
+    double lb = MPC_GP(P.LB, (k) * NZ + (i)), ub = MPC_GP(P.UB, (k) * NZ + (i));    \
     if ((k) == 0 && (i) == 1) { lb = c.a0lb; ub = c.a0ub; }
 
 // ---- model pieces ----------------------------------------------------------------------------------------
@@ -252,7 +331,7 @@ MPC_HD double friction_eval(const Params& P, double a, double dl, double v, doub
 template <int NX>
 MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c.obst[i] = P.per_inst_obst ? MPC_AT(P.OBST, i) : P.obst[i];
+    for (int i = 0; i < 6; ++i) c.obst[i] = P.per_inst_obst ? MPC_S(P.OBST, i) : P.obst[i];
 }
 
 // =========================================================================================================
@@ -268,15 +347,15 @@ template <int NX>
 MPC_HD void prestart_instance(const Params& P, int b) {
     constexpr int NZ = NX + 2;
     const int N = P.N;
-    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
+    const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;
     const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-    const double* x0b = P.x0 + bb * nw;
-    const double* pb = P.p + bb * nw;
+    const MPC_GLOBAL_AS double* x0b = (const MPC_GLOBAL_AS double*)P.x0 + (size_t)bb * nw;
+    const MPC_GLOBAL_AS double* pb = (const MPC_GLOBAL_AS double*)P.p + (size_t)bb * nw;
     // presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
     // by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
     // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
     // start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
-    double a0lb = P.LB[1], a0ub = P.UB[1];
+    double a0lb = MPC_GP(P.LB, 1), a0ub = MPC_GP(P.UB, 1);
     int frow = 1;
     if (!P.has_fl && P.has_fu) {
         const double dl0 = pb[2 * N + 2], v0 = pb[2 * N + 3];
@@ -289,29 +368,29 @@ MPC_HD void prestart_instance(const Params& P, int b) {
             frow = 0;
         }
     }
-    P.SC[(size_t)SC_A0LB * Bp + bb] = a0lb;
-    P.SC[(size_t)SC_A0UB * Bp + bb] = a0ub;
-    P.ISC[(size_t)IS_FROW * Bp + bb] = frow;
+    MPC_U(P.SC, (uint32_t)SC_A0LB) = a0lb;
+    MPC_U(P.SC, (uint32_t)SC_A0UB) = a0ub;
+    MPC_U(P.ISC, (uint32_t)IS_FROW) = frow;
     double xg[NX], xr[NX], f[NX], u[2], s, c, td;
     double th_g = 0.0, th_r = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const double r0 = pb[2 * N + i];
-        xg[i] = push_in(x0b[2 * N + i], P.LB[2 + i], P.UB[2 + i]);
-        xr[i] = push_in(r0, P.LB[2 + i], P.UB[2 + i]);
+        xg[i] = push_in(x0b[2 * N + i], MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
+        xr[i] = push_in(r0, MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
         th_g += fabs(xg[i] - r0);
         th_r += fabs(xr[i] - r0);
-        P.ROLL[(size_t)i * Bp + bb] = xr[i];
+        MPC_U(P.ROLL, (uint32_t)i) = xr[i];
     }
     for (int k = 0; k < N; ++k) {
-        u[0] = push_in(x0b[2 * k], P.LB[k * NZ], P.UB[k * NZ]);
-        u[1] = push_in(x0b[2 * k + 1], (k == 0) ? a0lb : P.LB[k * NZ + 1], (k == 0) ? a0ub : P.UB[k * NZ + 1]);
+        u[0] = push_in(x0b[2 * k], MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
+        u[1] = push_in(x0b[2 * k + 1], (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
         double fr[NX];
         ode_eval<NX>(P, xg, u, f, s, c, td);
         ode_eval<NX>(P, xr, u, fr, s, c, td);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double lb = P.LB[(k + 1) * NZ + 2 + i], ub = P.UB[(k + 1) * NZ + 2 + i];
+            const double lb = MPC_GP(P.LB, (k + 1) * NZ + 2 + i), ub = MPC_GP(P.UB, (k + 1) * NZ + 2 + i);
             const double gn = push_in(x0b[2 * N + NX * (k + 1) + i], lb, ub);
             th_g += fabs(gn - (f[i] * P.dt + xg[i]));
             xg[i] = gn;
@@ -319,11 +398,11 @@ MPC_HD void prestart_instance(const Params& P, int b) {
             const double rn = push_in(rraw, lb, ub);
             th_r += fabs(rn - rraw);
             xr[i] = rn;
-            P.ROLL[((size_t)(k + 1) * NX + i) * Bp + bb] = rn;
+            MPC_U(P.ROLL, ((uint32_t)(k + 1) * NX + i)) = rn;
         }
     }
     const bool use = !(th_g <= ROLLOUT_FACTOR * fmax(1.0, th_r));      // also true when th_g is NaN
-    P.ISC[(size_t)IS_ROLL * Bp + bb] = use ? 1 : 0;
+    MPC_U(P.ISC, (uint32_t)IS_ROLL) = use ? 1 : 0;
 }
 
 // =========================================================================================================
@@ -337,22 +416,22 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     if (!c.valid) return;
     const int N = P.N, k = c.k;
     const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-    const double* x0b = P.x0 + (size_t)c.b * nw;
-    const double* pb = P.p + (size_t)c.b * nw;
+    const MPC_GLOBAL_AS double* x0b = (const MPC_GLOBAL_AS double*)P.x0 + (size_t)c.b * nw;
+    const MPC_GLOBAL_AS double* pb = (const MPC_GLOBAL_AS double*)P.p + (size_t)c.b * nw;
     load_obst(P, c);
-    c.fric_row = MPC_AT(P.ISC, IS_FROW) != 0;
-    c.a0lb = MPC_AT(P.SC, SC_A0LB);
-    c.a0ub = MPC_AT(P.SC, SC_A0UB);
-    const bool roll = MPC_AT(P.ISC, IS_ROLL) != 0;
+    c.fric_row = MPC_S(P.ISC, IS_FROW) != 0;
+    c.a0lb = MPC_S(P.SC, SC_A0LB);
+    c.a0ub = MPC_S(P.SC, SC_A0UB);
+    const bool roll = MPC_S(P.ISC, IS_ROLL) != 0;
     double gmax = 0.0;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
         double raw = 0.0, lb = -INFINITY, ub = INFINITY;
         if (!(isu && k == N)) {
-            raw = isu ? x0b[2 * k + i] : (roll ? MPC_AT(P.ROLL, k * NX + (i - 2)) : x0b[2 * N + NX * k + (i - 2)]);
-            lb = P.LB[k * NZ + i];
-            ub = P.UB[k * NZ + i];
+            raw = isu ? x0b[2 * k + i] : (roll ? MPC_K(P.ROLL, NX, 0, (i - 2)) : x0b[2 * N + NX * k + (i - 2)]);
+            lb = MPC_GP(P.LB, k * NZ + i);
+            ub = MPC_GP(P.UB, k * NZ + i);
             if (k == 0 && i == 1) { lb = c.a0lb; ub = c.a0ub; }
         }
         if (k < N) {
@@ -362,15 +441,16 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
         }
         const double v = push_in(raw, lb, ub);
         c.z[i] = v;
-        MPC_AT(P.Z, k * NZ + i) = v;
-        MPC_AT(P.ZL, k * NZ + i) = has_lo(lb) ? 1.0 : 0.0;
-        MPC_AT(P.ZU, k * NZ + i) = has_hi(ub) ? 1.0 : 0.0;
-        MPC_AT(P.DZ, k * NZ + i) = 0.0;
+        MPC_K(P.Z, NZ, 0, i) = v;
+        MPC_K(P.ZL, NZ, 0, i) = has_lo(lb) ? 1.0 : 0.0;
+        MPC_K(P.ZU, NZ, 0, i) = has_hi(ub) ? 1.0 : 0.0;
+        MPC_K(P.DZ, NZ, 0, i) = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        MPC_AT(P.REF, k * NX + i) = pb[2 * N + NX * k + i];
-        MPC_AT(P.LAM, k * NX + i) = 0.0;
+        MPC_K(P.REF, NX, 0, i) = pb[2 * N + NX * k + i];
+        MPC_K(P.LAM, NX, 0, i) = 0.0;
+        c.lam[i] = 0.0;
     }
     // slacks: s = d(w0) pushed inside its bounds
     double sps, cps;
@@ -385,25 +465,25 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         c.so[j] = push_in(dist[j], ol, ou);
-        MPC_AT(P.SO, k * 3 + j) = c.so[j];
-        MPC_AT(P.NUO, k * 3 + j) = 0.0;
-        MPC_AT(P.ZLO, k * 3 + j) = P.has_ol ? 1.0 : 0.0;
-        MPC_AT(P.ZUO, k * 3 + j) = P.has_ou ? 1.0 : 0.0;
+        MPC_K(P.SO, 3, 0, j) = c.so[j];
+        MPC_K(P.NUO, 3, 0, j) = 0.0;
+        MPC_K(P.ZLO, 3, 0, j) = P.has_ol ? 1.0 : 0.0;
+        MPC_K(P.ZUO, 3, 0, j) = P.has_ou ? 1.0 : 0.0;
     }
     if (k == 0) {
         const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
         const double dfr = c.fric_row ? friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false) : 0.0;
         c.sf = c.fric_row ? push_in(dfr, fl, fu) : 0.0;
-        MPC_AT(P.SC, SC_SF) = c.sf;
-        MPC_AT(P.SC, SC_NUF) = 0.0;
-        MPC_AT(P.SC, SC_ZLF) = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
-        MPC_AT(P.SC, SC_ZUF) = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
-        MPC_AT(P.SC, SC_DFRIC) = 0.0;
-        MPC_AT(P.SC, SC_GFR0) = 0.0;
-        MPC_AT(P.SC, SC_GFR1) = 0.0;
-        MPC_AT(P.SC, SC_GFR2) = 0.0;
-        MPC_AT(P.SC, SC_HUX0) = 0.0;
-        MPC_AT(P.SC, SC_HUX1) = 0.0;
+        MPC_S(P.SC, SC_SF) = c.sf;
+        MPC_S(P.SC, SC_NUF) = 0.0;
+        MPC_S(P.SC, SC_ZLF) = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
+        MPC_S(P.SC, SC_ZUF) = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
+        MPC_S(P.SC, SC_DFRIC) = 0.0;
+        MPC_S(P.SC, SC_GFR0) = 0.0;
+        MPC_S(P.SC, SC_GFR1) = 0.0;
+        MPC_S(P.SC, SC_GFR2) = 0.0;
+        MPC_S(P.SC, SC_HUX0) = 0.0;
+        MPC_S(P.SC, SC_HUX1) = 0.0;
     }
     red.gmax = gmax;
 }
@@ -422,19 +502,19 @@ MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
     c.thmax = 0.0;
     c.thmin = 0.0;
     if (c.k == 0) {
-        MPC_AT(P.SC, SC_DF) = c.df;
-        MPC_AT(P.SC, SC_DLAST) = 0.0;
-        MPC_AT(P.SC, SC_DELTA) = 0.0;
-        MPC_AT(P.SC, SC_THMAX) = 0.0;
-        MPC_AT(P.SC, SC_THMIN) = 0.0;
-        MPC_AT(P.SC, SC_ALPHA) = 0.0;
-        MPC_AT(P.SC, SC_ADU) = 0.0;
-        MPC_AT(P.SC, SC_PHI) = 0.0;
-        MPC_AT(P.SC, SC_NTRIAL) = 0.0;
-        MPC_AT(P.ISC, IS_NFILT) = 0;
-        MPC_AT(P.ISC, IS_HAVETH0) = 0;
-        MPC_AT(P.ISC, IS_CONV) = 0;
-        MPC_AT(P.ISC, IS_ITERS) = 0;
+        MPC_S(P.SC, SC_DF) = c.df;
+        MPC_S(P.SC, SC_DLAST) = 0.0;
+        MPC_S(P.SC, SC_DELTA) = 0.0;
+        MPC_S(P.SC, SC_THMAX) = 0.0;
+        MPC_S(P.SC, SC_THMIN) = 0.0;
+        MPC_S(P.SC, SC_ALPHA) = 0.0;
+        MPC_S(P.SC, SC_ADU) = 0.0;
+        MPC_S(P.SC, SC_PHI) = 0.0;
+        MPC_S(P.SC, SC_NTRIAL) = 0.0;
+        MPC_S(P.ISC, IS_NFILT) = 0;
+        MPC_S(P.ISC, IS_HAVETH0) = 0;
+        MPC_S(P.ISC, IS_CONV) = 0;
+        MPC_S(P.ISC, IS_ITERS) = 0;
     }
 }
 
@@ -443,23 +523,23 @@ MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
 // =========================================================================================================
 template <int NX>
 MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
-    c.status = c.valid ? MPC_AT(P.ISC, IS_STATUS) : 0;
+    c.status = c.valid ? MPC_S(P.ISC, IS_STATUS) : 0;
     c.active = c.valid && c.status == ST_RUNNING;
     if (!c.active) return;
-    c.mu = MPC_AT(P.SC, SC_MU);
-    c.tau = MPC_AT(P.SC, SC_TAU);
-    c.df = MPC_AT(P.SC, SC_DF);
-    c.theta = MPC_AT(P.SC, SC_THETA);
-    c.phi = c.df * MPC_AT(P.SC, SC_FCOST) - c.mu * MPC_AT(P.SC, SC_LOGSUM);
-    c.thmax = MPC_AT(P.SC, SC_THMAX);
-    c.thmin = MPC_AT(P.SC, SC_THMIN);
-    c.nfilt = MPC_AT(P.ISC, IS_NFILT);
-    c.iters = MPC_AT(P.ISC, IS_ITERS);
-    c.conv = P.fixed_iters > 0 && MPC_AT(P.ISC, IS_CONV) != 0;
-    c.fric_row = MPC_AT(P.ISC, IS_FROW) != 0;
-    c.a0lb = MPC_AT(P.SC, SC_A0LB);
-    c.a0ub = MPC_AT(P.SC, SC_A0UB);
-    if (!MPC_AT(P.ISC, IS_HAVETH0)) {      // first iteration: theta_max / theta_min from theta(w_0)
+    c.mu = MPC_S(P.SC, SC_MU);
+    c.tau = MPC_S(P.SC, SC_TAU);
+    c.df = MPC_S(P.SC, SC_DF);
+    c.theta = MPC_S(P.SC, SC_THETA);
+    c.phi = c.df * MPC_S(P.SC, SC_FCOST) - c.mu * MPC_S(P.SC, SC_LOGSUM);
+    c.thmax = MPC_S(P.SC, SC_THMAX);
+    c.thmin = MPC_S(P.SC, SC_THMIN);
+    c.nfilt = MPC_S(P.ISC, IS_NFILT);
+    c.iters = MPC_S(P.ISC, IS_ITERS);
+    c.conv = P.fixed_iters > 0 && MPC_S(P.ISC, IS_CONV) != 0;
+    c.fric_row = MPC_S(P.ISC, IS_FROW) != 0;
+    c.a0lb = MPC_S(P.SC, SC_A0LB);
+    c.a0ub = MPC_S(P.SC, SC_A0UB);
+    if (!MPC_S(P.ISC, IS_HAVETH0)) {      // first iteration: theta_max / theta_min from theta(w_0)
         c.thmax = 1e4 * fmax(1.0, c.theta);
         c.thmin = 1e-4 * fmax(1.0, c.theta);
     }
@@ -476,12 +556,12 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     double a_pr = 1.0, a_du = 1.0, dphi = 0.0;
     load_obst(P, c);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) c.rn[i] = (k < N) ? MPC_AT(P.REF, (k + 1) * NX + i) : 0.0;
+    for (int i = 0; i < NX; ++i) c.rn[i] = (k < N) ? MPC_K(P.REF, NX, 1, i) : 0.0;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
-        const double zi = MPC_AT(P.Z, k * NZ + i);
-        const double dv = MPC_AT(P.DZ, k * NZ + i);
+        const double zi = MPC_K(P.Z, NZ, 0, i);
+        const double dv = MPC_K(P.DZ, NZ, 0, i);
         c.z[i] = zi;
         c.dz[i] = dv;
         if (isu && k == N) continue;
@@ -489,15 +569,16 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         double gradf = 0.0;
         if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
         double gb = 0.0;
+        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
         if (has_lo(lb)) {
-            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            const double gap = zi - lb, zl = zl_ld;
             const double dzl = mu / gap - zl - zl / gap * dv;
             gb -= mu / gap;
             if (dv < 0) a_pr = fmin(a_pr, -tau * gap / dv);
             if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
         }
         if (has_hi(ub)) {
-            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            const double gap = ub - zi, zu = zu_ld;
             const double dzu = mu / gap - zu + zu / gap * dv;
             gb += mu / gap;
             if (dv > 0) a_pr = fmin(a_pr, tau * gap / dv);
@@ -507,29 +588,29 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        c.xn[i] = (k < N) ? MPC_AT(P.Z, (k + 1) * NZ + 2 + i) : 0.0;
-        c.dxn[i] = (k < N) ? MPC_AT(P.DZ, (k + 1) * NZ + 2 + i) : 0.0;
+        c.xn[i] = (k < N) ? MPC_K(P.Z, NZ, 1, 2 + i) : 0.0;
+        c.dxn[i] = (k < N) ? MPC_K(P.DZ, NZ, 1, 2 + i) : 0.0;
     }
     // obstacle slacks: ds = J dx + (d - s)
     const int oi[3] = {0, 1, 4};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double s = MPC_AT(P.SO, k * 3 + j);
-        double ds = MPC_AT(P.EV, k * D::NEV + j) - s;
+        const double s = MPC_K(P.SO, 3, 0, j);
+        double ds = MPC_K(P.EV, D::NEV, 0, j) - s;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) ds += MPC_AT(P.EV, k * D::NEV + 3 + 3 * j + a) * c.dz[2 + oi[a]];
+        for (int a = 0; a < 3; ++a) ds += MPC_K(P.EV, D::NEV, 0, 3 + 3 * j + a) * c.dz[2 + oi[a]];
         c.so[j] = s;
         c.dso[j] = ds;
         double gb = 0.0;
         if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
             const double dzl = mu / gap - zl - zl / gap * ds;
             gb -= mu / gap;
             if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
             if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
         }
         if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
             const double dzu = mu / gap - zu + zu / gap * ds;
             gb += mu / gap;
             if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
@@ -540,21 +621,21 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     c.sf = 0.0;
     c.dsf = 0.0;
     if (k == 0 && c.fric_row) {
-        const double s = MPC_AT(P.SC, SC_SF);
-        const double ds = MPC_AT(P.SC, SC_DFRIC) - s + MPC_AT(P.SC, SC_GFR0) * c.dz[1] + MPC_AT(P.SC, SC_GFR1) * c.dz[2 + 2] +
-                          MPC_AT(P.SC, SC_GFR2) * c.dz[2 + 3];
+        const double s = MPC_S(P.SC, SC_SF);
+        const double ds = MPC_S(P.SC, SC_DFRIC) - s + MPC_S(P.SC, SC_GFR0) * c.dz[1] + MPC_S(P.SC, SC_GFR1) * c.dz[2 + 2] +
+                          MPC_S(P.SC, SC_GFR2) * c.dz[2 + 3];
         c.sf = s;
         c.dsf = ds;
         double gb = 0.0;
         if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
             const double dzl = mu / gap - zl - zl / gap * ds;
             gb -= mu / gap;
             if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
             if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
         }
         if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
             const double dzu = mu / gap - zu + zu / gap * ds;
             gb += mu / gap;
             if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
@@ -628,7 +709,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     }
     if (k == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - MPC_AT(P.REF, i));
+        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - MPC_S(P.REF, i));
     }
     double dist[3];
     obstacle_eval(P, c.obst, c.zt[2], c.zt[3], sps, cps, dist, nullptr, nullptr, false);
@@ -664,7 +745,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
     const double ph_t = red.bad > 0.0 ? INFINITY : c.df * red.fcost - c.mu * red.logsum;
     bool good = isfinite(th_t) && isfinite(ph_t) && th_t <= c.thmax;
     for (int q = 0; q < c.nfilt && good; ++q) {
-        const double tf = MPC_AT(P.FILT, 2 * q), pf = MPC_AT(P.FILT, 2 * q + 1);
+        const double tf = MPC_SD(P.FILT, 2 * q), pf = MPC_SD(P.FILT, 2 * q + 1);
         if (!(cmp_le(fmax(th_t, THETA_FLOOR), fmax(tf, THETA_FLOOR), tf) || cmp_le(ph_t, pf, pf))) good = false;
     }
     if (good && c.conv) {
@@ -698,7 +779,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     const int N = P.N, k = c.k;
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
-        if (k == 0) { MPC_AT(P.ISC, IS_STATUS) = c.status; MPC_AT(P.SC, SC_ALPHA) = 0.0; MPC_AT(P.SC, SC_NTRIAL) = c.ntrial; }
+        if (k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
@@ -707,70 +788,72 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         if (i < 2 && k == N) continue;
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
-        MPC_AT(P.Z, k * NZ + i) = zn;
+        MPC_K(P.Z, NZ, 0, i) = zn;
+        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
         if (has_lo(lb)) {
-            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            const double gap = zi - lb, zl = zl_ld;
             const double dzl = mu / gap - zl - zl / gap * dv;
-            MPC_AT(P.ZL, k * NZ + i) = zreset(zl + ad * dzl, zn - lb, mu);
+            MPC_K(P.ZL, NZ, 0, i) = zreset(zl + ad * dzl, zn - lb, mu);
         }
         if (has_hi(ub)) {
-            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            const double gap = ub - zi, zu = zu_ld;
             const double dzu = mu / gap - zu + zu / gap * dv;
-            MPC_AT(P.ZU, k * NZ + i) = zreset(zu + ad * dzu, ub - zn, mu);
+            MPC_K(P.ZU, NZ, 0, i) = zreset(zu + ad * dzu, ub - zn, mu);
         }
         c.z[i] = zn;
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        double s = MPC_AT(P.PK, k * D::NPK + D::NS + i);
+        double s = MPC_K(P.PK, D::NPK, 0, D::NS + i);
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int r = (i <= j) ? D::sidx(i, j) : D::sidx(j, i);
-            s += MPC_AT(P.PK, k * D::NPK + r) * c.dz[2 + j];
+            s += MPC_K(P.PK, D::NPK, 0, r) * c.dz[2 + j];
         }
-        const double lam = MPC_AT(P.LAM, k * NX + i);
-        MPC_AT(P.LAM, k * NX + i) = lam + al * (-s - lam);
+        const double lam = MPC_K(P.LAM, NX, 0, i);
+        c.lam[i] = lam + al * (-s - lam);
+        MPC_K(P.LAM, NX, 0, i) = c.lam[i];
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
         double sg = 0.0, gb = 0.0;
         if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
             const double dzl = mu / gap - zl - zl / gap * ds;
             sg += zl / gap; gb -= mu / gap;
-            MPC_AT(P.ZLO, k * 3 + j) = zreset(zl + ad * dzl, sn - P.ol, mu);
+            MPC_K(P.ZLO, 3, 0, j) = zreset(zl + ad * dzl, sn - P.ol, mu);
         }
         if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
             const double dzu = mu / gap - zu + zu / gap * ds;
             sg += zu / gap; gb += mu / gap;
-            MPC_AT(P.ZUO, k * 3 + j) = zreset(zu + ad * dzu, P.ou - sn, mu);
+            MPC_K(P.ZUO, 3, 0, j) = zreset(zu + ad * dzu, P.ou - sn, mu);
         }
-        const double nu = MPC_AT(P.NUO, k * 3 + j);
-        MPC_AT(P.NUO, k * 3 + j) = nu + al * (gb - nu + sg * ds);
-        MPC_AT(P.SO, k * 3 + j) = sn;
+        const double nu = MPC_K(P.NUO, 3, 0, j);
+        MPC_K(P.NUO, 3, 0, j) = nu + al * (gb - nu + sg * ds);
+        MPC_K(P.SO, 3, 0, j) = sn;
         c.so[j] = sn;
     }
     if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
             const double dzl = mu / gap - zl - zl / gap * ds;
             sg += zl / gap; gb -= mu / gap;
-            MPC_AT(P.SC, SC_ZLF) = zreset(zl + ad * dzl, sn - P.fl, mu);
+            MPC_S(P.SC, SC_ZLF) = zreset(zl + ad * dzl, sn - P.fl, mu);
         }
         if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
             const double dzu = mu / gap - zu + zu / gap * ds;
             sg += zu / gap; gb += mu / gap;
-            MPC_AT(P.SC, SC_ZUF) = zreset(zu + ad * dzu, P.fu - sn, mu);
+            MPC_S(P.SC, SC_ZUF) = zreset(zu + ad * dzu, P.fu - sn, mu);
         }
-        const double nu = MPC_AT(P.SC, SC_NUF);
-        MPC_AT(P.SC, SC_NUF) = nu + al * (gb - nu + sg * ds);
-        MPC_AT(P.SC, SC_SF) = sn;
+        const double nu = MPC_S(P.SC, SC_NUF);
+        MPC_S(P.SC, SC_NUF) = nu + al * (gb - nu + sg * ds);
+        MPC_S(P.SC, SC_SF) = sn;
         c.sf = sn;
     }
     if (k == 0) {
@@ -779,23 +862,23 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
             int nf = c.nfilt;
             if (nf == FILTER_MAX) {
                 for (int q = 1; q < FILTER_MAX; ++q) {
-                    MPC_AT(P.FILT, 2 * (q - 1)) = MPC_AT(P.FILT, 2 * q);
-                    MPC_AT(P.FILT, 2 * (q - 1) + 1) = MPC_AT(P.FILT, 2 * q + 1);
+                    MPC_SD(P.FILT, 2 * (q - 1)) = MPC_SD(P.FILT, 2 * q);
+                    MPC_SD(P.FILT, 2 * (q - 1) + 1) = MPC_SD(P.FILT, 2 * q + 1);
                 }
                 --nf;
             }
-            MPC_AT(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
-            MPC_AT(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
-            MPC_AT(P.ISC, IS_NFILT) = nf + 1;
+            MPC_SD(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
+            MPC_SD(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
+            MPC_S(P.ISC, IS_NFILT) = nf + 1;
         }
-        MPC_AT(P.ISC, IS_ITERS) = c.iters + 1;
-        MPC_AT(P.ISC, IS_HAVETH0) = 1;
-        MPC_AT(P.SC, SC_THMAX) = c.thmax;
-        MPC_AT(P.SC, SC_THMIN) = c.thmin;
-        MPC_AT(P.SC, SC_ALPHA) = al;
-        MPC_AT(P.SC, SC_ADU) = ad;
-        MPC_AT(P.SC, SC_PHI) = c.phi;
-        MPC_AT(P.SC, SC_NTRIAL) = c.ntrial;
+        MPC_S(P.ISC, IS_ITERS) = c.iters + 1;
+        MPC_S(P.ISC, IS_HAVETH0) = 1;
+        MPC_S(P.SC, SC_THMAX) = c.thmax;
+        MPC_S(P.SC, SC_THMIN) = c.thmin;
+        MPC_S(P.SC, SC_ALPHA) = al;
+        MPC_S(P.SC, SC_ADU) = ad;
+        MPC_S(P.SC, SC_PHI) = c.phi;
+        MPC_S(P.SC, SC_NTRIAL) = c.ntrial;
     }
     if (!c.ftype) { if (c.nfilt == FILTER_MAX) --c.nfilt; ++c.nfilt; }
     ++c.iters;
@@ -819,12 +902,13 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) H[i] = 0.0;
     double lamn[NX], lam[NX], f[NX], sps, cps, td, cn[NX];
+    // c.xn / c.lamn (stage k+1 at the new iterate) were exchanged through LDS by the kernel
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        lam[i] = MPC_AT(P.LAM, k * NX + i);
-        lamn[i] = (k < N) ? MPC_AT(P.LAM, (k + 1) * NX + i) : 0.0;
-        c.xn[i] = (k < N) ? MPC_AT(P.Z, (k + 1) * NZ + 2 + i) : 0.0;
-        c.rn[i] = (k < N) ? MPC_AT(P.REF, (k + 1) * NX + i) : 0.0;
+        lam[i] = c.lam[i];
+        lamn[i] = (k < N) ? c.lamn[i] : 0.0;
+        if (k >= N) c.xn[i] = 0.0;
+        c.rn[i] = (k < N) ? MPC_K(P.REF, NX, 1, i) : 0.0;
     }
     ode_eval<NX>(P, x, u, f, sps, cps, td);
     const double cd = cos(x[2]), secd2 = 1.0 / (cd * cd), v = x[3], il = 1.0 / P.wheelbase;
@@ -882,8 +966,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     if (k == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double c0 = x[i] - MPC_AT(P.REF, i);
-            MPC_AT(P.SC, SC_C0 + i) = c0;
+            const double c0 = x[i] - MPC_S(P.REF, i);
+            MPC_S(P.SC, SC_C0 + i) = c0;
             theta += fabs(c0);
             prim = fmax(prim, fabs(c0));
         }
@@ -896,15 +980,16 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i];
         double sg = 0.0, gbb = 0.0, rz = 0.0;
+        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
         if (has_lo(lb)) {
-            const double gap = zi - lb, zl = MPC_AT(P.ZL, k * NZ + i);
+            const double gap = zi - lb, zl = zl_ld;
             sg += zl / gap; gbb -= 1.0 / gap; rz -= zl;
             const double cc = gap * zl;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
             ls += log(gap);
         }
         if (has_hi(ub)) {
-            const double gap = ub - zi, zu = MPC_AT(P.ZU, k * NZ + i);
+            const double gap = ub - zi, zu = zu_ld;
             sg += zu / gap; gbb += 1.0 / gap; rz += zu;
             const double cc = gap * zu;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
@@ -919,17 +1004,17 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     const int oi[3] = {0, 1, 4};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double s = c.so[j], nu = MPC_AT(P.NUO, k * 3 + j);
+        const double s = c.so[j], nu = MPC_K(P.NUO, 3, 0, j);
         double sg = 0.0, gbb = 0.0, rs = -nu;
         if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_AT(P.ZLO, k * 3 + j);
+            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
             sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
             const double cc = gap * zl;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zl;
             ls += m * log(gap);
         }
         if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_AT(P.ZUO, k * 3 + j);
+            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
             sg += zu / gap; gbb += 1.0 / gap; rs += zu;
             const double cc = gap * zu;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zu;
@@ -940,12 +1025,12 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         theta += m * fabs(res);
         prim = fmax(prim, fabs(res));
         smult += m * fabs(nu);
-        MPC_AT(P.EV, k * D::NEV + j) = dist[j];
+        MPC_K(P.EV, D::NEV, 0, j) = dist[j];
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double ja = J[3 * j + a];
-            MPC_AT(P.EV, k * D::NEV + 3 + 3 * j + a) = ja;
+            MPC_K(P.EV, D::NEV, 0, 3 + 3 * j + a) = ja;
             rx[oi[a]] += m * nu * ja;
             c.gxa[oi[a]] += ja * (m * sg * res);
             c.gxb[oi[a]] += ja * (m * gbb);
@@ -957,17 +1042,17 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     if (k == 0 && c.fric_row) {
         double g[3], h[4];
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
-        const double s = c.sf, nu = MPC_AT(P.SC, SC_NUF);
+        const double s = c.sf, nu = MPC_S(P.SC, SC_NUF);
         double sg = 0.0, gbb = 0.0, rs = -nu;
         if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_AT(P.SC, SC_ZLF);
+            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
             sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
             const double cc = gap * zl;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
             ls += log(gap);
         }
         if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_AT(P.SC, SC_ZUF);
+            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
             sg += zu / gap; gbb += 1.0 / gap; rs += zu;
             const double cc = gap * zu;
             cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
@@ -988,12 +1073,12 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         H[D::sidx(2, 2)] += nu * h[1] + sg * g[1] * g[1];
         H[D::sidx(2, 3)] += nu * h[2] + sg * g[1] * g[2];
         H[D::sidx(3, 3)] += nu * h[3] + sg * g[2] * g[2];
-        MPC_AT(P.SC, SC_HUX0) = sg * g[0] * g[1];
-        MPC_AT(P.SC, SC_HUX1) = sg * g[0] * g[2];
-        MPC_AT(P.SC, SC_DFRIC) = dfr;
-        MPC_AT(P.SC, SC_GFR0) = g[0];
-        MPC_AT(P.SC, SC_GFR1) = g[1];
-        MPC_AT(P.SC, SC_GFR2) = g[2];
+        MPC_S(P.SC, SC_HUX0) = sg * g[0] * g[1];
+        MPC_S(P.SC, SC_HUX1) = sg * g[0] * g[2];
+        MPC_S(P.SC, SC_DFRIC) = dfr;
+        MPC_S(P.SC, SC_GFR0) = g[0];
+        MPC_S(P.SC, SC_GFR1) = g[1];
+        MPC_S(P.SC, SC_GFR2) = g[2];
     }
     double nanflag = 0.0;
 #pragma unroll
@@ -1005,17 +1090,17 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     // stage blocks that do not depend on the barrier parameter
     const int base = k * D::NBLK;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) MPC_AT(P.BLK, base + D::B_H + i) = H[i];
-    MPC_AT(P.BLK, base + D::B_RUU + 0) = ruu[0];
-    MPC_AT(P.BLK, base + D::B_RUU + 1) = ruu[1];
-    MPC_AT(P.BLK, base + D::B_A + 0) = a03;
-    MPC_AT(P.BLK, base + D::B_A + 1) = a04;
-    MPC_AT(P.BLK, base + D::B_A + 2) = a13;
-    MPC_AT(P.BLK, base + D::B_A + 3) = a14;
-    MPC_AT(P.BLK, base + D::B_A + 4) = a42;
-    MPC_AT(P.BLK, base + D::B_A + 5) = a43;
+    for (int i = 0; i < NS; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_H + i) = H[i];
+    MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 0) = ruu[0];
+    MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 1) = ruu[1];
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 0) = a03;
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 1) = a04;
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 2) = a13;
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 3) = a14;
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 4) = a42;
+    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 5) = a43;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) MPC_AT(P.BLK, base + D::B_CN + i) = cn[i];
+    for (int i = 0; i < NX; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_CN + i) = cn[i];
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
 }
@@ -1055,21 +1140,21 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         }
         const int base_row = k * D::NBLK;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) MPC_AT(P.BLK, base_row + D::B_GX + i) = c.gxa[i] + mu * c.gxb[i];
-        MPC_AT(P.BLK, base_row + D::B_GU + 0) = c.gua[0] + mu * c.gub[0];
-        MPC_AT(P.BLK, base_row + D::B_GU + 1) = c.gua[1] + mu * c.gub[1];
+        for (int i = 0; i < NX; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_GX + i) = c.gxa[i] + mu * c.gxb[i];
+        MPC_K(P.BLK, D::NBLK, 0, D::B_GU + 0) = c.gua[0] + mu * c.gub[0];
+        MPC_K(P.BLK, D::NBLK, 0, D::B_GU + 1) = c.gua[1] + mu * c.gub[1];
     }
     c.status = status;
     if (k == 0) {
-        MPC_AT(P.SC, SC_MU) = mu;
-        MPC_AT(P.SC, SC_TAU) = tau;
-        MPC_AT(P.SC, SC_THETA) = red.theta;
-        MPC_AT(P.SC, SC_FCOST) = red.fcost;
-        MPC_AT(P.SC, SC_LOGSUM) = red.logsum;
-        MPC_AT(P.SC, SC_E0) = E0;
-        MPC_AT(P.ISC, IS_STATUS) = status;
-        if (mu_changed) MPC_AT(P.ISC, IS_NFILT) = 0;       // the filter is reset whenever mu changes
-        if (P.fixed_iters > 0 && E0 <= P.tol) MPC_AT(P.ISC, IS_CONV) = 1;
+        MPC_S(P.SC, SC_MU) = mu;
+        MPC_S(P.SC, SC_TAU) = tau;
+        MPC_S(P.SC, SC_THETA) = red.theta;
+        MPC_S(P.SC, SC_FCOST) = red.fcost;
+        MPC_S(P.SC, SC_LOGSUM) = red.logsum;
+        MPC_S(P.SC, SC_E0) = E0;
+        MPC_S(P.ISC, IS_STATUS) = status;
+        if (mu_changed) MPC_S(P.ISC, IS_NFILT) = 0;       // the filter is reset whenever mu changes
+        if (P.fixed_iters > 0 && E0 <= P.tol) MPC_S(P.ISC, IS_CONV) = 1;
     }
 }
 
@@ -1091,8 +1176,8 @@ struct RicStage {
 template <int NX>
 MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
     using D = Dim<NX>;
-    const size_t base = (size_t)k * D::NBLK;
-#define RL(row) P.BLK[(base + (row)) * (size_t)P.Bp + (size_t)b]
+    const uint32_t base = (uint32_t)k * D::NBLK;
+#define RL(row) MPC_UB(P.BLK, base + (row), b)
 #pragma unroll
     for (int i = 0; i < D::NS; ++i) s.H[i] = RL(D::B_H + i);
     s.ruu[0] = RL(D::B_RUU); s.ruu[1] = RL(D::B_RUU + 1);
@@ -1108,21 +1193,133 @@ MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
 template <int NX>
 MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>::sidx(i, j) : Dim<NX>::sidx(j, i)]; }
 
+// one backward step of the recursion: consumes stage block `s`, updates (Ps, pv) in place, stores gains and cost-to-go
+template <int NX>
+MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
+                                  double hux1, double* Ps, double* pv) {
+    using D = Dim<NX>;
+    constexpr int NS = D::NS;
+    const uint32_t Bp = (uint32_t)P.Bp;
+    const double dt = P.dt;
+    const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
+    // h = p+ - P+ c_{k+1}
+    double h[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double t = pv[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) t -= sym<NX>(Ps, i, j) * s.cn[j];
+        h[i] = t;
+    }
+    // PA = P+ A  (A = I + six off-identity entries (+ dt at (5,3) for NX = 6))
+    double PA[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const double pi0 = sym<NX>(Ps, i, 0), pi1 = sym<NX>(Ps, i, 1), pi4 = sym<NX>(Ps, i, 4);
+        PA[i][0] = pi0;
+        PA[i][1] = pi1;
+        PA[i][2] = sym<NX>(Ps, i, 2) + pi4 * a42;
+        double t3 = sym<NX>(Ps, i, 3) + pi0 * a03 + pi1 * a13 + pi4 * a43;
+        if (NX == 6) t3 += sym<NX>(Ps, i, 5) * dt;
+        PA[i][3] = t3;
+        PA[i][4] = pi4 + pi0 * a04 + pi1 * a14;
+        if (NX == 6) PA[i][5] = sym<NX>(Ps, i, 5);
+    }
+    // G = B' P+ A (+ Hux at stage 0), Lam = Ruu + B' P+ B, l = gu + B' h,  B = dt [e_2 e_3]
+    double G0[NX], G1[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { G0[j] = dt * PA[2][j]; G1[j] = dt * PA[3][j]; }
+    if (k == 0) { G1[2] += hux0; G1[3] += hux1; }
+    const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
+    const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
+    const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
+    const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
+    const double det = L00 * L11 - L01 * L01;
+    if (!(L00 > 0.0) || !(det > 0.0)) return false;
+    const double idet = 1.0 / det;
+    const double i00 = L11 * idet, i01 = -L01 * idet, i11 = L00 * idet;
+    double K0[NX], K1[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        K0[j] = -(i00 * G0[j] + i01 * G1[j]);
+        K1[j] = -(i01 * G0[j] + i11 * G1[j]);
+    }
+    const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
+    // p_k = gx + A' h + G' kff
+    double pn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pn[i] = s.gx[i] + h[i] + G0[i] * kf0 + G1[i] * kf1;
+    pn[2] += a42 * h[4];
+    pn[3] += a03 * h[0] + a13 * h[1] + a43 * h[4];
+    if (NX == 6) pn[3] += dt * h[5];
+    pn[4] += a04 * h[0] + a14 * h[1];
+    // P_k = H + A' (P+ A) + G' K : upper triangle only (the matrix is symmetric by construction)
+    double Pn[NS];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = i; j < NX; ++j) {
+            double t = s.H[D::sidx(i, j)] + PA[i][j] + G0[i] * K0[j] + G1[i] * K1[j];
+            if (i == 2) t += a42 * PA[4][j];
+            if (i == 3) { t += a03 * PA[0][j] + a13 * PA[1][j] + a43 * PA[4][j]; if (NX == 6) t += dt * PA[5][j]; }
+            if (i == 4) t += a04 * PA[0][j] + a14 * PA[1][j];
+            if (i == j) t += delta;
+            Pn[D::sidx(i, j)] = t;
+        }
+    }
+    const uint32_t kk = (uint32_t)k * D::NKK, pk = (uint32_t)k * D::NPK;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        MPC_U(P.KK, (kk + j)) = K0[j];
+        MPC_U(P.KK, (kk + NX + j)) = K1[j];
+    }
+    MPC_U(P.KK, (kk + 2 * NX)) = kf0;
+    MPC_U(P.KK, (kk + 2 * NX + 1)) = kf1;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { Ps[i] = Pn[i]; MPC_U(P.PK, (pk + i)) = Pn[i]; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { pv[i] = pn[i]; MPC_U(P.PK, (pk + NS + i)) = pn[i]; }
+    return true;
+}
+
+// stage data of the forward sweep
+template <int NX>
+struct FwdStage {
+    double K0[NX], K1[NX], kf0, kf1, a[6], cn[NX];
+};
+template <int NX>
+MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
+    using D = Dim<NX>;
+    const size_t Bp = (size_t)P.Bp, kk = (size_t)k * D::NKK, br = (size_t)k * D::NBLK;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        f.K0[j] = MPC_U(P.KK, (kk + j));
+        f.K1[j] = MPC_U(P.KK, (kk + NX + j));
+        f.cn[j] = MPC_U(P.BLK, (br + D::B_CN + j));
+    }
+    f.kf0 = MPC_U(P.KK, (kk + 2 * NX));
+    f.kf1 = MPC_U(P.KK, (kk + 2 * NX + 1));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f.a[i] = MPC_U(P.BLK, (br + D::B_A + i));
+}
+
 template <int NX>
 MPC_HD void riccati_instance(const Params& P, int b) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const int N = P.N;
-    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
-    if (P.ISC[(size_t)IS_STATUS * Bp + bb] != ST_RUNNING) return;
+    const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;
+    if (MPC_U(P.ISC, (uint32_t)IS_STATUS) != ST_RUNNING) return;
     const double dt = P.dt;
-    const double delta_last = P.SC[(size_t)SC_DLAST * Bp + bb];
-    const double hux0 = P.SC[(size_t)SC_HUX0 * Bp + bb], hux1 = P.SC[(size_t)SC_HUX1 * Bp + bb];
+    const double delta_last = MPC_U(P.SC, (uint32_t)SC_DLAST);
+    const double hux0 = MPC_U(P.SC, (uint32_t)SC_HUX0), hux1 = MPC_U(P.SC, (uint32_t)SC_HUX1);
     double delta = 0.0;
     bool ok = false;
     for (;;) {
         ok = true;
         double Ps[NS], pv[NX];
+        RicStage<NX> cur, nxt;
+        ric_load<NX>(P, b, N - 1, cur);        // in flight while the terminal block is processed
         {
             RicStage<NX> s;
             ric_load<NX>(P, b, N, s);
@@ -1130,154 +1327,73 @@ MPC_HD void riccati_instance(const Params& P, int b) {
             for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
-            const size_t pk = (size_t)N * D::NPK;
+            const uint32_t pk = (uint32_t)N * D::NPK;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) P.PK[(pk + i) * Bp + bb] = Ps[i];
+            for (int i = 0; i < NS; ++i) MPC_U(P.PK, (pk + i)) = Ps[i];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) P.PK[(pk + NS + i) * Bp + bb] = pv[i];
+            for (int i = 0; i < NX; ++i) MPC_U(P.PK, (pk + NS + i)) = pv[i];
         }
-        for (int k = N - 1; k >= 0; --k) {
-            RicStage<NX> s;
-            ric_load<NX>(P, b, k, s);
-            const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
-            // h = p+ - P+ c_{k+1}
-            double h[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double t = pv[i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) t -= sym<NX>(Ps, i, j) * s.cn[j];
-                h[i] = t;
-            }
-            // PA = P+ A
-            double PA[NX][NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const double pi0 = sym<NX>(Ps, i, 0), pi1 = sym<NX>(Ps, i, 1), pi4 = sym<NX>(Ps, i, 4);
-                PA[i][0] = pi0;
-                PA[i][1] = pi1;
-                PA[i][2] = sym<NX>(Ps, i, 2) + pi4 * a42;
-                double t3 = sym<NX>(Ps, i, 3) + pi0 * a03 + pi1 * a13 + pi4 * a43;
-                if (NX == 6) t3 += sym<NX>(Ps, i, 5) * dt;
-                PA[i][3] = t3;
-                PA[i][4] = pi4 + pi0 * a04 + pi1 * a14;
-                if (NX == 6) PA[i][5] = sym<NX>(Ps, i, 5);
-            }
-            // G = B' P+ A (+ Hux at stage 0), Lam = Ruu + B' P+ B, l = gu + B' h
-            double G[2][NX];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) { G[0][j] = dt * PA[2][j]; G[1][j] = dt * PA[3][j]; }
-            if (k == 0) { G[1][2] += hux0; G[1][3] += hux1; }
-            const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
-            const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
-            const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
-            const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
-            const double det = L00 * L11 - L01 * L01;
-            if (!(L00 > 0.0) || !(det > 0.0)) { ok = false; break; }
-            const double idet = 1.0 / det;
-            const double i00 = L11 * idet, i01 = -L01 * idet, i11 = L00 * idet;
-            double K0[NX], K1[NX];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                K0[j] = -(i00 * G[0][j] + i01 * G[1][j]);
-                K1[j] = -(i01 * G[0][j] + i11 * G[1][j]);
-            }
-            const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
-            // p_k = gx + A' h + G' kff
-            double pn[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = s.gx[i] + h[i] + G[0][i] * kf0 + G[1][i] * kf1;
-            pn[2] += a42 * h[4];
-            pn[3] += a03 * h[0] + a13 * h[1] + a43 * h[4];
-            if (NX == 6) pn[3] += dt * h[5];
-            pn[4] += a04 * h[0] + a14 * h[1];
-            // P_k = H + A' (P+ A) + G' K   (upper triangle)
-            double Pn[NS];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-#pragma unroll
-                for (int j = i; j < NX; ++j) {
-                    double t = s.H[D::sidx(i, j)] + PA[i][j] + G[0][i] * K0[j] + G[1][i] * K1[j];
-                    if (i == 2) t += a42 * PA[4][j];
-                    if (i == 3) { t += a03 * PA[0][j] + a13 * PA[1][j] + a43 * PA[4][j]; if (NX == 6) t += dt * PA[5][j]; }
-                    if (i == 4) t += a04 * PA[0][j] + a14 * PA[1][j];
-                    if (i == j) t += delta;
-                    Pn[D::sidx(i, j)] = t;
-                }
-            }
-            // PA is not exactly symmetric-consistent in floating point for (i<j) vs (j<i): symmetrise the way
-            // the oracle does, P_ij = (P_ij + P_ji)/2, using the lower-triangle expression as well
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-#pragma unroll
-                for (int j = i + 1; j < NX; ++j) {
-                    // lower entry (j,i): H_ji + (A'PA)_ji + G_j' K_i
-                    double t = s.H[D::sidx(i, j)] + PA[j][i] + G[0][j] * K0[i] + G[1][j] * K1[i];
-                    if (j == 2) t += a42 * PA[4][i];
-                    if (j == 3) { t += a03 * PA[0][i] + a13 * PA[1][i] + a43 * PA[4][i]; if (NX == 6) t += dt * PA[5][i]; }
-                    if (j == 4) t += a04 * PA[0][i] + a14 * PA[1][i];
-                    Pn[D::sidx(i, j)] = 0.5 * (Pn[D::sidx(i, j)] + t);
-                }
-            }
-            // store gains and cost-to-go, roll
-            const size_t kk = (size_t)k * D::NKK, pk = (size_t)k * D::NPK;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                P.KK[(kk + j) * Bp + bb] = K0[j];
-                P.KK[(kk + NX + j) * Bp + bb] = K1[j];
-            }
-            P.KK[(kk + 2 * NX) * Bp + bb] = kf0;
-            P.KK[(kk + 2 * NX + 1) * Bp + bb] = kf1;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) { Ps[i] = Pn[i]; P.PK[(pk + i) * Bp + bb] = Pn[i]; }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { pv[i] = pn[i]; P.PK[(pk + NS + i) * Bp + bb] = pn[i]; }
+        // software pipeline: the block of stage k-1 is requested before stage k is processed, so its HBM latency
+        // overlaps the ~330 fp64 operations of the step (two stages per trip: cur/nxt ping-pong without copies)
+        int k = N - 1;
+        for (; k >= 1; k -= 2) {
+            ric_load<NX>(P, b, k - 1, nxt);
+            if (!riccati_backward_step<NX>(P, bb, k, cur, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+            if (k >= 2) ric_load<NX>(P, b, k - 2, cur);
+            if (!riccati_backward_step<NX>(P, bb, k - 1, nxt, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+        }
+        if (ok && k == 0) {
+            if (!riccati_backward_step<NX>(P, bb, 0, cur, delta, hux0, hux1, Ps, pv)) ok = false;
         }
         if (ok) break;
         if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);
         else delta *= (delta_last == 0.0) ? KW_PLUS_BAR : KW_PLUS;
         if (delta > DW_MAX) break;
     }
-    if (!ok) { P.ISC[(size_t)IS_STATUS * Bp + bb] = -7; return; }
-    if (delta > 0.0) P.SC[(size_t)SC_DLAST * Bp + bb] = delta;
-    P.SC[(size_t)SC_DELTA * Bp + bb] = delta;
-    // forward sweep
+    if (!ok) { MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7; return; }
+    if (delta > 0.0) MPC_U(P.SC, (uint32_t)SC_DLAST) = delta;
+    MPC_U(P.SC, (uint32_t)SC_DELTA) = delta;
+    // forward sweep (same software pipeline)
     double dx[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = -P.SC[(size_t)(SC_C0 + i) * Bp + bb];
-    for (int k = 0; k < N; ++k) {
-        const size_t kk = (size_t)k * D::NKK, zr = (size_t)k * D::NZ, br = (size_t)k * D::NBLK;
-        double du0 = P.KK[(kk + 2 * NX) * Bp + bb], du1 = P.KK[(kk + 2 * NX + 1) * Bp + bb];
+    for (int i = 0; i < NX; ++i) dx[i] = -MPC_U(P.SC, (uint32_t)(SC_C0 + i));
+    FwdStage<NX> fa, fb;
+    fwd_load<NX>(P, bb, 0, fa);
+    auto fwd_step = [&](int k, const FwdStage<NX>& f) {
+        const uint32_t zr = (uint32_t)k * D::NZ;
+        double du0 = f.kf0, du1 = f.kf1;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            du0 += P.KK[(kk + j) * Bp + bb] * dx[j];
-            du1 += P.KK[(kk + NX + j) * Bp + bb] * dx[j];
-        }
-        P.DZ[(zr + 0) * Bp + bb] = du0;
-        P.DZ[(zr + 1) * Bp + bb] = du1;
+        for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
+        MPC_U(P.DZ, (zr + 0)) = du0;
+        MPC_U(P.DZ, (zr + 1)) = du1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) P.DZ[(zr + 2 + i) * Bp + bb] = dx[i];
-        const double a03 = P.BLK[(br + D::B_A + 0) * Bp + bb], a04 = P.BLK[(br + D::B_A + 1) * Bp + bb];
-        const double a13 = P.BLK[(br + D::B_A + 2) * Bp + bb], a14 = P.BLK[(br + D::B_A + 3) * Bp + bb];
-        const double a42 = P.BLK[(br + D::B_A + 4) * Bp + bb], a43 = P.BLK[(br + D::B_A + 5) * Bp + bb];
+        for (int i = 0; i < NX; ++i) MPC_U(P.DZ, (zr + 2 + i)) = dx[i];
         double dn[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dn[i] = dx[i] - P.BLK[(br + D::B_CN + i) * Bp + bb];
-        dn[0] += a03 * dx[3] + a04 * dx[4];
-        dn[1] += a13 * dx[3] + a14 * dx[4];
+        for (int i = 0; i < NX; ++i) dn[i] = dx[i] - f.cn[i];
+        dn[0] += f.a[0] * dx[3] + f.a[1] * dx[4];
+        dn[1] += f.a[2] * dx[3] + f.a[3] * dx[4];
         dn[2] += dt * du0;
         dn[3] += dt * du1;
-        dn[4] += a42 * dx[2] + a43 * dx[3];
+        dn[4] += f.a[4] * dx[2] + f.a[5] * dx[3];
         if (NX == 6) dn[5] += dt * dx[3];
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = dn[i];
+    };
+    int k = 0;
+    for (; k + 1 < N; k += 2) {
+        fwd_load<NX>(P, bb, k + 1, fb);
+        fwd_step(k, fa);
+        if (k + 2 < N) fwd_load<NX>(P, bb, k + 2, fa);
+        fwd_step(k + 1, fb);
     }
+    if (k < N) fwd_step(k, fa);
     {
-        const size_t zr = (size_t)N * D::NZ;
-        P.DZ[(zr + 0) * Bp + bb] = 0.0;
-        P.DZ[(zr + 1) * Bp + bb] = 0.0;
+        const uint32_t zr = (uint32_t)N * D::NZ;
+        MPC_U(P.DZ, (zr + 0)) = 0.0;
+        MPC_U(P.DZ, (zr + 1)) = 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) P.DZ[(zr + 2 + i) * Bp + bb] = dx[i];
+        for (int i = 0; i < NX; ++i) MPC_U(P.DZ, (zr + 2 + i)) = dx[i];
     }
 }
 
@@ -1288,21 +1404,21 @@ template <int NX>
 MPC_HD void output_instance(const Params& P, int b) {
     using D = Dim<NX>;
     const int N = P.N;
-    const size_t Bp = (size_t)P.Bp, bb = (size_t)b;
+    const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;
     const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-    double* xo = P.x_out + bb * nw;
+    MPC_GLOBAL_AS double* xo = (MPC_GLOBAL_AS double*)P.x_out + (size_t)bb * nw;
     for (int k = 0; k <= N; ++k) {
         if (k < N) {
-            xo[2 * k] = P.Z[((size_t)k * D::NZ + 0) * Bp + bb];
-            xo[2 * k + 1] = P.Z[((size_t)k * D::NZ + 1) * Bp + bb];
+            xo[2 * k] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 0));
+            xo[2 * k + 1] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 1));
         }
-        for (int i = 0; i < NX; ++i) xo[2 * N + NX * k + i] = P.Z[((size_t)k * D::NZ + 2 + i) * Bp + bb];
+        for (int i = 0; i < NX; ++i) xo[2 * N + NX * k + i] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 2 + i));
     }
-    int st = P.ISC[(size_t)IS_STATUS * Bp + bb];
+    int st = MPC_U(P.ISC, (uint32_t)IS_STATUS);
     if (st == ST_RUNNING) st = 0;     // iteration budget of the launch loop exhausted
     if (P.status_out) P.status_out[b] = st;
-    if (P.iters_out) P.iters_out[b] = P.ISC[(size_t)IS_ITERS * Bp + bb];
-    if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)SC_E0 * Bp + bb];
+    if (P.iters_out) P.iters_out[b] = MPC_U(P.ISC, (uint32_t)IS_ITERS);
+    if (P.kkt_out) P.kkt_out[b] = MPC_U(P.SC, (uint32_t)SC_E0);
 }
 
 }  // namespace mpc

@@ -95,7 +95,6 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
         phase_init_point<NX>(P, c, r0);
         block_reduce(r0, bx, lds);
         phase_init_scalars<NX>(P, c, r0);
-        __syncthreads();
     } else {
         phase_load_scalars<NX>(P, c);
         if (!__syncthreads_or(c.active ? 1 : 0)) return;
@@ -110,7 +109,19 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
             phase_linesearch_decide<NX>(P, c, r2);
         }
         phase_apply_update<NX>(P, c);
+    }
+    // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
+    {
+        double* ex = lds + (blockDim.x >> 6) * 10 * bx;       // behind the reduction scratch
+        const int T = blockDim.x;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ex[i * T + t] = c.z[2 + i]; ex[(NX + i) * T + t] = c.lam[i]; }
         __syncthreads();
+        const int tn = t + bx;
+        if (tn < T) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { c.xn[i] = ex[i * T + tn]; c.lamn[i] = ex[(NX + i) * T + tn]; }
+        }
     }
     Red3 r3;
     phase_eval_assemble<NX>(P, c, r3);
@@ -136,18 +147,27 @@ __global__ void __launch_bounds__(64) k_output(const Params P) {
     if (b < P.B) output_instance<NX>(P, b);
 }
 
-__global__ void k_count_running(const int32_t* status, int B, int32_t* counter) {
+__global__ void k_count_running(const int32_t* iws, uint32_t itile_elems, int B, int32_t* counter) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    const int run = (b < B && status[b] == ST_RUNNING) ? 1 : 0;
+    const int run = (b < B && iws[((uint32_t)b >> 6) * itile_elems + (uint32_t)IS_STATUS * 64u + ((uint32_t)b & 63u)] == ST_RUNNING) ? 1 : 0;
     const unsigned long long m = __ballot(run);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
 }
 
-__global__ void k_transpose_obst(const double* obst /*[B][6]*/, double* OBST /*[6][Bp]*/, int B, int Bp) {
+__global__ void k_transpose_obst(const double* obst /*[B][6]*/, double* OBST /*rows of tile 0*/, int B, uint32_t tile_elems) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) OBST[(size_t)i * Bp + b] = obst[(size_t)b * 6 + i];
+    for (int i = 0; i < 6; ++i) OBST[((uint32_t)b >> 6) * tile_elems + (uint32_t)i * 64u + ((uint32_t)b & 63u)] = obst[(size_t)b * 6 + i];
+}
+
+// debug/trace helper: gather 8 per-instance scalar rows into a contiguous [8][B] buffer
+__global__ void k_gather_trace(const double* SC /*rows of tile 0*/, uint32_t tile_elems, int B, double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[(size_t)q * B + b] = SC[((uint32_t)b >> 6) * tile_elems + (uint32_t)rows[q] * 64u + ((uint32_t)b & 63u)];
 }
 
 template <int NX>
@@ -315,6 +335,10 @@ static int ensure_ws(mpc_handle* h, size_t Bp) {
     free_ws(h);
     // workspace addressing depends on Bp, so it is (re)allocated exactly for the padded batch size
     const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp);
+    if (w.total * sizeof(double) >= ((size_t)1 << 32)) {
+        h->err = "batch too large: the workspace must stay below 4 GiB (32-bit buffer offsets); split the batch";
+        return MPC_ERR_INVALID;
+    }
     HIP_TRY(h, hipMalloc(&h->d_ws, w.total * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->d_iws, w.itotal * sizeof(int32_t)));
     h->cap_Bp = Bp;
@@ -370,15 +394,14 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     Prof prof{h, stream};
     if (d_obst) {
         P.per_inst_obst = 1;
-        hipLaunchKernelGGL(k_transpose_obst, dim3((B + 255) / 256), dim3(256), 0, stream, d_obst, h->d_ws + w.OBST, B, (int)Bp);
+        hipLaunchKernelGGL(k_transpose_obst, dim3((B + 255) / 256), dim3(256), 0, stream, d_obst, h->d_ws + w.OBST * 64, B, (uint32_t)w.tile_elems);
     }
     const int S = d.N + 1;
     const int threads = ((S * bx + 63) / 64) * 64;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
-    const size_t lds_bytes = (size_t)nw * 10 * bx * sizeof(double);
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * NX * threads) * sizeof(double);   // reductions + stage exchange
     const int rblk = (int)(Bp / 64);
-    int32_t* d_stat_row = h->d_iws + (size_t)IS_STATUS * Bp;
 
     prof.begin(2);
     hipLaunchKernelGGL((k_prestart<NX>), dim3(rblk), dim3(64), 0, stream, P);
@@ -387,13 +410,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
 
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     const int chunk = d.fixed_iters > 0 ? cap : 4;
+    double* d_trace = nullptr;
+    if (trace) HIP_TRY(h, hipMalloc(&d_trace, sizeof(double) * 8 * (size_t)B));
     auto record_trace = [&](int it) -> int {
         if (!trace || it >= trace_rows) return MPC_OK;
-        static const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
+        hipLaunchKernelGGL(k_gather_trace, dim3((B + 255) / 256), dim3(256), 0, stream, h->d_ws + w.SC * 64, (uint32_t)w.tile_elems, B, d_trace);
         HIP_TRY(h, hipStreamSynchronize(stream));
-        for (int q = 0; q < 8; ++q)
-            HIP_TRY(h, hipMemcpy(trace + ((size_t)it * 8 + q) * B, h->d_ws + w.SC + (size_t)rows[q] * Bp, sizeof(double) * B,
-                                 hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(trace + (size_t)it * 8 * B, d_trace, sizeof(double) * 8 * (size_t)B, hipMemcpyDeviceToHost));
         return MPC_OK;
     };
     int it = 0;
@@ -411,12 +434,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (d.fixed_iters > 0) break;
         // convergence poll
         HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), stream));
-        hipLaunchKernelGGL(k_count_running, dim3((B + 255) / 256), dim3(256), 0, stream, d_stat_row, B, h->d_counter);
+        hipLaunchKernelGGL(k_count_running, dim3((B + 255) / 256), dim3(256), 0, stream, h->d_iws, (uint32_t)w.itile_elems, B, h->d_counter);
         HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
         if (*h->h_counter == 0) break;
     }
-    if (trace) { rc = record_trace(it); if (rc) return rc; }
+    if (trace) { rc = record_trace(it); if (rc) return rc; (void)hipFree(d_trace); }
     if (n_it_out) *n_it_out = it;
     prof.begin(2);
     hipLaunchKernelGGL((k_output<NX>), dim3(rblk), dim3(64), 0, stream, P);

@@ -41,7 +41,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
     if (obst) {
         P.per_inst_obst = 1;
         for (int b = 0; b < B; ++b)
-            for (int i = 0; i < 6; ++i) ws[w.OBST + (size_t)i * Bp + b] = obst[(size_t)b * 6 + i];
+            for (int i = 0; i < 6; ++i) ws[w.elem(w.OBST, i, b)] = obst[(size_t)b * 6 + i];
     }
     const int nblocks = (int)((B + bx - 1) / bx);
     const int nthreads = S * bx;
@@ -63,6 +63,9 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         }
     };
     auto eval_finish = [&]() {
+        // neighbour-stage exchange (LDS on the GPU): x_{k+1} and lambda_{k+1} at the new iterate
+        for (int t = 0; t + bx < nthreads; ++t)
+            for (int i = 0; i < NX; ++i) { ctx[t].xn[i] = ctx[t + bx].z[2 + i]; ctx[t].lamn[i] = ctx[t + bx].lam[i]; }
         for (int t = 0; t < nthreads; ++t) phase_eval_assemble<NX>(P, ctx[t], r3[t]);
         reduce_block(r3, bx, S);
         for (int t = 0; t < nthreads; ++t) phase_finish<NX>(P, ctx[t], r3[t], hp.n_mult, hp.n_z);
@@ -82,13 +85,13 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         double* tr = trace + (size_t)it * 8 * B;
         const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
         for (int q = 0; q < 8; ++q)
-            for (int b = 0; b < B; ++b) tr[(size_t)q * B + b] = ws[w.SC + (size_t)rows[q] * Bp + b];
+            for (int b = 0; b < B; ++b) tr[(size_t)q * B + b] = ws[w.elem(w.SC, rows[q], b)];
     };
     int it = 0;
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     for (; it < cap; ++it) {
         int running = 0;
-        for (int b = 0; b < B; ++b) running += iws[(size_t)IS_STATUS * Bp + b] == ST_RUNNING;
+        for (int b = 0; b < B; ++b) running += iws[w.ielem(IS_STATUS, b)] == ST_RUNNING;
         if (!running) break;
         // ---- Riccati kernel: one instance per thread
         for (int b = 0; b < B; ++b) riccati_instance<NX>(P, b);
