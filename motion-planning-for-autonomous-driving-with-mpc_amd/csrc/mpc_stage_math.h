@@ -115,17 +115,26 @@ MPC_HD uint32_t ws_index(const Params& P, const int32_t*, uint32_t row, uint32_t
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int mpc_v2u __attribute__((ext_vector_type(2)));
+// buffer descriptor over a workspace; base pointer and scalar offsets pass through readfirstlane so that the compiler
+// can PROVE they are wave-uniform (otherwise each buffer op is wrapped in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mpc_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int mpc_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
 struct WsRefD {          // element of the double workspace: converts to double (load) / assigns from double (store)
     const Params& P;
     uint32_t aoff, uoff, voff;     // array offset (uniform), uniform row offset, per-lane offset; bytes
     __device__ __forceinline__ operator double() const {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.WS, 0, (int)P.ws_bytes, 0x00020000);
-        const mpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)(aoff + uoff), 0);
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.WS, P.ws_bytes);
+        const mpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, mpc_uni(aoff + uoff), 0);
         return __builtin_bit_cast(double, v);
     }
     __device__ __forceinline__ double operator=(double x) const {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.WS, 0, (int)P.ws_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, (int)(aoff + uoff), 0);
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.WS, P.ws_bytes);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, mpc_uni(aoff + uoff), 0);
         return x;
     }
     __device__ __forceinline__ double operator=(const WsRefD& o) const { return (*this = (double)o); }
@@ -134,12 +143,12 @@ struct WsRefI {          // element of the int32 workspace
     const Params& P;
     uint32_t soff, voff;
     __device__ __forceinline__ operator int32_t() const {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.IWS, 0, (int)P.iws_bytes, 0x00020000);
-        return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.IWS, P.iws_bytes);
+        return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, mpc_uni(soff), 0);
     }
     __device__ __forceinline__ int32_t operator=(int32_t x) const {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)P.IWS, 0, (int)P.iws_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)x, r, (int)voff, (int)soff, 0);
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.IWS, P.iws_bytes);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)x, r, (int)voff, mpc_uni(soff), 0);
         return x;
     }
 };
@@ -1193,13 +1202,15 @@ MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
 template <int NX>
 MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>::sidx(i, j) : Dim<NX>::sidx(j, i)]; }
 
-// one backward step of the recursion: consumes stage block `s`, updates (Ps, pv) in place, stores gains and cost-to-go
+// one backward step of the recursion: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go.
+// With A = I + dtF (F has 7 nonzeros) the products are organised around W = P+ (dtF), which has only three nonzero
+// columns (delta, v, psi):   A'P+A = P+ + W + W' + (dtF)'W,   P+A = P+ + W,
+// so the 6x6 product P+A is never formed and P_k is accumulated onto P+ (18 + 12 + 12 temporaries instead of 36 + 21).
 template <int NX>
 MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
                                   double hux1, double* Ps, double* pv) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
-    const uint32_t Bp = (uint32_t)P.Bp;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
     // h = p+ - P+ c_{k+1}
@@ -1211,24 +1222,26 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         for (int j = 0; j < NX; ++j) t -= sym<NX>(Ps, i, j) * s.cn[j];
         h[i] = t;
     }
-    // PA = P+ A  (A = I + six off-identity entries (+ dt at (5,3) for NX = 6))
-    double PA[NX][NX];
+    // W[i][c] = (P+ dtF)[i][2 + c], c = 0,1,2  (columns delta, v, psi)
+    double W[NX][3];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const double pi0 = sym<NX>(Ps, i, 0), pi1 = sym<NX>(Ps, i, 1), pi4 = sym<NX>(Ps, i, 4);
-        PA[i][0] = pi0;
-        PA[i][1] = pi1;
-        PA[i][2] = sym<NX>(Ps, i, 2) + pi4 * a42;
-        double t3 = sym<NX>(Ps, i, 3) + pi0 * a03 + pi1 * a13 + pi4 * a43;
-        if (NX == 6) t3 += sym<NX>(Ps, i, 5) * dt;
-        PA[i][3] = t3;
-        PA[i][4] = pi4 + pi0 * a04 + pi1 * a14;
-        if (NX == 6) PA[i][5] = sym<NX>(Ps, i, 5);
+        W[i][0] = pi4 * a42;
+        double t = pi0 * a03 + pi1 * a13 + pi4 * a43;
+        if (NX == 6) t += sym<NX>(Ps, i, 5) * dt;
+        W[i][1] = t;
+        W[i][2] = pi0 * a04 + pi1 * a14;
     }
-    // G = B' P+ A (+ Hux at stage 0), Lam = Ruu + B' P+ B, l = gu + B' h,  B = dt [e_2 e_3]
+    // G = B'(P+A) (+ Hux at stage 0) = dt * rows (2,3) of (P+ + W);  Lam = Ruu + B'P+B;  l = gu + B'h
     double G0[NX], G1[NX];
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { G0[j] = dt * PA[2][j]; G1[j] = dt * PA[3][j]; }
+    for (int j = 0; j < NX; ++j) {
+        double g0 = sym<NX>(Ps, 2, j), g1 = sym<NX>(Ps, 3, j);
+        if (j >= 2 && j <= 4) { g0 += W[2][j - 2]; g1 += W[3][j - 2]; }
+        G0[j] = dt * g0;
+        G1[j] = dt * g1;
+    }
     if (k == 0) { G1[2] += hux0; G1[3] += hux1; }
     const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
     const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
@@ -1245,40 +1258,43 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         K1[j] = -(i01 * G0[j] + i11 * G1[j]);
     }
     const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
-    // p_k = gx + A' h + G' kff
-    double pn[NX];
+    const uint32_t kk = (uint32_t)k * D::NKK, pk = (uint32_t)k * D::NPK;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) pn[i] = s.gx[i] + h[i] + G0[i] * kf0 + G1[i] * kf1;
-    pn[2] += a42 * h[4];
-    pn[3] += a03 * h[0] + a13 * h[1] + a43 * h[4];
-    if (NX == 6) pn[3] += dt * h[5];
-    pn[4] += a04 * h[0] + a14 * h[1];
-    // P_k = H + A' (P+ A) + G' K : upper triangle only (the matrix is symmetric by construction)
-    double Pn[NS];
+    for (int j = 0; j < NX; ++j) {
+        MPC_U(P.KK, kk + j) = K0[j];
+        MPC_U(P.KK, kk + NX + j) = K1[j];
+    }
+    MPC_U(P.KK, kk + 2 * NX) = kf0;
+    MPC_U(P.KK, kk + 2 * NX + 1) = kf1;
+    // p_k = gx + A'h + G'kff
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double t = s.gx[i] + h[i] + G0[i] * kf0 + G1[i] * kf1;
+        if (i == 2) t += a42 * h[4];
+        if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NX == 6) t += dt * h[5]; }
+        if (i == 4) t += a04 * h[0] + a14 * h[1];
+        pv[i] = t;
+        MPC_U(P.PK, pk + NS + i) = t;
+    }
+    // P_k = H + P+ + W + W' + (dtF)'W + G'K, upper triangle, accumulated onto P+
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
         for (int j = i; j < NX; ++j) {
-            double t = s.H[D::sidx(i, j)] + PA[i][j] + G0[i] * K0[j] + G1[i] * K1[j];
-            if (i == 2) t += a42 * PA[4][j];
-            if (i == 3) { t += a03 * PA[0][j] + a13 * PA[1][j] + a43 * PA[4][j]; if (NX == 6) t += dt * PA[5][j]; }
-            if (i == 4) t += a04 * PA[0][j] + a14 * PA[1][j];
+            double t = Ps[D::sidx(i, j)] + s.H[D::sidx(i, j)] + G0[i] * K0[j] + G1[i] * K1[j];
+            if (j >= 2 && j <= 4) t += W[i][j - 2];
+            if (i >= 2 && i <= 4) t += W[j][i - 2];
+            if (i >= 2 && i <= 4 && j >= 2 && j <= 4) {          // ((dtF)'W)[i][j], rows/cols (delta, v, psi)
+                const int cj = j - 2;
+                if (i == 2) t += a42 * W[4][cj];
+                if (i == 3) { t += a03 * W[0][cj] + a13 * W[1][cj] + a43 * W[4][cj]; if (NX == 6) t += dt * W[5][cj]; }
+                if (i == 4) t += a04 * W[0][cj] + a14 * W[1][cj];
+            }
             if (i == j) t += delta;
-            Pn[D::sidx(i, j)] = t;
+            Ps[D::sidx(i, j)] = t;
+            MPC_U(P.PK, pk + D::sidx(i, j)) = t;
         }
     }
-    const uint32_t kk = (uint32_t)k * D::NKK, pk = (uint32_t)k * D::NPK;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-        MPC_U(P.KK, (kk + j)) = K0[j];
-        MPC_U(P.KK, (kk + NX + j)) = K1[j];
-    }
-    MPC_U(P.KK, (kk + 2 * NX)) = kf0;
-    MPC_U(P.KK, (kk + 2 * NX + 1)) = kf1;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) { Ps[i] = Pn[i]; MPC_U(P.PK, (pk + i)) = Pn[i]; }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { pv[i] = pn[i]; MPC_U(P.PK, (pk + NS + i)) = pn[i]; }
     return true;
 }
 
@@ -1301,6 +1317,32 @@ MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
     f.kf1 = MPC_U(P.KK, (kk + 2 * NX + 1));
 #pragma unroll
     for (int i = 0; i < 6; ++i) f.a[i] = MPC_U(P.BLK, (br + D::B_A + i));
+}
+
+// one step of the forward sweep: du_k = K dx_k + kff, dx_{k+1} = A dx_k + B du_k - c_{k+1}; stores (du_k, dx_k)
+template <int NX>
+MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
+    using D = Dim<NX>;
+    const double dt = P.dt;
+    const uint32_t zr = (uint32_t)k * D::NZ;
+    double du0 = f.kf0, du1 = f.kf1;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
+    MPC_U(P.DZ, zr + 0) = du0;
+    MPC_U(P.DZ, zr + 1) = du1;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) MPC_U(P.DZ, zr + 2 + i) = dx[i];
+    double dn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dn[i] = dx[i] - f.cn[i];
+    dn[0] += f.a[0] * dx[3] + f.a[1] * dx[4];
+    dn[1] += f.a[2] * dx[3] + f.a[3] * dx[4];
+    dn[2] += dt * du0;
+    dn[3] += dt * du1;
+    dn[4] += f.a[4] * dx[2] + f.a[5] * dx[3];
+    if (NX == 6) dn[5] += dt * dx[3];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = dn[i];
 }
 
 template <int NX>
@@ -1359,27 +1401,7 @@ MPC_HD void riccati_instance(const Params& P, int b) {
     for (int i = 0; i < NX; ++i) dx[i] = -MPC_U(P.SC, (uint32_t)(SC_C0 + i));
     FwdStage<NX> fa, fb;
     fwd_load<NX>(P, bb, 0, fa);
-    auto fwd_step = [&](int k, const FwdStage<NX>& f) {
-        const uint32_t zr = (uint32_t)k * D::NZ;
-        double du0 = f.kf0, du1 = f.kf1;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
-        MPC_U(P.DZ, (zr + 0)) = du0;
-        MPC_U(P.DZ, (zr + 1)) = du1;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) MPC_U(P.DZ, (zr + 2 + i)) = dx[i];
-        double dn[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dn[i] = dx[i] - f.cn[i];
-        dn[0] += f.a[0] * dx[3] + f.a[1] * dx[4];
-        dn[1] += f.a[2] * dx[3] + f.a[3] * dx[4];
-        dn[2] += dt * du0;
-        dn[3] += dt * du1;
-        dn[4] += f.a[4] * dx[2] + f.a[5] * dx[3];
-        if (NX == 6) dn[5] += dt * dx[3];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = dn[i];
-    };
+    auto fwd_step = [&](int k, const FwdStage<NX>& f) { riccati_forward_step<NX>(P, bb, k, f, dx); };
     int k = 0;
     for (; k + 1 < N; k += 2) {
         fwd_load<NX>(P, bb, k + 1, fb);

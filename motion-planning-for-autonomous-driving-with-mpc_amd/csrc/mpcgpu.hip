@@ -129,10 +129,182 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
     phase_finish<NX>(P, c, r3, n_mult, n_z);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_riccati: block-tridiagonal (Riccati) factor + solve.  One workgroup = one tile of 64 instances = two wavefronts:
+//   wave 1 (loader)  streams the condensed stage blocks HBM -> LDS with asynchronous buffer->LDS DMA (1 KiB per wave
+//                    instruction, no VGPR round trip) RIC_DEPTH-1 stages ahead into a ring of RIC_DEPTH slots; its
+//                    vmcnt counter tracks nothing but those DMAs, so "stage k has landed" is an exact s_waitcnt.
+//   wave 0 (compute) one instance per lane: s_barrier -> ds_read of the stage block -> ~220 fp64 FMAs -> fire-and-forget
+//                    stores of gains / cost-to-go; it never waits on HBM.
+// The stage block of stage k is ONE contiguous 512*NBLK-byte chunk of the tile-major workspace, so the LDS image is
+// [row][lane] and every ds_read_b64 is conflict free.  Arithmetic: riccati_backward_step / riccati_forward_step of
+// mpc_stage_math.h (shared with the CPU emulation harness).  Inertia correction: if some lane finds an indefinite
+// 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int RIC_DEPTH = 4;
+
+template <int NCH>
+__device__ __forceinline__ void wait_dma_behind(int stages_behind) {
+    // wait until at most `stages_behind` stage-DMAs (NCH buffer ops each) are still in flight
+    if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+    else if (stages_behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int NX>
-__global__ void __launch_bounds__(64) k_riccati(const Params P) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b < P.B) riccati_instance<NX>(P, b);
+__global__ void __launch_bounds__(128) k_riccati(const Params P) {
+#if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
+    using D = Dim<NX>;
+    constexpr int NS = D::NS;
+    constexpr uint32_t BLK_BYTES = D::NBLK * 512u;
+    constexpr int BLK_CHUNKS = (BLK_BYTES + 1023u) / 1024u;
+    constexpr uint32_t SLOT = BLK_CHUNKS * 1024u;
+    constexpr int KK_CHUNKS = (D::NKK * 512u + 1023u) / 1024u;
+    constexpr int FWD_CHUNKS = KK_CHUNKS + 6;                      // gains + A rows + defect rows
+    constexpr uint32_t FSLOT = FWD_CHUNKS * 1024u;
+    static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* flag = reinterpret_cast<int*>(smem + RIC_DEPTH * SLOT);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x;
+    const int b = (int)(tile * 64u) + lane;
+    const uint32_t bb = (uint32_t)b;
+    const int N = P.N;
+    const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
+    if (!__any(active ? 1 : 0)) return;                             // both waves see the same 64 instances
+    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    const uint32_t tile_off = tile * P.tile_elems * 8u;
+    const uint32_t blk_base = (uint32_t)(uintptr_t)P.BLK - (uint32_t)(uintptr_t)P.WS + tile_off;
+    const uint32_t kk_base = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS + tile_off;
+    auto dma = [&](uint32_t src_, uint32_t dst_, int nchunks) {
+        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)src_), dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst_);
+#pragma unroll
+        for (int c = 0; c < nchunks; ++c)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + dst + (uint32_t)c * 1024u), 16, lane * 16, (int)(src + (uint32_t)c * 1024u), 0, 0);
+    };
+    auto lds_d = [&](uint32_t off) { return *reinterpret_cast<const double*>(smem + off + (uint32_t)lane * 8u); };
+    auto read_stage = [&](uint32_t slot, RicStage<NX>& s) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s.H[i] = lds_d(slot + (D::B_H + i) * 512u);
+        s.ruu[0] = lds_d(slot + (D::B_RUU) * 512u);
+        s.ruu[1] = lds_d(slot + (D::B_RUU + 1) * 512u);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s.a[i] = lds_d(slot + (D::B_A + i) * 512u);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { s.gx[i] = lds_d(slot + (D::B_GX + i) * 512u); s.cn[i] = lds_d(slot + (D::B_CN + i) * 512u); }
+        s.gu[0] = lds_d(slot + (D::B_GU) * 512u);
+        s.gu[1] = lds_d(slot + (D::B_GU + 1) * 512u);
+    };
+    // ================================================================ backward sweep(s)
+    double delta = 0.0, delta_last = 0.0, hux0 = 0.0, hux1 = 0.0;
+    bool need = false, failed = false;
+    if (wave == 0) {
+        need = active;
+        if (active) { delta_last = MPC_U(P.SC, (uint32_t)SC_DLAST); hux0 = MPC_U(P.SC, (uint32_t)SC_HUX0); hux1 = MPC_U(P.SC, (uint32_t)SC_HUX1); }
+    }
+    for (;;) {
+        if (wave == 1) {
+            // ---------------- loader: stages N, N-1, ... ; stage N-t lives in slot t % RIC_DEPTH
+            for (int j = 0; j < RIC_DEPTH - 1 && j <= N; ++j) dma(blk_base + (uint32_t)(N - j) * BLK_BYTES, (uint32_t)j * SLOT, BLK_CHUNKS);
+            for (int t = 0; t <= N; ++t) {
+                const int k = N - t;
+                wait_dma_behind<BLK_CHUNKS>(k < RIC_DEPTH - 2 ? k : RIC_DEPTH - 2);       // stage k has landed
+                __syncthreads();                                                           // compute: go on stage k (and is done with k+1)
+                const int kn = k - (RIC_DEPTH - 1);
+                if (kn >= 0) dma(blk_base + (uint32_t)kn * BLK_BYTES, (uint32_t)((t + RIC_DEPTH - 1) % RIC_DEPTH) * SLOT, BLK_CHUNKS);
+            }
+        } else {
+            // ---------------- compute
+            bool ok = need;
+            double Ps[NS], pv[NX];
+            for (int t = 0; t <= N; ++t) {
+                const int k = N - t;
+                __syncthreads();
+                RicStage<NX> s;
+                read_stage((uint32_t)(t % RIC_DEPTH) * SLOT, s);
+                if (t == 0) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
+                    if (ok) {
+                        const uint32_t pk = (uint32_t)N * D::NPK;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) MPC_U(P.PK, pk + i) = Ps[i];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) MPC_U(P.PK, pk + NS + i) = pv[i];
+                    }
+                } else if (ok) {
+                    ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+                }
+            }
+            if (need && ok) need = false;
+            else if (need) {
+                if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);
+                else delta *= (delta_last == 0.0) ? KW_PLUS_BAR : KW_PLUS;
+                if (delta > DW_MAX) { need = false; failed = true; }
+            }
+            const int again = __any(need ? 1 : 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // gains / cost-to-go are out
+            if (lane == 0) *flag = again;
+        }
+        __syncthreads();
+        const int again = *flag;
+        __syncthreads();
+        if (!again) break;
+    }
+    // ================================================================ forward sweep
+    const bool go = (wave == 0) && active && !failed;
+    if (wave == 1) {
+        auto dma_fwd = [&](int k, uint32_t dst) {
+            dma(kk_base + (uint32_t)k * (D::NKK * 512u), dst, KK_CHUNKS);
+            dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_A * 512u, dst + KK_CHUNKS * 1024u, 3);
+            dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_CN * 512u, dst + (KK_CHUNKS + 3) * 1024u, 3);
+        };
+        for (int j = 0; j < RIC_DEPTH - 1 && j < N; ++j) dma_fwd(j, (uint32_t)j * FSLOT);
+        for (int k = 0; k < N; ++k) {
+            const int left = N - 1 - k;                                                    // stages after k already requested
+            wait_dma_behind<FWD_CHUNKS>(left < RIC_DEPTH - 2 ? left : RIC_DEPTH - 2);
+            __syncthreads();
+            const int kn = k + RIC_DEPTH - 1;
+            if (kn < N) dma_fwd(kn, (uint32_t)((k + RIC_DEPTH - 1) % RIC_DEPTH) * FSLOT);
+        }
+    } else {
+        if (active && failed) MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7;
+        if (go) {
+            if (delta > 0.0) MPC_U(P.SC, (uint32_t)SC_DLAST) = delta;
+            MPC_U(P.SC, (uint32_t)SC_DELTA) = delta;
+        }
+        double dx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = go ? -(double)MPC_U(P.SC, (uint32_t)(SC_C0 + i)) : 0.0;
+        for (int k = 0; k < N; ++k) {
+            const uint32_t slot = (uint32_t)(k % RIC_DEPTH) * FSLOT;
+            __syncthreads();
+            FwdStage<NX> f;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                f.K0[j] = lds_d(slot + (uint32_t)j * 512u);
+                f.K1[j] = lds_d(slot + (uint32_t)(NX + j) * 512u);
+                f.cn[j] = lds_d(slot + (KK_CHUNKS + 3) * 1024u + (uint32_t)j * 512u);
+            }
+            f.kf0 = lds_d(slot + (uint32_t)(2 * NX) * 512u);
+            f.kf1 = lds_d(slot + (uint32_t)(2 * NX + 1) * 512u);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) f.a[i] = lds_d(slot + KK_CHUNKS * 1024u + (uint32_t)i * 512u);
+            if (go) riccati_forward_step<NX>(P, bb, k, f, dx);
+        }
+        if (go) {
+            const uint32_t zr = (uint32_t)N * D::NZ;
+            MPC_U(P.DZ, zr + 0) = 0.0;
+            MPC_U(P.DZ, zr + 1) = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) MPC_U(P.DZ, zr + 2 + i) = dx[i];
+        }
+    }
+#endif
 }
 
 template <int NX>
@@ -402,6 +574,14 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int nw = threads / 64;
     const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * NX * threads) * sizeof(double);   // reductions + stage exchange
     const int rblk = (int)(Bp / 64);
+    const size_t ric_lds = RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024 + 64;   // ring of stage slots + flag
+    {
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[NX - 5]) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
+            attr_set[NX - 5] = true;
+        }
+    }
 
     prof.begin(2);
     hipLaunchKernelGGL((k_prestart<NX>), dim3(rblk), dim3(64), 0, stream, P);
@@ -424,7 +604,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const int n = std::min(trace ? 1 : chunk, cap - it);
         for (int j = 0; j < n; ++j, ++it) {
             prof.begin(0);
-            hipLaunchKernelGGL((k_riccati<NX>), dim3(rblk), dim3(64), 0, stream, P);
+            hipLaunchKernelGGL((k_riccati<NX>), dim3(rblk), dim3(128), ric_lds, stream, P);
             prof.end();
             prof.begin(1);
             hipLaunchKernelGGL((k_stage<NX, false>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
