@@ -233,6 +233,38 @@ MPC_HD double push_in(double v, double lo, double hi) {
 // IPOPT's Compare_le (IpUtils.cpp): lhs <= rhs up to 10 machine epsilons of a reference magnitude
 MPC_HD bool cmp_le(double lhs, double rhs, double base) { return lhs - rhs <= EPS10 * fabs(base); }
 
+// multiplier step of one bound side and its fraction-to-the-boundary candidates.  gap > 0 is the distance to the
+// bound, dg its change along the step, z its multiplier; ig returns 1/gap (shared by the callers: one division per side)
+MPC_HD double side_step(double gap, double z, double dg, double mu, double tau, double& a_pr, double& a_du, double& ig) {
+    ig = 1.0 / gap;
+    const double dz = (mu - z * dg) * ig - z;               // mu/gap - z - (z/gap) dg
+    if (dg < 0) a_pr = fmin(a_pr, -tau * gap / dg);
+    if (dz < 0) a_du = fmin(a_du, -tau * z / dz);
+    return dz;
+}
+// new multiplier after the dual step, clamped to [mu/(kappa gap), kappa mu/gap] (IPOPT eq. (16)); ign = 1/gap_new
+MPC_HD double side_update(double ig_old, double z, double dg, double mu, double a_du, double ign) {
+    const double dz = (mu - z * dg) * ig_old - z;
+    const double lo = mu * ign * (1.0 / KAPPA_SIGMA), hi = KAPPA_SIGMA * mu * ign;
+    return fmin(fmax(z + a_du * dz, lo), hi);
+}
+// KKT bookkeeping of one bound side at the new iterate: sigma, barrier-gradient factor, complementarity, log product
+MPC_HD void side_kkt(double gap, double z, double sign, int mult, double& sg, double& gbb, double& rz, double& cmin, double& cmax,
+                     double& sz, double& gp) {
+    const double ig = 1.0 / gap;
+    sg += z * ig;
+    gbb -= sign * ig;
+    rz -= sign * z;
+    const double cc = gap * z;
+    cmin = fmin(cmin, cc);
+    cmax = fmax(cmax, cc);
+    sz += mult * z;
+    double gm = gap;
+    for (int q = 1; q < mult; ++q) gm *= gap;
+    gp *= gm;
+}
+MPC_HD double powi_small(double g, int m) { double r = g; for (int q = 1; q < m; ++q) r *= g; return r; }
+
 MPC_HD double zreset(double z, double gap, double mu) {
     const double lo = mu / (KAPPA_SIGMA * gap), hi = KAPPA_SIGMA * mu / gap;
     return fmin(fmax(z, lo), hi);
@@ -249,6 +281,10 @@ struct Ctx {
     double z[NZ], dz[NZ];
     double xn[NX], dxn[NX];          // x_{k+1} and its step (k < N)
     double lam[NX], lamn[NX];        // equality multipliers of stage k and k+1 at the new iterate (exchanged through LDS)
+    double zl[NZ], zu[NZ];           // bound multipliers of (u_k, x_k), register resident across the phases (0 = no bound)
+    double nuo[3], zlo[3], zuo[3];   // obstacle-row multipliers and their slack-bound multipliers
+    double nuf, zlf, zuf;            // friction row (k == 0, only when the row is kept)
+    double pw_theta, pw_dphi;        // theta^s_theta, (-dphi)^s_phi of the switching condition (cached per line search)
     double rn[NX];                   // r_{k+1} (k < N)
     double so[3], dso[3];
     double sf, dsf;                  // friction slack (k == 0)
@@ -451,8 +487,10 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
         const double v = push_in(raw, lb, ub);
         c.z[i] = v;
         MPC_K(P.Z, NZ, 0, i) = v;
-        MPC_K(P.ZL, NZ, 0, i) = has_lo(lb) ? 1.0 : 0.0;
-        MPC_K(P.ZU, NZ, 0, i) = has_hi(ub) ? 1.0 : 0.0;
+        c.zl[i] = has_lo(lb) ? 1.0 : 0.0;
+        c.zu[i] = has_hi(ub) ? 1.0 : 0.0;
+        MPC_K(P.ZL, NZ, 0, i) = c.zl[i];
+        MPC_K(P.ZU, NZ, 0, i) = c.zu[i];
         MPC_K(P.DZ, NZ, 0, i) = 0.0;
     }
 #pragma unroll
@@ -475,18 +513,24 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     for (int j = 0; j < 3; ++j) {
         c.so[j] = push_in(dist[j], ol, ou);
         MPC_K(P.SO, 3, 0, j) = c.so[j];
+        c.nuo[j] = 0.0;
+        c.zlo[j] = P.has_ol ? 1.0 : 0.0;
+        c.zuo[j] = P.has_ou ? 1.0 : 0.0;
         MPC_K(P.NUO, 3, 0, j) = 0.0;
-        MPC_K(P.ZLO, 3, 0, j) = P.has_ol ? 1.0 : 0.0;
-        MPC_K(P.ZUO, 3, 0, j) = P.has_ou ? 1.0 : 0.0;
+        MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
+        MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
     }
     if (k == 0) {
         const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
         const double dfr = c.fric_row ? friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false) : 0.0;
         c.sf = c.fric_row ? push_in(dfr, fl, fu) : 0.0;
         MPC_S(P.SC, SC_SF) = c.sf;
+        c.nuf = 0.0;
+        c.zlf = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
+        c.zuf = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
         MPC_S(P.SC, SC_NUF) = 0.0;
-        MPC_S(P.SC, SC_ZLF) = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
-        MPC_S(P.SC, SC_ZUF) = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
+        MPC_S(P.SC, SC_ZLF) = c.zlf;
+        MPC_S(P.SC, SC_ZUF) = c.zuf;
         MPC_S(P.SC, SC_DFRIC) = 0.0;
         MPC_S(P.SC, SC_GFR0) = 0.0;
         MPC_S(P.SC, SC_GFR1) = 0.0;
@@ -573,26 +617,15 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         const double dv = MPC_K(P.DZ, NZ, 0, i);
         c.z[i] = zi;
         c.dz[i] = dv;
+        c.zl[i] = MPC_K(P.ZL, NZ, 0, i);        // unconditional loads: nothing waits behind a data-dependent branch
+        c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
         if (isu && k == N) continue;
         MPC_BOUNDS(k, i, lb, ub);
         double gradf = 0.0;
         if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
-        double gb = 0.0;
-        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
-        if (has_lo(lb)) {
-            const double gap = zi - lb, zl = zl_ld;
-            const double dzl = mu / gap - zl - zl / gap * dv;
-            gb -= mu / gap;
-            if (dv < 0) a_pr = fmin(a_pr, -tau * gap / dv);
-            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
-        }
-        if (has_hi(ub)) {
-            const double gap = ub - zi, zu = zu_ld;
-            const double dzu = mu / gap - zu + zu / gap * dv;
-            gb += mu / gap;
-            if (dv > 0) a_pr = fmin(a_pr, tau * gap / dv);
-            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
-        }
+        double gb = 0.0, ig;
+        if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
+        if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
         dphi += (gradf + gb) * dv;
     }
 #pragma unroll
@@ -610,46 +643,29 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         for (int a = 0; a < 3; ++a) ds += MPC_K(P.EV, D::NEV, 0, 3 + 3 * j + a) * c.dz[2 + oi[a]];
         c.so[j] = s;
         c.dso[j] = ds;
-        double gb = 0.0;
-        if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
-            const double dzl = mu / gap - zl - zl / gap * ds;
-            gb -= mu / gap;
-            if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
-            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
-        }
-        if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
-            const double dzu = mu / gap - zu + zu / gap * ds;
-            gb += mu / gap;
-            if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
-            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
-        }
+        c.nuo[j] = MPC_K(P.NUO, 3, 0, j);
+        c.zlo[j] = P.has_ol ? (double)MPC_K(P.ZLO, 3, 0, j) : 0.0;
+        c.zuo[j] = P.has_ou ? (double)MPC_K(P.ZUO, 3, 0, j) : 0.0;
+        double gb = 0.0, ig;
+        if (P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
+        if (P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
         dphi += m * gb * ds;
     }
     c.sf = 0.0;
     c.dsf = 0.0;
+    c.nuf = c.zlf = c.zuf = 0.0;
     if (k == 0 && c.fric_row) {
         const double s = MPC_S(P.SC, SC_SF);
         const double ds = MPC_S(P.SC, SC_DFRIC) - s + MPC_S(P.SC, SC_GFR0) * c.dz[1] + MPC_S(P.SC, SC_GFR1) * c.dz[2 + 2] +
                           MPC_S(P.SC, SC_GFR2) * c.dz[2 + 3];
         c.sf = s;
         c.dsf = ds;
-        double gb = 0.0;
-        if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
-            const double dzl = mu / gap - zl - zl / gap * ds;
-            gb -= mu / gap;
-            if (ds < 0) a_pr = fmin(a_pr, -tau * gap / ds);
-            if (dzl < 0) a_du = fmin(a_du, -tau * zl / dzl);
-        }
-        if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
-            const double dzu = mu / gap - zu + zu / gap * ds;
-            gb += mu / gap;
-            if (ds > 0) a_pr = fmin(a_pr, tau * gap / ds);
-            if (dzu < 0) a_du = fmin(a_du, -tau * zu / dzu);
-        }
+        c.nuf = MPC_S(P.SC, SC_NUF);
+        c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
+        c.zuf = P.has_fu ? (double)MPC_S(P.SC, SC_ZUF) : 0.0;
+        double gb = 0.0, ig;
+        if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
+        if (P.has_fu) { side_step(P.fu - s, c.zuf, -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
         dphi += gb * ds;
     }
     red.a_pr = a_pr;
@@ -669,8 +685,14 @@ MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red)
     c.a_du = red.a_du;
     c.dphi = red.dphi;
     double a_min;
+    c.pw_theta = 0.0;
+    c.pw_dphi = 0.0;
+    if (c.dphi < 0 && c.theta <= c.thmin) {          // the only case in which the switching condition can hold
+        c.pw_theta = pow(c.theta, S_THETA);
+        c.pw_dphi = pow(-c.dphi, S_PHI);
+    }
     if (c.dphi < 0 && c.theta <= c.thmin)
-        a_min = fmin(fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi)), LS_DELTA * pow(c.theta, S_THETA) / pow(-c.dphi, S_PHI));
+        a_min = fmin(fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi)), LS_DELTA * c.pw_theta / c.pw_dphi);
     else if (c.dphi < 0)
         a_min = fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi));
     else
@@ -692,7 +714,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     if (!(c.active && c.searching)) return;
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double al = c.alpha;
-    double theta = 0.0, fc = 0.0, ls = 0.0, bad = 0.0;
+    double theta = 0.0, fc = 0.0, gp = 1.0, bad = 0.0;      // gp: product of all gaps; sum of logs = log(gp), one log per thread
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
@@ -700,8 +722,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         c.zt[i] = v;
         if (isu && k == N) continue;
         MPC_BOUNDS(k, i, lb, ub);
-        if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else ls += log(gap); }
-        if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+        if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
+        if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
         if (k < N) {
             if (isu) fc += P.R[i] * v * v;
             else { const double e = v - c.rn[i - 2]; fc += P.Q[i - 2] * e * e; }
@@ -727,8 +749,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         const double s = c.so[j] + al * c.dso[j];
         c.sot[j] = s;
         theta += m * fabs(dist[j] - s);
-        if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
-        if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else ls += m * log(gap); }
+        if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+        if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
     }
     c.sft = 0.0;
     if (k == 0 && c.fric_row) {
@@ -736,12 +758,12 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         c.sft = s;
         const double dfr = friction_eval(P, c.zt[1], c.zt[2 + 2], c.zt[2 + 3], nullptr, nullptr, false);
         theta += fabs(dfr - s);
-        if (P.has_fl) { const double gap = s - P.fl; if (gap <= 0) bad = 1.0; else ls += log(gap); }
-        if (P.has_fu) { const double gap = P.fu - s; if (gap <= 0) bad = 1.0; else ls += log(gap); }
+        if (P.has_fl) { const double gap = s - P.fl; if (gap <= 0) bad = 1.0; else gp *= gap; }
+        if (P.has_fu) { const double gap = P.fu - s; if (gap <= 0) bad = 1.0; else gp *= gap; }
     }
     red.theta = theta;
     red.fcost = fc;
-    red.logsum = ls;
+    red.logsum = log(gp);
     red.bad = bad;
 }
 
@@ -761,7 +783,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
         c.accepted = true;
         c.ftype = true;
     } else if (good) {
-        const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha * pow(-c.dphi, S_PHI) > LS_DELTA * pow(c.theta, S_THETA);
+        const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha * c.pw_dphi > LS_DELTA * c.pw_theta;
         if (sw) {
             if (cmp_le(ph_t - c.phi, ETA_PHI * c.alpha * c.dphi, c.phi)) { c.accepted = true; c.ftype = true; }
         } else if (cmp_le(fmax(th_t, THETA_FLOOR), fmax((1 - GAMMA_THETA) * c.theta, THETA_FLOOR), c.theta) ||
@@ -798,17 +820,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
         MPC_K(P.Z, NZ, 0, i) = zn;
-        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
-        if (has_lo(lb)) {
-            const double gap = zi - lb, zl = zl_ld;
-            const double dzl = mu / gap - zl - zl / gap * dv;
-            MPC_K(P.ZL, NZ, 0, i) = zreset(zl + ad * dzl, zn - lb, mu);
-        }
-        if (has_hi(ub)) {
-            const double gap = ub - zi, zu = zu_ld;
-            const double dzu = mu / gap - zu + zu / gap * dv;
-            MPC_K(P.ZU, NZ, 0, i) = zreset(zu + ad * dzu, ub - zn, mu);
-        }
+        if (has_lo(lb)) { c.zl[i] = side_update(1.0 / (zi - lb), c.zl[i], dv, mu, ad, 1.0 / (zn - lb)); MPC_K(P.ZL, NZ, 0, i) = c.zl[i]; }
+        if (has_hi(ub)) { c.zu[i] = side_update(1.0 / (ub - zi), c.zu[i], -dv, mu, ad, 1.0 / (ub - zn)); MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
         c.z[i] = zn;
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k)
@@ -829,19 +842,19 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
         double sg = 0.0, gb = 0.0;
         if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
-            const double dzl = mu / gap - zl - zl / gap * ds;
-            sg += zl / gap; gb -= mu / gap;
-            MPC_K(P.ZLO, 3, 0, j) = zreset(zl + ad * dzl, sn - P.ol, mu);
+            const double ig = 1.0 / (s - P.ol);
+            sg += c.zlo[j] * ig; gb -= mu * ig;
+            c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, 1.0 / (sn - P.ol));
+            MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
         }
         if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
-            const double dzu = mu / gap - zu + zu / gap * ds;
-            sg += zu / gap; gb += mu / gap;
-            MPC_K(P.ZUO, 3, 0, j) = zreset(zu + ad * dzu, P.ou - sn, mu);
+            const double ig = 1.0 / (P.ou - s);
+            sg += c.zuo[j] * ig; gb += mu * ig;
+            c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, 1.0 / (P.ou - sn));
+            MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
         }
-        const double nu = MPC_K(P.NUO, 3, 0, j);
-        MPC_K(P.NUO, 3, 0, j) = nu + al * (gb - nu + sg * ds);
+        c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
+        MPC_K(P.NUO, 3, 0, j) = c.nuo[j];
         MPC_K(P.SO, 3, 0, j) = sn;
         c.so[j] = sn;
     }
@@ -849,19 +862,19 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
-            const double dzl = mu / gap - zl - zl / gap * ds;
-            sg += zl / gap; gb -= mu / gap;
-            MPC_S(P.SC, SC_ZLF) = zreset(zl + ad * dzl, sn - P.fl, mu);
+            const double ig = 1.0 / (s - P.fl);
+            sg += c.zlf * ig; gb -= mu * ig;
+            c.zlf = side_update(ig, c.zlf, ds, mu, ad, 1.0 / (sn - P.fl));
+            MPC_S(P.SC, SC_ZLF) = c.zlf;
         }
         if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
-            const double dzu = mu / gap - zu + zu / gap * ds;
-            sg += zu / gap; gb += mu / gap;
-            MPC_S(P.SC, SC_ZUF) = zreset(zu + ad * dzu, P.fu - sn, mu);
+            const double ig = 1.0 / (P.fu - s);
+            sg += c.zuf * ig; gb += mu * ig;
+            c.zuf = side_update(ig, c.zuf, -ds, mu, ad, 1.0 / (P.fu - sn));
+            MPC_S(P.SC, SC_ZUF) = c.zuf;
         }
-        const double nu = MPC_S(P.SC, SC_NUF);
-        MPC_S(P.SC, SC_NUF) = nu + al * (gb - nu + sg * ds);
+        c.nuf += al * (gb - c.nuf + sg * ds);
+        MPC_S(P.SC, SC_NUF) = c.nuf;
         MPC_S(P.SC, SC_SF) = sn;
         c.sf = sn;
     }
@@ -981,7 +994,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
             prim = fmax(prim, fabs(c0));
         }
     }
-    // variable bounds
+    // variable bounds (multipliers are register resident: c.zl / c.zu)
+    double gp = 1.0;                                           // product of all gaps; sum of logs = log(gp)
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
@@ -989,21 +1003,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i];
         double sg = 0.0, gbb = 0.0, rz = 0.0;
-        const double zl_ld = MPC_K(P.ZL, NZ, 0, i), zu_ld = MPC_K(P.ZU, NZ, 0, i);   // unconditional: no load behind a branch
-        if (has_lo(lb)) {
-            const double gap = zi - lb, zl = zl_ld;
-            sg += zl / gap; gbb -= 1.0 / gap; rz -= zl;
-            const double cc = gap * zl;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
-            ls += log(gap);
-        }
-        if (has_hi(ub)) {
-            const double gap = ub - zi, zu = zu_ld;
-            sg += zu / gap; gbb += 1.0 / gap; rz += zu;
-            const double cc = gap * zu;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
-            ls += log(gap);
-        }
+        if (has_lo(lb)) side_kkt(zi - lb, c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+        if (has_hi(ub)) side_kkt(ub - zi, c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
         if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
         else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
     }
@@ -1013,22 +1014,10 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     const int oi[3] = {0, 1, 4};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double s = c.so[j], nu = MPC_K(P.NUO, 3, 0, j);
+        const double s = c.so[j], nu = c.nuo[j];
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_ol) {
-            const double gap = s - P.ol, zl = MPC_K(P.ZLO, 3, 0, j);
-            sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
-            const double cc = gap * zl;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zl;
-            ls += m * log(gap);
-        }
-        if (P.has_ou) {
-            const double gap = P.ou - s, zu = MPC_K(P.ZUO, 3, 0, j);
-            sg += zu / gap; gbb += 1.0 / gap; rs += zu;
-            const double cc = gap * zu;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += m * zu;
-            ls += m * log(gap);
-        }
+        if (P.has_ol) side_kkt(s - P.ol, c.zlo[j], 1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_ou) side_kkt(P.ou - s, c.zuo[j], -1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
         dual = fmax(dual, fabs(rs));
         const double res = dist[j] - s;
         theta += m * fabs(res);
@@ -1051,22 +1040,10 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     if (k == 0 && c.fric_row) {
         double g[3], h[4];
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
-        const double s = c.sf, nu = MPC_S(P.SC, SC_NUF);
+        const double s = c.sf, nu = c.nuf;
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_fl) {
-            const double gap = s - P.fl, zl = MPC_S(P.SC, SC_ZLF);
-            sg += zl / gap; gbb -= 1.0 / gap; rs -= zl;
-            const double cc = gap * zl;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zl;
-            ls += log(gap);
-        }
-        if (P.has_fu) {
-            const double gap = P.fu - s, zu = MPC_S(P.SC, SC_ZUF);
-            sg += zu / gap; gbb += 1.0 / gap; rs += zu;
-            const double cc = gap * zu;
-            cmin = fmin(cmin, cc); cmax = fmax(cmax, cc); sz += zu;
-            ls += log(gap);
-        }
+        if (P.has_fl) side_kkt(s - P.fl, c.zlf, 1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_fu) side_kkt(P.fu - s, c.zuf, -1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
         dual = fmax(dual, fabs(rs));
         const double res = dfr - s;
         theta += fabs(res);
@@ -1111,6 +1088,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_CN + i) = cn[i];
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
+    ls = log(gp);
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
 }
 
@@ -1141,7 +1119,7 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         for (int guard = 0; guard < 64; ++guard) {
             const double Emu = fmax(base, (n_z ? fmax(red.cmax - mu, mu - red.cmin) : 0.0) / s_c);
             if (!(Emu <= KAPPA_EPS * mu)) break;
-            const double nm = fmax(P.tol / 10.0, fmin(KAPPA_MU * mu, pow(mu, THETA_MU)));
+            const double nm = fmax(P.tol / 10.0, fmin(KAPPA_MU * mu, mu * sqrt(mu)));     // theta_mu = 1.5
             if (nm == mu) break;
             mu = nm;
             tau = fmax(TAU_MIN, 1.0 - mu);
