@@ -103,6 +103,7 @@ struct Params {
     int32_t* IWS;                // base of the int32 workspace
     uint32_t ws_bytes, iws_bytes;
     uint32_t tile_elems, itile_elems;   // elements per 64-instance tile of the double / int32 workspace
+    unsigned long long* DBG;            // optional [blocks][16] shader-clock stamps of the stage kernel (profiling aid), or null
     double* x_out;               // [B][n_w] row-major (ABI output)
     int32_t* status_out;
     int32_t* iters_out;
@@ -284,6 +285,9 @@ struct Ctx {
     double zl[NZ], zu[NZ];           // bound multipliers of (u_k, x_k), register resident across the phases (0 = no bound)
     double nuo[3], zlo[3], zuo[3];   // obstacle-row multipliers and their slack-bound multipliers
     double nuf, zlf, zuf;            // friction row (k == 0, only when the row is kept)
+    double dlam[NX];                 // step of the equality multipliers, -(P_k dx_k + p_k) - lambda_k
+    double r0[NX];                   // r_0 (k == 0)
+    double dfric0, gfr0[3];          // friction row value / gradient at the current iterate (k == 0, row kept)
     double pw_theta, pw_dphi;        // theta^s_theta, (-dphi)^s_phi of the switching condition (cached per line search)
     double rn[NX];                   // r_{k+1} (k < N)
     double so[3], dso[3];
@@ -498,6 +502,8 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
         MPC_K(P.REF, NX, 0, i) = pb[2 * N + NX * k + i];
         MPC_K(P.LAM, NX, 0, i) = 0.0;
         c.lam[i] = 0.0;
+        c.rn[i] = (k < N) ? (double)pb[2 * N + NX * (k + 1) + i] : 0.0;
+        c.r0[i] = (k == 0) ? (double)pb[2 * N + i] : 0.0;
     }
     // slacks: s = d(w0) pushed inside its bounds
     double sps, cps;
@@ -576,26 +582,97 @@ MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
 // =========================================================================================================
 template <int NX>
 MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
-    c.status = c.valid ? MPC_S(P.ISC, IS_STATUS) : 0;
-    c.active = c.valid && c.status == ST_RUNNING;
-    if (!c.active) return;
-    c.mu = MPC_S(P.SC, SC_MU);
-    c.tau = MPC_S(P.SC, SC_TAU);
-    c.df = MPC_S(P.SC, SC_DF);
-    c.theta = MPC_S(P.SC, SC_THETA);
-    c.phi = c.df * MPC_S(P.SC, SC_FCOST) - c.mu * MPC_S(P.SC, SC_LOGSUM);
-    c.thmax = MPC_S(P.SC, SC_THMAX);
-    c.thmin = MPC_S(P.SC, SC_THMIN);
-    c.nfilt = MPC_S(P.ISC, IS_NFILT);
-    c.iters = MPC_S(P.ISC, IS_ITERS);
-    c.conv = P.fixed_iters > 0 && MPC_S(P.ISC, IS_CONV) != 0;
-    c.fric_row = MPC_S(P.ISC, IS_FROW) != 0;
-    c.a0lb = MPC_S(P.SC, SC_A0LB);
-    c.a0ub = MPC_S(P.SC, SC_A0UB);
-    if (!MPC_S(P.ISC, IS_HAVETH0)) {      // first iteration: theta_max / theta_min from theta(w_0)
-        c.thmax = 1e4 * fmax(1.0, c.theta);
-        c.thmin = 1e-4 * fmax(1.0, c.theta);
+    c.status = 0;
+    c.active = false;
+    if (!c.valid) return;
+    // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
+    const int32_t status = MPC_S(P.ISC, IS_STATUS), nfilt = MPC_S(P.ISC, IS_NFILT), iters = MPC_S(P.ISC, IS_ITERS);
+    const int32_t convf = MPC_S(P.ISC, IS_CONV), frow = MPC_S(P.ISC, IS_FROW), haveth0 = MPC_S(P.ISC, IS_HAVETH0);
+    const double mu = MPC_S(P.SC, SC_MU), tau = MPC_S(P.SC, SC_TAU), df = MPC_S(P.SC, SC_DF), theta = MPC_S(P.SC, SC_THETA);
+    const double fcost = MPC_S(P.SC, SC_FCOST), logsum = MPC_S(P.SC, SC_LOGSUM);
+    const double thmax = MPC_S(P.SC, SC_THMAX), thmin = MPC_S(P.SC, SC_THMIN);
+    const double a0lb = MPC_S(P.SC, SC_A0LB), a0ub = MPC_S(P.SC, SC_A0UB);
+    c.status = status;
+    c.active = status == ST_RUNNING;
+    c.mu = mu; c.tau = tau; c.df = df; c.theta = theta;
+    c.phi = df * fcost - mu * logsum;
+    c.thmax = thmax; c.thmin = thmin;
+    c.nfilt = nfilt; c.iters = iters;
+    c.conv = P.fixed_iters > 0 && convf != 0;
+    c.fric_row = frow != 0;
+    c.a0lb = a0lb; c.a0ub = a0ub;
+    if (!haveth0) {                        // first iteration: theta_max / theta_min from theta(w_0)
+        c.thmax = 1e4 * fmax(1.0, theta);
+        c.thmin = 1e-4 * fmax(1.0, theta);
     }
+}
+
+// all array loads of the stage kernel in ONE batch (no dependence on the per-instance scalars), plus the arithmetic
+// that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
+template <int NX>
+MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    if (!c.valid) return;
+    const int N = P.N, k = c.k;
+    load_obst(P, c);
+    double pk[D::NPK], lam[NX], ev[D::NEV];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        c.z[i] = MPC_K(P.Z, NZ, 0, i);
+        c.dz[i] = MPC_K(P.DZ, NZ, 0, i);
+        c.zl[i] = MPC_K(P.ZL, NZ, 0, i);
+        c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
+        c.xn[i] = (k < N) ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : 0.0;
+        c.dxn[i] = (k < N) ? (double)MPC_K(P.DZ, NZ, 1, 2 + i) : 0.0;
+        lam[i] = MPC_K(P.LAM, NX, 0, i);
+        c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < D::NPK; ++i) pk[i] = MPC_K(P.PK, D::NPK, 0, i);
+#pragma unroll
+    for (int i = 0; i < D::NEV; ++i) ev[i] = MPC_K(P.EV, D::NEV, 0, i);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        c.so[j] = MPC_K(P.SO, 3, 0, j);
+        c.nuo[j] = MPC_K(P.NUO, 3, 0, j);
+        c.zlo[j] = P.has_ol ? (double)MPC_K(P.ZLO, 3, 0, j) : 0.0;
+        c.zuo[j] = P.has_ou ? (double)MPC_K(P.ZUO, 3, 0, j) : 0.0;
+    }
+    c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
+    c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
+    if (k == 0) {                                          // (fric_row is not known yet; the values are only used if it is set)
+        c.sf = MPC_S(P.SC, SC_SF);
+        c.nuf = MPC_S(P.SC, SC_NUF);
+        c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
+        c.zuf = P.has_fu ? (double)MPC_S(P.SC, SC_ZUF) : 0.0;
+        c.dfric0 = MPC_S(P.SC, SC_DFRIC);
+        c.gfr0[0] = MPC_S(P.SC, SC_GFR0);
+        c.gfr0[1] = MPC_S(P.SC, SC_GFR1);
+        c.gfr0[2] = MPC_S(P.SC, SC_GFR2);
+    }
+    // ---- arithmetic on loaded arrays only
+    const int oi[3] = {0, 1, 4};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double ds = ev[j] - c.so[j];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ds += ev[3 + 3 * j + a] * c.dz[2 + oi[a]];
+        c.dso[j] = ds;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double s = pk[D::NS + i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
+        c.lam[i] = lam[i];
+        c.dlam[i] = -s - lam[i];
+    }
+    c.dsf = c.dfric0 - c.sf + c.gfr0[0] * c.dz[1] + c.gfr0[1] * c.dz[2 + 2] + c.gfr0[2] * c.dz[2 + 3];
 }
 
 template <int NX>
@@ -607,19 +684,11 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double mu = c.mu, tau = c.tau;
     double a_pr = 1.0, a_du = 1.0, dphi = 0.0;
-    load_obst(P, c);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) c.rn[i] = (k < N) ? MPC_K(P.REF, NX, 1, i) : 0.0;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
-        const double zi = MPC_K(P.Z, NZ, 0, i);
-        const double dv = MPC_K(P.DZ, NZ, 0, i);
-        c.z[i] = zi;
-        c.dz[i] = dv;
-        c.zl[i] = MPC_K(P.ZL, NZ, 0, i);        // unconditional loads: nothing waits behind a data-dependent branch
-        c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
         if (isu && k == N) continue;
+        const double zi = c.z[i], dv = c.dz[i];
         MPC_BOUNDS(k, i, lb, ub);
         double gradf = 0.0;
         if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
@@ -629,44 +698,21 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         dphi += (gradf + gb) * dv;
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        c.xn[i] = (k < N) ? MPC_K(P.Z, NZ, 1, 2 + i) : 0.0;
-        c.dxn[i] = (k < N) ? MPC_K(P.DZ, NZ, 1, 2 + i) : 0.0;
-    }
-    // obstacle slacks: ds = J dx + (d - s)
-    const int oi[3] = {0, 1, 4};
-#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double s = MPC_K(P.SO, 3, 0, j);
-        double ds = MPC_K(P.EV, D::NEV, 0, j) - s;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) ds += MPC_K(P.EV, D::NEV, 0, 3 + 3 * j + a) * c.dz[2 + oi[a]];
-        c.so[j] = s;
-        c.dso[j] = ds;
-        c.nuo[j] = MPC_K(P.NUO, 3, 0, j);
-        c.zlo[j] = P.has_ol ? (double)MPC_K(P.ZLO, 3, 0, j) : 0.0;
-        c.zuo[j] = P.has_ou ? (double)MPC_K(P.ZUO, 3, 0, j) : 0.0;
+        const double s = c.so[j], ds = c.dso[j];
         double gb = 0.0, ig;
         if (P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
         if (P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
         dphi += m * gb * ds;
     }
-    c.sf = 0.0;
-    c.dsf = 0.0;
-    c.nuf = c.zlf = c.zuf = 0.0;
     if (k == 0 && c.fric_row) {
-        const double s = MPC_S(P.SC, SC_SF);
-        const double ds = MPC_S(P.SC, SC_DFRIC) - s + MPC_S(P.SC, SC_GFR0) * c.dz[1] + MPC_S(P.SC, SC_GFR1) * c.dz[2 + 2] +
-                          MPC_S(P.SC, SC_GFR2) * c.dz[2 + 3];
-        c.sf = s;
-        c.dsf = ds;
-        c.nuf = MPC_S(P.SC, SC_NUF);
-        c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
-        c.zuf = P.has_fu ? (double)MPC_S(P.SC, SC_ZUF) : 0.0;
+        const double s = c.sf, ds = c.dsf;
         double gb = 0.0, ig;
         if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
         if (P.has_fu) { side_step(P.fu - s, c.zuf, -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
         dphi += gb * ds;
+    } else {
+        c.sf = c.dsf = c.nuf = c.zlf = c.zuf = 0.0;
     }
     red.a_pr = a_pr;
     red.a_du = a_du;
@@ -740,7 +786,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     }
     if (k == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - MPC_S(P.REF, i));
+        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - c.r0[i]);
     }
     double dist[3];
     obstacle_eval(P, c.obst, c.zt[2], c.zt[3], sps, cps, dist, nullptr, nullptr, false);
@@ -824,17 +870,10 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         if (has_hi(ub)) { c.zu[i] = side_update(1.0 / (ub - zi), c.zu[i], -dv, mu, ad, 1.0 / (ub - zn)); MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
         c.z[i] = zn;
     }
-    // equality multipliers: lambda+ = -(P_k dx_k + p_k)
+    // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        double s = MPC_K(P.PK, D::NPK, 0, D::NS + i);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int r = (i <= j) ? D::sidx(i, j) : D::sidx(j, i);
-            s += MPC_K(P.PK, D::NPK, 0, r) * c.dz[2 + j];
-        }
-        const double lam = MPC_K(P.LAM, NX, 0, i);
-        c.lam[i] = lam + al * (-s - lam);
+        c.lam[i] += al * c.dlam[i];
         MPC_K(P.LAM, NX, 0, i) = c.lam[i];
     }
 #pragma unroll
@@ -930,7 +969,6 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         lam[i] = c.lam[i];
         lamn[i] = (k < N) ? c.lamn[i] : 0.0;
         if (k >= N) c.xn[i] = 0.0;
-        c.rn[i] = (k < N) ? MPC_K(P.REF, NX, 1, i) : 0.0;
     }
     ode_eval<NX>(P, x, u, f, sps, cps, td);
     const double cd = cos(x[2]), secd2 = 1.0 / (cd * cd), v = x[3], il = 1.0 / P.wheelbase;
@@ -988,7 +1026,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     if (k == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double c0 = x[i] - MPC_S(P.REF, i);
+            const double c0 = x[i] - c.r0[i];
             MPC_S(P.SC, SC_C0 + i) = c0;
             theta += fabs(c0);
             prim = fmax(prim, fabs(c0));

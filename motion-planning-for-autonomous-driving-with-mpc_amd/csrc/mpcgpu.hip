@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,7 +33,7 @@ using namespace mpc;
 // ============================================================================================== device
 namespace {
 
-constexpr int STAGE_MAX_THREADS = 512;
+constexpr int STAGE_MAX_THREADS = 256;
 
 template <typename R>
 __device__ __forceinline__ R shfl_xor_struct(const R& r, int mask) {
@@ -90,6 +91,8 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
     c.active = false;
     c.status = 0;
     c.iters = 0;
+#define MPC_STAMP(i) do { if (P.DBG && t == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    MPC_STAMP(0);
     if (INIT) {
         Red0 r0;
         phase_init_point<NX>(P, c, r0);
@@ -97,18 +100,25 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
         phase_init_scalars<NX>(P, c, r0);
     } else {
         phase_load_scalars<NX>(P, c);
+        phase_preload<NX>(P, c);                       // every array load of the kernel is in flight before the first wait
+        MPC_STAMP(1);
         if (!__syncthreads_or(c.active ? 1 : 0)) return;
+        MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX>(P, c, r1);
+        MPC_STAMP(3);
         block_reduce(r1, bx, lds);
         phase_linesearch_begin<NX>(P, c, r1);
+        MPC_STAMP(4);
         while (__syncthreads_or((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
+        MPC_STAMP(5);
         phase_apply_update<NX>(P, c);
+        MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
     {
@@ -123,10 +133,15 @@ __global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, con
             for (int i = 0; i < NX; ++i) { c.xn[i] = ex[i * T + tn]; c.lamn[i] = ex[(NX + i) * T + tn]; }
         }
     }
+    MPC_STAMP(7);
     Red3 r3;
     phase_eval_assemble<NX>(P, c, r3);
+    MPC_STAMP(8);
     block_reduce(r3, bx, lds);
+    MPC_STAMP(9);
     phase_finish<NX>(P, c, r3, n_mult, n_z);
+    MPC_STAMP(10);
+#undef MPC_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -570,6 +585,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     const int S = d.N + 1;
     const int threads = ((S * bx + 63) / 64) * 64;
+    const bool stage_timing = getenv("MPCGPU_STAGE_TIMING") != nullptr;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
     const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * NX * threads) * sizeof(double);   // reductions + stage exchange
@@ -599,6 +615,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         HIP_TRY(h, hipMemcpy(trace + (size_t)it * 8 * B, d_trace, sizeof(double) * 8 * (size_t)B, hipMemcpyDeviceToHost));
         return MPC_OK;
     };
+    unsigned long long* d_dbg = nullptr;
+    if (stage_timing) {
+        HIP_TRY(h, hipMalloc(&d_dbg, sizeof(unsigned long long) * 16 * (size_t)nblk));
+        HIP_TRY(h, hipMemset(d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)nblk));
+    }
     int it = 0;
     while (it < cap) {
         const int n = std::min(trace ? 1 : chunk, cap - it);
@@ -607,6 +628,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             hipLaunchKernelGGL((k_riccati<NX>), dim3(rblk), dim3(128), ric_lds, stream, P);
             prof.end();
             prof.begin(1);
+            if (stage_timing && it == 2) P.DBG = d_dbg; else P.DBG = nullptr;      // stamp the third iteration
             hipLaunchKernelGGL((k_stage<NX, false>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
             prof.end();
             if (trace) { rc = record_trace(it); if (rc) return rc; }
@@ -620,6 +642,23 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (*h->h_counter == 0) break;
     }
     if (trace) { rc = record_trace(it); if (rc) return rc; (void)hipFree(d_trace); }
+    if (stage_timing) {
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        std::vector<unsigned long long> hd((size_t)16 * nblk);
+        HIP_TRY(h, hipMemcpy(hd.data(), d_dbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double acc[10] = {0};
+        int cnt = 0;
+        for (int bq = 0; bq < nblk; ++bq) {
+            if (!hd[(size_t)bq * 16 + 10]) continue;
+            for (int q = 0; q < 10; ++q) acc[q] += (double)(hd[(size_t)bq * 16 + q + 1] - hd[(size_t)bq * 16 + q]);
+            ++cnt;
+        }
+        fprintf(stderr, "[mpcgpu stage timing, shader-clock ticks per block, mean over %d blocks]", cnt);
+        static const char* names[10] = {"issue-loads", "wait+barrier", "P1", "reduce1", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3", "P5"};
+        for (int q = 0; q < 10; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
+        fprintf(stderr, "\n");
+        (void)hipFree(d_dbg);
+    }
     if (n_it_out) *n_it_out = it;
     prof.begin(2);
     hipLaunchKernelGGL((k_output<NX>), dim3(rblk), dim3(64), 0, stream, P);
