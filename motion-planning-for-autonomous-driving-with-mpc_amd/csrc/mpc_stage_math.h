@@ -392,14 +392,33 @@ MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
 // (bound-projected) control guess), the state guess is replaced by that rollout.  The optimum the solver
 // converges to is a KKT point of the same NLP either way.
 // =========================================================================================================
+// caller rows -> workspace (what the LDS-tiled k_ingest kernel does on the GPU): Z <- x0 (raw), REF <- X_ref part of p
+template <int NX>
+MPC_HD void ingest_instance(const Params& P, int b) {
+    constexpr int NZ = NX + 2;
+    const int N = P.N;
+    const uint32_t bb = (uint32_t)b;
+    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+    const double* x0b = P.x0 + (size_t)b * nw;
+    const double* pb = P.p + (size_t)b * nw;
+    for (int k = 0; k <= N; ++k) {
+        for (int i = 0; i < 2; ++i) MPC_U(P.Z, (uint32_t)k * NZ + i) = (k < N) ? x0b[2 * k + i] : 0.0;
+        for (int i = 0; i < NX; ++i) {
+            MPC_U(P.Z, (uint32_t)k * NZ + 2 + i) = x0b[2 * N + NX * k + i];
+            MPC_U(P.REF, (uint32_t)k * NX + i) = pb[2 * N + NX * k + i];
+        }
+    }
+}
+
 template <int NX>
 MPC_HD void prestart_instance(const Params& P, int b) {
     constexpr int NZ = NX + 2;
     const int N = P.N;
     const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;
-    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-    const MPC_GLOBAL_AS double* x0b = (const MPC_GLOBAL_AS double*)P.x0 + (size_t)bb * nw;
-    const MPC_GLOBAL_AS double* pb = (const MPC_GLOBAL_AS double*)P.p + (size_t)bb * nw;
+    // the caller's rows were transposed into the workspace by the ingest kernel: Z holds the raw x0, REF holds X_ref
+#define X0U(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + (uint32_t)(i_)))
+#define X0X(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + 2u + (uint32_t)(i_)))
+#define PRX(k_, i_) ((double)MPC_U(P.REF, (uint32_t)(k_) * NX + (uint32_t)(i_)))
     // presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
     // by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
     // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
@@ -407,7 +426,7 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     double a0lb = MPC_GP(P.LB, 1), a0ub = MPC_GP(P.UB, 1);
     int frow = 1;
     if (!P.has_fl && P.has_fu) {
-        const double dl0 = pb[2 * N + 2], v0 = pb[2 * N + 3];
+        const double dl0 = PRX(0, 2), v0 = PRX(0, 3);
         const double cf = v0 * (tan(dl0) * v0 / P.friction_div);
         const double Rhi = P.fu - cf, Rlo = -P.fu - cf;
         if (Rhi > 0.0 && Rlo <= 0.0) {
@@ -424,23 +443,23 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     double th_g = 0.0, th_r = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const double r0 = pb[2 * N + i];
-        xg[i] = push_in(x0b[2 * N + i], MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
+        const double r0 = PRX(0, i);
+        xg[i] = push_in(X0X(0, i), MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
         xr[i] = push_in(r0, MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
         th_g += fabs(xg[i] - r0);
         th_r += fabs(xr[i] - r0);
         MPC_U(P.ROLL, (uint32_t)i) = xr[i];
     }
     for (int k = 0; k < N; ++k) {
-        u[0] = push_in(x0b[2 * k], MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
-        u[1] = push_in(x0b[2 * k + 1], (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
+        u[0] = push_in(X0U(k, 0), MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
+        u[1] = push_in(X0U(k, 1), (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
         double fr[NX];
         ode_eval<NX>(P, xg, u, f, s, c, td);
         ode_eval<NX>(P, xr, u, fr, s, c, td);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double lb = MPC_GP(P.LB, (k + 1) * NZ + 2 + i), ub = MPC_GP(P.UB, (k + 1) * NZ + 2 + i);
-            const double gn = push_in(x0b[2 * N + NX * (k + 1) + i], lb, ub);
+            const double gn = push_in(X0X(k + 1, i), lb, ub);
             th_g += fabs(gn - (f[i] * P.dt + xg[i]));
             xg[i] = gn;
             const double rraw = fr[i] * P.dt + xr[i];
@@ -453,6 +472,9 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     const bool use = !(th_g <= ROLLOUT_FACTOR * fmax(1.0, th_r));      // also true when th_g is NaN
     MPC_U(P.ISC, (uint32_t)IS_ROLL) = use ? 1 : 0;
 }
+#undef X0U
+#undef X0X
+#undef PRX
 
 // =========================================================================================================
 // Phase 0 (init kernel only): build the start iterate from the caller's x0 (IPOPT section 3.6)
@@ -464,9 +486,6 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     red = red_neutral0();
     if (!c.valid) return;
     const int N = P.N, k = c.k;
-    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-    const MPC_GLOBAL_AS double* x0b = (const MPC_GLOBAL_AS double*)P.x0 + (size_t)c.b * nw;
-    const MPC_GLOBAL_AS double* pb = (const MPC_GLOBAL_AS double*)P.p + (size_t)c.b * nw;
     load_obst(P, c);
     c.fric_row = MPC_S(P.ISC, IS_FROW) != 0;
     c.a0lb = MPC_S(P.SC, SC_A0LB);
@@ -478,14 +497,14 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
         const bool isu = i < 2;
         double raw = 0.0, lb = -INFINITY, ub = INFINITY;
         if (!(isu && k == N)) {
-            raw = isu ? x0b[2 * k + i] : (roll ? MPC_K(P.ROLL, NX, 0, (i - 2)) : x0b[2 * N + NX * k + (i - 2)]);
+            raw = (!isu && roll) ? (double)MPC_K(P.ROLL, NX, 0, (i - 2)) : (double)MPC_K(P.Z, NZ, 0, i);    // raw x0 (ingested)
             lb = MPC_GP(P.LB, k * NZ + i);
             ub = MPC_GP(P.UB, k * NZ + i);
             if (k == 0 && i == 1) { lb = c.a0lb; ub = c.a0ub; }
         }
         if (k < N) {
             // |grad f| at the user's start point (objective scaling, IPOPT section 3.8)
-            const double g = isu ? 2 * P.R[i] * raw : 2 * P.Q[i - 2] * (raw - pb[2 * N + NX * (k + 1) + (i - 2)]);
+            const double g = isu ? 2 * P.R[i] * raw : 2 * P.Q[i - 2] * (raw - (double)MPC_K(P.REF, NX, 1, (i - 2)));
             gmax = fmax(gmax, fabs(g));
         }
         const double v = push_in(raw, lb, ub);
@@ -499,11 +518,10 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        MPC_K(P.REF, NX, 0, i) = pb[2 * N + NX * k + i];
         MPC_K(P.LAM, NX, 0, i) = 0.0;
         c.lam[i] = 0.0;
-        c.rn[i] = (k < N) ? (double)pb[2 * N + NX * (k + 1) + i] : 0.0;
-        c.r0[i] = (k == 0) ? (double)pb[2 * N + i] : 0.0;
+        c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
+        c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
     }
     // slacks: s = d(w0) pushed inside its bounds
     double sps, cps;

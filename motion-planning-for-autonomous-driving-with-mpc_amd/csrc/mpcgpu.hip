@@ -13,7 +13,7 @@
 //                      Hessian and writes the banded KKT blocks.
 //   k_riccati<NX>      one thread per instance, sequential over the stages: block-tridiagonal (Riccati)
 //                      factor + solve of the condensed KKT system, with the sparsity of A_k, B_k hard-wired.
-//   k_output<NX>       SoA iterate -> caller's row-major result.
+//   k_ingest / k_egest LDS-tiled transposes between the caller's row-major buffers and the tile-major workspace.
 // HBM layout: structure-of-arrays [row][instance]; a 64-lane wavefront touches 64 (k_riccati) or bx (k_stage)
 // consecutive doubles per row => fully coalesced 512 B / 128-256 B segments.
 #include <hip/hip_runtime.h>
@@ -33,7 +33,9 @@ using namespace mpc;
 // ============================================================================================== device
 namespace {
 
-constexpr int STAGE_MAX_THREADS = 256;
+// stage-kernel workgroups: 256 threads (one wave per SIMD, the full 512-entry register file, no scratch) when
+// bx * (N + 1) <= 256 with bx >= 8 instances, else 512 threads
+constexpr int STAGE_MAX_THREADS = 512;
 
 template <typename R>
 __device__ __forceinline__ R shfl_xor_struct(const R& r, int mask) {
@@ -80,8 +82,8 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
     }
 }
 
-template <int NX, bool INIT>
-__global__ void __launch_bounds__(STAGE_MAX_THREADS) k_stage(const Params P, const int n_mult, const int n_z) {
+template <int NX, bool INIT, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
@@ -328,10 +330,82 @@ __global__ void __launch_bounds__(64) k_prestart(const Params P) {
     if (b < P.B) prestart_instance<NX>(P, b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_ingest / k_egest: LDS-tiled transposes between the caller's row-major [B][n_w] buffers (optimizer.py:550 order)
+// and the tile-major workspace.  One workgroup per tile of 64 instances; both the global reads and the global
+// writes are 512-byte contiguous per wavefront.
+//   ingest:  Z[(k, i)] <- x0 (raw),  REF[(k, i)] <- X_ref part of p        egest:  x_out <- Z, plus status/iters/kkt
+// ---------------------------------------------------------------------------------------------------------------
 template <int NX>
-__global__ void __launch_bounds__(64) k_output(const Params P) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b < P.B) output_instance<NX>(P, b);
+__device__ __forceinline__ uint32_t zrow_of_col(int col, int N) {          // decision-vector column -> row of Z
+    constexpr int NZ = NX + 2;
+    if (col < 2 * N) return (uint32_t)(col >> 1) * NZ + (uint32_t)(col & 1);
+    const int cx = col - 2 * N;
+    return (uint32_t)(cx / NX) * NZ + 2u + (uint32_t)(cx % NX);
+}
+
+template <int NX>
+__global__ void __launch_bounds__(256) k_ingest(const Params P) {
+    __shared__ double tile[64][65];
+    const int N = P.N, nw = 2 * N + NX * (N + 1);
+    const uint32_t t0 = blockIdx.x * 64u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* Zt = P.Z + (size_t)blockIdx.x * P.tile_elems;
+    double* Rt = P.REF + (size_t)blockIdx.x * P.tile_elems;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* src = pass == 0 ? P.x0 : P.p;
+        for (int c0 = (pass == 0 ? 0 : 2 * N); c0 < nw; c0 += 64) {
+            for (int r = w; r < 64; r += 4) {
+                const int col = c0 + lane;
+                const uint32_t b = t0 + (uint32_t)r;
+                tile[r][lane] = (col < nw && b < (uint32_t)P.B) ? src[(size_t)b * nw + col] : 0.0;
+            }
+            __syncthreads();
+            for (int cc = w; cc < 64; cc += 4) {
+                const int col = c0 + cc;
+                if (col < nw) {
+                    if (pass == 0) Zt[zrow_of_col<NX>(col, N) * 64u + lane] = tile[lane][cc];
+                    else Rt[(uint32_t)(col - 2 * N) * 64u + lane] = tile[lane][cc];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // u rows of the terminal stage do not exist in x0
+    constexpr int NZ = NX + 2;
+    if (threadIdx.x < 128) Zt[((uint32_t)N * NZ + (threadIdx.x >> 6)) * 64u + lane] = 0.0;
+}
+
+template <int NX>
+__global__ void __launch_bounds__(256) k_egest(const Params P) {
+    __shared__ double tile[64][65];
+    const int N = P.N, nw = 2 * N + NX * (N + 1);
+    const uint32_t t0 = blockIdx.x * 64u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double* Zt = P.Z + (size_t)blockIdx.x * P.tile_elems;
+    for (int c0 = 0; c0 < nw; c0 += 64) {
+        for (int cc = w; cc < 64; cc += 4) {
+            const int col = c0 + cc;
+            tile[lane][cc] = (col < nw) ? Zt[zrow_of_col<NX>(col, N) * 64u + lane] : 0.0;
+        }
+        __syncthreads();
+        for (int r = w; r < 64; r += 4) {
+            const int col = c0 + lane;
+            const uint32_t b = t0 + (uint32_t)r;
+            if (col < nw && b < (uint32_t)P.B) P.x_out[(size_t)b * nw + col] = tile[r][lane];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        const uint32_t b = t0 + (uint32_t)lane;
+        if (b < (uint32_t)P.B) {
+            int st = P.ISC[blockIdx.x * P.itile_elems + (uint32_t)IS_STATUS * 64u + lane];
+            if (st == ST_RUNNING) st = 0;          // iteration budget of the launch loop exhausted
+            if (P.status_out) P.status_out[b] = st;
+            if (P.iters_out) P.iters_out[b] = P.ISC[blockIdx.x * P.itile_elems + (uint32_t)IS_ITERS * 64u + lane];
+            if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)blockIdx.x * P.tile_elems + (uint32_t)SC_E0 * 64u + lane];
+        }
+    }
 }
 
 __global__ void k_count_running(const int32_t* iws, uint32_t itile_elems, int B, int32_t* counter) {
@@ -573,7 +647,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (Bp != h->cap_Bp) { h->cap_Bp = 0; }
     int rc = ensure_ws(h, Bp);
     if (rc) return rc;
-    const int bx = pick_bx(d.N, STAGE_MAX_THREADS);
+    const bool small_wg = 8 * (d.N + 1) <= 256;
+    const int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
@@ -600,8 +675,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
 
     prof.begin(2);
+    hipLaunchKernelGGL((k_ingest<NX>), dim3(rblk), dim3(256), 0, stream, P);
     hipLaunchKernelGGL((k_prestart<NX>), dim3(rblk), dim3(64), 0, stream, P);
-    hipLaunchKernelGGL((k_stage<NX, true>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+    if (small_wg) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+    else hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
     prof.end();
 
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
@@ -629,7 +706,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.end();
             prof.begin(1);
             if (stage_timing && it == 2) P.DBG = d_dbg; else P.DBG = nullptr;      // stamp the third iteration
-            hipLaunchKernelGGL((k_stage<NX, false>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+            if (small_wg) hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
+            else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
             prof.end();
             if (trace) { rc = record_trace(it); if (rc) return rc; }
         }
@@ -661,7 +739,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     if (n_it_out) *n_it_out = it;
     prof.begin(2);
-    hipLaunchKernelGGL((k_output<NX>), dim3(rblk), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL((k_egest<NX>), dim3(rblk), dim3(256), 0, stream, P);
     prof.end();
     HIP_TRY(h, hipGetLastError());
     h->prof[5] = it;

@@ -71,6 +71,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         for (int t = 0; t < nthreads; ++t) phase_finish<NX>(P, ctx[t], r3[t], hp.n_mult, hp.n_z);
     };
     // ---- start-point safeguard kernel: one instance per thread
+    for (int b = 0; b < B; ++b) ingest_instance<NX>(P, b);
     for (int b = 0; b < B; ++b) prestart_instance<NX>(P, b);
     // ---- init kernel
     for (int blk = 0; blk < nblocks; ++blk) {
