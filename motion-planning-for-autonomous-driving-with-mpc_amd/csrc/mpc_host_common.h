@@ -171,6 +171,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.ws_bytes = (uint32_t)(w.total * sizeof(double)); P.iws_bytes = (uint32_t)(w.itotal * sizeof(int32_t));
     P.x_out = nullptr; P.status_out = nullptr; P.iters_out = nullptr; P.kkt_out = nullptr;
     P.DBG = nullptr;
+    P.tile0 = 0;
 }
 
 inline void default_desc(mpc_problem_desc* d, int32_t N, int32_t nx) {

@@ -103,6 +103,7 @@ struct Params {
     int32_t* IWS;                // base of the int32 workspace
     uint32_t ws_bytes, iws_bytes;
     uint32_t tile_elems, itile_elems;   // elements per 64-instance tile of the double / int32 workspace
+    int32_t tile0;                      // first 64-instance tile handled by this launch (sub-batch pipelining)
     unsigned long long* DBG;            // optional [blocks][16] shader-clock stamps of the stage kernel (profiling aid), or null
     double* x_out;               // [B][n_w] row-major (ABI output)
     int32_t* status_out;

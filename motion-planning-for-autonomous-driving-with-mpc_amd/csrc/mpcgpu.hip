@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
-    c.b = blockIdx.x * bx + (t & (bx - 1));
+    c.b = (int)((blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + (t & (bx - 1));
     c.valid = (c.k <= P.N) && (c.b < P.B);
     c.active = false;
     c.status = 0;
@@ -159,12 +159,15 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr int RIC_DEPTH = 4;
+constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 22 KiB each)
+constexpr int RIC_DEPTH_F = 6;      // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead
 
 template <int NCH>
 __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
     // wait until at most `stages_behind` stage-DMAs (NCH buffer ops each) are still in flight
-    if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+    if (stages_behind >= 4 && 4 * NCH <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NCH <= 63 ? 4 * NCH : 0) : "memory");
+    else if (stages_behind >= 3 && 3 * NCH <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCH <= 63 ? 3 * NCH : 0) : "memory");
+    else if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
     else if (stages_behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -180,17 +183,20 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
     constexpr int KK_CHUNKS = (D::NKK * 512u + 1023u) / 1024u;
     constexpr int FWD_CHUNKS = KK_CHUNKS + 6;                      // gains + A rows + defect rows
     constexpr uint32_t FSLOT = FWD_CHUNKS * 1024u;
-    static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4, "vmcnt is a 6-bit counter");
+    static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4 && 4 * FWD_CHUNKS <= 63 && RIC_DEPTH_F == 6, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* flag = reinterpret_cast<int*>(smem + RIC_DEPTH * SLOT);
+    constexpr uint32_t RING_BYTES = (RIC_DEPTH * SLOT > RIC_DEPTH_F * FSLOT) ? RIC_DEPTH * SLOT : RIC_DEPTH_F * FSLOT;
+    int* flag = reinterpret_cast<int*>(smem + RING_BYTES);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x + (uint32_t)P.tile0;
     const int b = (int)(tile * 64u) + lane;
     const uint32_t bb = (uint32_t)b;
     const int N = P.N;
     const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
     if (!__any(active ? 1 : 0)) return;                             // both waves see the same 64 instances
+#define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
     const uint32_t tile_off = tile * P.tile_elems * 8u;
     const uint32_t blk_base = (uint32_t)(uintptr_t)P.BLK - (uint32_t)(uintptr_t)P.WS + tile_off;
@@ -238,7 +244,9 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             double Ps[NS], pv[NX];
             for (int t = 0; t <= N; ++t) {
                 const int k = N - t;
+                if (t == 15) RIC_STAMP(3);
                 __syncthreads();
+                if (t == 15) RIC_STAMP(4);
                 RicStage<NX> s;
                 read_stage((uint32_t)(t % RIC_DEPTH) * SLOT, s);
                 if (t == 0) {
@@ -256,6 +264,7 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
                 } else if (ok) {
                     ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
                 }
+                if (t == 15) RIC_STAMP(5);
             }
             if (need && ok) need = false;
             else if (need) {
@@ -272,6 +281,7 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
         __syncthreads();
         if (!again) break;
     }
+    RIC_STAMP(1);
     // ================================================================ forward sweep
     const bool go = (wave == 0) && active && !failed;
     if (wave == 1) {
@@ -280,13 +290,13 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_A * 512u, dst + KK_CHUNKS * 1024u, 3);
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_CN * 512u, dst + (KK_CHUNKS + 3) * 1024u, 3);
         };
-        for (int j = 0; j < RIC_DEPTH - 1 && j < N; ++j) dma_fwd(j, (uint32_t)j * FSLOT);
+        for (int j = 0; j < RIC_DEPTH_F - 1 && j < N; ++j) dma_fwd(j, (uint32_t)j * FSLOT);
         for (int k = 0; k < N; ++k) {
             const int left = N - 1 - k;                                                    // stages after k already requested
-            wait_dma_behind<FWD_CHUNKS>(left < RIC_DEPTH - 2 ? left : RIC_DEPTH - 2);
+            wait_dma_behind<FWD_CHUNKS>(left < RIC_DEPTH_F - 2 ? left : RIC_DEPTH_F - 2);
             __syncthreads();
-            const int kn = k + RIC_DEPTH - 1;
-            if (kn < N) dma_fwd(kn, (uint32_t)((k + RIC_DEPTH - 1) % RIC_DEPTH) * FSLOT);
+            const int kn = k + RIC_DEPTH_F - 1;
+            if (kn < N) dma_fwd(kn, (uint32_t)((k + RIC_DEPTH_F - 1) % RIC_DEPTH_F) * FSLOT);
         }
     } else {
         if (active && failed) MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7;
@@ -298,8 +308,10 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = go ? -(double)MPC_U(P.SC, (uint32_t)(SC_C0 + i)) : 0.0;
         for (int k = 0; k < N; ++k) {
-            const uint32_t slot = (uint32_t)(k % RIC_DEPTH) * FSLOT;
+            const uint32_t slot = (uint32_t)(k % RIC_DEPTH_F) * FSLOT;
+            if (k == 15) RIC_STAMP(6);
             __syncthreads();
+            if (k == 15) RIC_STAMP(7);
             FwdStage<NX> f;
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
@@ -311,7 +323,10 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             f.kf1 = lds_d(slot + (uint32_t)(2 * NX + 1) * 512u);
 #pragma unroll
             for (int i = 0; i < 6; ++i) f.a[i] = lds_d(slot + KK_CHUNKS * 1024u + (uint32_t)i * 512u);
-            if (go) riccati_forward_step<NX>(P, bb, k, f, dx);
+            // executed by every lane (finished / padding instances just write an unused step): keeping the stores out of
+            // a divergent branch spares a waterfall loop around each of them
+            riccati_forward_step<NX>(P, bb, k, f, dx);
+            if (k == 15) RIC_STAMP(8);
         }
         if (go) {
             const uint32_t zr = (uint32_t)N * D::NZ;
@@ -321,12 +336,14 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             for (int i = 0; i < NX; ++i) MPC_U(P.DZ, zr + 2 + i) = dx[i];
         }
     }
+    RIC_STAMP(2);
+#undef RIC_STAMP
 #endif
 }
 
 template <int NX>
 __global__ void __launch_bounds__(64) k_prestart(const Params P) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + threadIdx.x;
     if (b < P.B) prestart_instance<NX>(P, b);
 }
 
@@ -348,10 +365,10 @@ template <int NX>
 __global__ void __launch_bounds__(256) k_ingest(const Params P) {
     __shared__ double tile[64][65];
     const int N = P.N, nw = 2 * N + NX * (N + 1);
-    const uint32_t t0 = blockIdx.x * 64u;
+    const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double* Zt = P.Z + (size_t)blockIdx.x * P.tile_elems;
-    double* Rt = P.REF + (size_t)blockIdx.x * P.tile_elems;
+    double* Zt = P.Z + (size_t)tl * P.tile_elems;
+    double* Rt = P.REF + (size_t)tl * P.tile_elems;
     for (int pass = 0; pass < 2; ++pass) {
         const double* src = pass == 0 ? P.x0 : P.p;
         for (int c0 = (pass == 0 ? 0 : 2 * N); c0 < nw; c0 += 64) {
@@ -380,9 +397,9 @@ template <int NX>
 __global__ void __launch_bounds__(256) k_egest(const Params P) {
     __shared__ double tile[64][65];
     const int N = P.N, nw = 2 * N + NX * (N + 1);
-    const uint32_t t0 = blockIdx.x * 64u;
+    const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double* Zt = P.Z + (size_t)blockIdx.x * P.tile_elems;
+    const double* Zt = P.Z + (size_t)tl * P.tile_elems;
     for (int c0 = 0; c0 < nw; c0 += 64) {
         for (int cc = w; cc < 64; cc += 4) {
             const int col = c0 + cc;
@@ -399,17 +416,17 @@ __global__ void __launch_bounds__(256) k_egest(const Params P) {
     if (threadIdx.x < 64) {
         const uint32_t b = t0 + (uint32_t)lane;
         if (b < (uint32_t)P.B) {
-            int st = P.ISC[blockIdx.x * P.itile_elems + (uint32_t)IS_STATUS * 64u + lane];
+            int st = P.ISC[tl * P.itile_elems + (uint32_t)IS_STATUS * 64u + lane];
             if (st == ST_RUNNING) st = 0;          // iteration budget of the launch loop exhausted
             if (P.status_out) P.status_out[b] = st;
-            if (P.iters_out) P.iters_out[b] = P.ISC[blockIdx.x * P.itile_elems + (uint32_t)IS_ITERS * 64u + lane];
-            if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)blockIdx.x * P.tile_elems + (uint32_t)SC_E0 * 64u + lane];
+            if (P.iters_out) P.iters_out[b] = P.ISC[tl * P.itile_elems + (uint32_t)IS_ITERS * 64u + lane];
+            if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)tl * P.tile_elems + (uint32_t)SC_E0 * 64u + lane];
         }
     }
 }
 
-__global__ void k_count_running(const int32_t* iws, uint32_t itile_elems, int B, int32_t* counter) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_count_running(const int32_t* iws, uint32_t itile_elems, int b0, int B, int32_t* counter) {
+    const int b = b0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int run = (b < B && iws[((uint32_t)b >> 6) * itile_elems + (uint32_t)IS_STATUS * 64u + ((uint32_t)b & 63u)] == ST_RUNNING) ? 1 : 0;
     const unsigned long long m = __ballot(run);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
@@ -481,6 +498,11 @@ struct mpc_handle {
     double *d_x0 = nullptr, *d_p = nullptr, *d_xout = nullptr, *d_kkt = nullptr, *d_obst = nullptr;
     int32_t *d_status = nullptr, *d_iters = nullptr;
     hipStream_t own_stream = nullptr;
+    // sub-batch pipelining: up to MAX_GROUPS tile groups iterate on their own streams so that the latency-bound
+    // Riccati sweep of one group overlaps the stage kernels of the others
+    static constexpr int MAX_GROUPS = 4;
+    hipStream_t sub_stream[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     // profiling
     bool profiling = false;
     double prof[6] = {0, 0, 0, 0, 0, 0};
@@ -539,11 +561,17 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     h->hp.desc = *desc;
     h->device = desc->device;
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&h->d_counter, sizeof(int32_t)) != hipSuccess || hipHostMalloc(&h->h_counter, sizeof(int32_t)) != hipSuccess) {
+        hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS) != hipSuccess ||
+        hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS) != hipSuccess) {
         g_create_error = "HIP stream/counter allocation failed";
         delete h;
         return MPC_ERR_HIP;
     }
+    bool ok_streams = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int g = 0; g < mpc_handle::MAX_GROUPS && ok_streams; ++g)
+        ok_streams = hipStreamCreateWithFlags(&h->sub_stream[g], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming) == hipSuccess;
+    if (!ok_streams) { g_create_error = "HIP stream/event creation failed"; mpc_destroy(h); return MPC_ERR_HIP; }
     rc = mpc_set_bounds(h, nullptr, nullptr, nullptr, nullptr);     // reference defaults until told otherwise
     if (rc) { g_create_error = h->err; mpc_destroy(h); return rc; }
     *out = h;
@@ -560,6 +588,11 @@ int mpc_destroy(mpc_handle* h) {
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g) {
+        if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
+        if (h->sub_stream[g]) (void)hipStreamDestroy(h->sub_stream[g]);
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return MPC_OK;
@@ -620,12 +653,12 @@ struct Prof {
         }
         return h->ev_pool[used++];
     }
-    void begin(int kind) { if (h->profiling) { kinds.push_back(kind); (void)hipEventRecord(get(), s); } }
-    void end() { if (h->profiling) (void)hipEventRecord(get(), s); }
+    void begin(int kind, hipStream_t st = nullptr) { if (h->profiling) { kinds.push_back(kind); (void)hipEventRecord(get(), st ? st : s); } }
+    void end(hipStream_t st = nullptr) { if (h->profiling) (void)hipEventRecord(get(), st ? st : s); }
     void collect() {
         for (int i = 0; i < 6; ++i) h->prof[i] = 0;
         if (!h->profiling) return;
-        (void)hipStreamSynchronize(s);
+        (void)hipDeviceSynchronize();
         for (size_t i = 0; i < kinds.size(); ++i) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
@@ -665,7 +698,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int nw = threads / 64;
     const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * NX * threads) * sizeof(double);   // reductions + stage exchange
     const int rblk = (int)(Bp / 64);
-    const size_t ric_lds = RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024 + 64;   // ring of stage slots + flag
+    const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
+                                    RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
     {
         static bool attr_set[2] = {false, false};
         if (!attr_set[NX - 5]) {
@@ -674,12 +708,57 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         }
     }
 
-    prof.begin(2);
-    hipLaunchKernelGGL((k_ingest<NX>), dim3(rblk), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL((k_prestart<NX>), dim3(rblk), dim3(64), 0, stream, P);
-    if (small_wg) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
-    else hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
-    prof.end();
+    // ---- tile groups (sub-batches).  Every group runs ingest -> init -> iterations -> egest on its own stream.
+    const int ntiles = (int)(Bp / 64);
+    int G = 1;
+    // (measured on MI355X at B = 4096: 4 groups gain 4 % in fixed-iteration mode and lose in converged mode, where
+    //  every group polls on its own; the workgroups of the two kernels cannot share a CU, so the overlap is small.
+    //  Kept as an opt-in: MPCGPU_GROUPS=2..4.)
+    if (!trace && !stage_timing && getenv("MPCGPU_GROUPS") != nullptr) {
+        G = atoi(getenv("MPCGPU_GROUPS"));
+        if (G > ntiles / 4) G = ntiles / 4;
+        if (G < 1) G = 1;
+        if (G > mpc_handle::MAX_GROUPS) G = mpc_handle::MAX_GROUPS;
+    }
+    struct Group { int tile0, ntl, blk0, nblk, b0, b1; hipStream_t st; bool running; };
+    Group grp[mpc_handle::MAX_GROUPS];
+    for (int g = 0; g < G; ++g) {
+        Group& q = grp[g];
+        q.tile0 = (int)((long long)ntiles * g / G);
+        q.ntl = (int)((long long)ntiles * (g + 1) / G) - q.tile0;
+        q.b0 = q.tile0 * 64;
+        q.b1 = std::min(B, (q.tile0 + q.ntl) * 64);
+        q.nblk = (q.b1 - q.b0 + bx - 1) / bx;
+        q.st = (G == 1) ? stream : h->sub_stream[g];
+        q.running = q.b1 > q.b0;
+    }
+    if (G > 1) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
+        for (int g = 0; g < G; ++g) HIP_TRY(h, hipStreamWaitEvent(h->sub_stream[g], h->ev_fork, 0));
+    }
+    auto launch_stage = [&](const Group& q, bool init) {
+        Params Pg = P;
+        Pg.tile0 = q.tile0;
+        if (!init && stage_timing && P.DBG) Pg.DBG = P.DBG;
+        if (small_wg) {
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+            else hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+        } else {
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+            else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+        }
+    };
+    for (int g = 0; g < G; ++g) {
+        const Group& q = grp[g];
+        if (!q.running) continue;
+        Params Pg = P;
+        Pg.tile0 = q.tile0;
+        prof.begin(2, q.st);
+        hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl), dim3(256), 0, q.st, Pg);
+        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(64), 0, q.st, Pg);
+        launch_stage(q, true);
+        prof.end(q.st);
+    }
 
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     const int chunk = d.fixed_iters > 0 ? cap : 4;
@@ -700,25 +779,47 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int it = 0;
     while (it < cap) {
         const int n = std::min(trace ? 1 : chunk, cap - it);
-        for (int j = 0; j < n; ++j, ++it) {
-            prof.begin(0);
-            hipLaunchKernelGGL((k_riccati<NX>), dim3(rblk), dim3(128), ric_lds, stream, P);
-            prof.end();
-            prof.begin(1);
-            if (stage_timing && it == 2) P.DBG = d_dbg; else P.DBG = nullptr;      // stamp the third iteration
-            if (small_wg) hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
-            else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(nblk), dim3(threads), lds_bytes, stream, P, h->hp.n_mult, h->hp.n_z);
-            prof.end();
-            if (trace) { rc = record_trace(it); if (rc) return rc; }
+        bool any = false;
+        for (int j = 0; j < n; ++j) {
+            for (int g = 0; g < G; ++g) {                 // interleave the groups launch by launch
+                const Group& q = grp[g];
+                if (!q.running) continue;
+                any = true;
+                Params Pg = P;
+                Pg.tile0 = q.tile0;
+                prof.begin(0, q.st);
+                if (stage_timing && it + j == 3) Pg.DBG = d_dbg + (size_t)8 * nblk;   // Riccati stamps of the 4th iteration
+                hipLaunchKernelGGL((k_riccati<NX>), dim3(q.ntl), dim3(128), ric_lds, q.st, Pg);
+                Pg.DBG = nullptr;
+                prof.end(q.st);
+                prof.begin(1, q.st);
+                P.DBG = (stage_timing && it + j == 2) ? d_dbg : nullptr;      // stamp the third iteration
+                launch_stage(q, false);
+                prof.end(q.st);
+            }
+            if (trace) { rc = record_trace(it + j); if (rc) return rc; }
         }
-        if (d.fixed_iters > 0) break;
-        // convergence poll
-        HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), stream));
-        hipLaunchKernelGGL(k_count_running, dim3((B + 255) / 256), dim3(256), 0, stream, h->d_iws, (uint32_t)w.itile_elems, B, h->d_counter);
-        HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(h, hipStreamSynchronize(stream));
-        if (*h->h_counter == 0) break;
+        it += n;
+        if (!any || d.fixed_iters > 0) { if (d.fixed_iters > 0 && it < cap) continue; break; }
+        // convergence poll, one 4-byte counter per group
+        for (int g = 0; g < G; ++g) {
+            const Group& q = grp[g];
+            if (!q.running) continue;
+            HIP_TRY(h, hipMemsetAsync(h->d_counter + g, 0, sizeof(int32_t), q.st));
+            hipLaunchKernelGGL(k_count_running, dim3((q.b1 - q.b0 + 255) / 256), dim3(256), 0, q.st, h->d_iws, (uint32_t)w.itile_elems, q.b0, q.b1,
+                               h->d_counter + g);
+            HIP_TRY(h, hipMemcpyAsync(h->h_counter + g, h->d_counter + g, sizeof(int32_t), hipMemcpyDeviceToHost, q.st));
+        }
+        bool still = false;
+        for (int g = 0; g < G; ++g) {
+            Group& q = grp[g];
+            if (!q.running) continue;
+            HIP_TRY(h, hipStreamSynchronize(q.st));
+            if (h->h_counter[g] == 0) q.running = false; else still = true;
+        }
+        if (!still) break;
     }
+    P.DBG = nullptr;
     if (trace) { rc = record_trace(it); if (rc) return rc; (void)hipFree(d_trace); }
     if (stage_timing) {
         HIP_TRY(h, hipStreamSynchronize(stream));
@@ -735,12 +836,36 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         static const char* names[10] = {"issue-loads", "wait+barrier", "P1", "reduce1", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3", "P5"};
         for (int q = 0; q < 10; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
         fprintf(stderr, "\n");
+        {
+            double bw = 0, fw = 0;
+            int c2 = 0;
+            for (int tq = 0; tq < ntiles && (size_t)(8 * nblk + (tq + 1) * 16) <= hd.size(); ++tq) {
+                const unsigned long long* r = hd.data() + (size_t)8 * nblk + (size_t)tq * 16;
+                if (!r[2]) continue;
+                bw += (double)(r[1] - r[0]);
+                fw += (double)(r[2] - r[1]);
+                ++c2;
+                if (tq == 0) fprintf(stderr, "[riccati stage 15 of tile 0] bwd barrier-wait=%lld compute=%lld | fwd barrier-wait=%lld compute=%lld\n",
+                                     (long long)(r[4] - r[3]), (long long)(r[5] - r[4]), (long long)(r[7] - r[6]), (long long)(r[8] - r[7]));
+            }
+            fprintf(stderr, "[mpcgpu riccati timing, ticks per workgroup, mean over %d] backward=%.0f forward=%.0f\n", c2, c2 ? bw / c2 : 0.0, c2 ? fw / c2 : 0.0);
+        }
         (void)hipFree(d_dbg);
     }
     if (n_it_out) *n_it_out = it;
-    prof.begin(2);
-    hipLaunchKernelGGL((k_egest<NX>), dim3(rblk), dim3(256), 0, stream, P);
-    prof.end();
+    for (int g = 0; g < G; ++g) {
+        const Group& q = grp[g];
+        if (q.b1 <= q.b0) continue;
+        Params Pg = P;
+        Pg.tile0 = q.tile0;
+        prof.begin(2, q.st);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl), dim3(256), 0, q.st, Pg);
+        prof.end(q.st);
+        if (G > 1) {
+            HIP_TRY(h, hipEventRecord(h->ev_join[g], q.st));
+            HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_join[g], 0));
+        }
+    }
     HIP_TRY(h, hipGetLastError());
     h->prof[5] = it;
     if (d.fixed_iters <= 0 || h->profiling) HIP_TRY(h, hipStreamSynchronize(stream));
