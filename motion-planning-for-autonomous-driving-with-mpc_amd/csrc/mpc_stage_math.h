@@ -121,8 +121,10 @@ typedef unsigned int mpc_v2u __attribute__((ext_vector_type(2)));
 // can PROVE they are wave-uniform (otherwise each buffer op is wrapped in a waterfall loop)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mpc_rsrc(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)(uintptr_t)base;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes);
+    asm("" : "+s"(lo), "+s"(hi), "+s"(bytes));       // pin to SGPRs right at the use (a phi through divergent control flow would move the descriptor to VGPRs)
     return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ int mpc_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
@@ -171,12 +173,16 @@ __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, u
 #define MPC_SD(ptr, row) ws_ref3(P, (ptr), 0u, (uint32_t)c.b, (uint32_t)(row) * 64u)
 #define MPC_U(ptr, row) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)bb, 0u)
 #define MPC_UB(ptr, row, b_) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)(b_), 0u)
+//   MPC_UK(arr, R, k, e)  same kernels, row k * R + e with a loop-variant stage k and a literal e: ONE scalar offset per
+//                         (array, stage), the literal goes into the instruction's immediate / a hoisted lane offset
+#define MPC_UK(ptr, R, k_, e) ws_ref3(P, (ptr), (uint32_t)(k_) * ((uint32_t)(R) * 64u), (uint32_t)bb, (uint32_t)(e) * 64u)
 #else
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k * (uint32_t)(R) + (uint32_t)(dk) * (uint32_t)(R) + (uint32_t)(e)), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
 #define MPC_SD(ptr, row) MPC_S(ptr, row)
 #define MPC_U(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)bb)])
 #define MPC_UB(ptr, row, b_) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)(b_))])
+#define MPC_UK(ptr, R, k_, e) ((ptr)[ws_index(P, (ptr), (uint32_t)(k_) * (uint32_t)(R) + (uint32_t)(e), (uint32_t)bb)])
 #endif
 
 template <int NX>
@@ -1293,14 +1299,13 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         K1[j] = -(i01 * G0[j] + i11 * G1[j]);
     }
     const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
-    const uint32_t kk = (uint32_t)k * D::NKK, pk = (uint32_t)k * D::NPK;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-        MPC_U(P.KK, kk + j) = K0[j];
-        MPC_U(P.KK, kk + NX + j) = K1[j];
+        MPC_UK(P.KK, D::NKK, k, j) = K0[j];
+        MPC_UK(P.KK, D::NKK, k, NX + j) = K1[j];
     }
-    MPC_U(P.KK, kk + 2 * NX) = kf0;
-    MPC_U(P.KK, kk + 2 * NX + 1) = kf1;
+    MPC_UK(P.KK, D::NKK, k, 2 * NX) = kf0;
+    MPC_UK(P.KK, D::NKK, k, 2 * NX + 1) = kf1;
     // p_k = gx + A'h + G'kff
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1309,7 +1314,7 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NX == 6) t += dt * h[5]; }
         if (i == 4) t += a04 * h[0] + a14 * h[1];
         pv[i] = t;
-        MPC_U(P.PK, pk + NS + i) = t;
+        MPC_UK(P.PK, D::NPK, k, NS + i) = t;
     }
     // P_k = H + P+ + W + W' + (dtF)'W + G'K, upper triangle, accumulated onto P+
 #pragma unroll
@@ -1327,7 +1332,7 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
             }
             if (i == j) t += delta;
             Ps[D::sidx(i, j)] = t;
-            MPC_U(P.PK, pk + D::sidx(i, j)) = t;
+            MPC_UK(P.PK, D::NPK, k, D::sidx(i, j)) = t;
         }
     }
     return true;
@@ -1359,14 +1364,13 @@ template <int NX>
 MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
     using D = Dim<NX>;
     const double dt = P.dt;
-    const uint32_t zr = (uint32_t)k * D::NZ;
     double du0 = f.kf0, du1 = f.kf1;
 #pragma unroll
     for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
-    MPC_U(P.DZ, zr + 0) = du0;
-    MPC_U(P.DZ, zr + 1) = du1;
+    MPC_UK(P.DZ, D::NZ, k, 0) = du0;
+    MPC_UK(P.DZ, D::NZ, k, 1) = du1;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) MPC_U(P.DZ, zr + 2 + i) = dx[i];
+    for (int i = 0; i < NX; ++i) MPC_UK(P.DZ, D::NZ, k, 2 + i) = dx[i];
     double dn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) dn[i] = dx[i] - f.cn[i];

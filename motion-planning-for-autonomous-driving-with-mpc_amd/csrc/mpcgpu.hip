@@ -82,13 +82,37 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
     }
 }
 
+// multiplier state that is not touched by the line search is parked in LDS while the search runs (registers of the
+// 256-thread variant are capped at 256 so that two workgroups share a CU): rows of STASH_ROWS x blockDim doubles
+#ifndef MPC_STAGE_OCC2
+#define MPC_STAGE_OCC2 0
+#endif
+template <int NX> struct Stash { static constexpr int ROWS = 2 * (NX + 2) + 3 * 3 + 2 * NX; };
+template <int NX, bool OUT>
+__device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t) {
+    int r = 0;
+#define MPC_ST(v) do { if (OUT) st[r * T + t] = (v); else (v) = st[r * T + t]; ++r; } while (0)
+#pragma unroll
+    for (int i = 0; i < NX + 2; ++i) { MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { MPC_ST(c.nuo[j]); MPC_ST(c.zlo[j]); MPC_ST(c.zuo[j]); }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
+#undef MPC_ST
+}
+
 template <int NX, bool INIT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z) {
+__global__ void __launch_bounds__(MAXT, (MPC_STAGE_OCC2 && MAXT <= 256 ? 2 : 1)) k_stage(const Params P, const int n_mult, const int n_z) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr bool STASH = MPC_STAGE_OCC2 && MAXT <= 256;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
-    c.b = (int)((blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + (t & (bx - 1));
+    // workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD gets a contiguous run of instance
+    // columns -- the 64/bx workgroups that share every 128-byte line of a tile then share one L2
+    uint32_t blk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    c.b = (int)((blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + (t & (bx - 1));
     c.valid = (c.k <= P.N) && (c.b < P.B);
     c.active = false;
     c.status = 0;
@@ -112,12 +136,15 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         block_reduce(r1, bx, lds);
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
+        double* stash = lds + (blockDim.x >> 6) * 10 * bx;     // shares the exchange region (each thread touches its own column only)
+        if (STASH) stash_xfer<NX, true>(c, stash, blockDim.x, t);
         while (__syncthreads_or((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
+        if (STASH) stash_xfer<NX, false>(c, stash, blockDim.x, t);
         MPC_STAMP(5);
         phase_apply_update<NX>(P, c);
         MPC_STAMP(6);
@@ -680,7 +707,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (Bp != h->cap_Bp) { h->cap_Bp = 0; }
     int rc = ensure_ws(h, Bp);
     if (rc) return rc;
-    const bool small_wg = 8 * (d.N + 1) <= 256;
+    const bool small_wg = 8 * (d.N + 1) <= 256 && getenv("MPCGPU_BIG_WG") == nullptr;
     const int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
@@ -696,7 +723,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const bool stage_timing = getenv("MPCGPU_STAGE_TIMING") != nullptr;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
-    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * NX * threads) * sizeof(double);   // reductions + stage exchange
+    // reductions + the larger of (stage exchange, multiplier stash of the 256-thread variant)
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)((MPC_STAGE_OCC2 && small_wg) ? Stash<NX>::ROWS : 2 * NX) * threads) * sizeof(double);
     const int rblk = (int)(Bp / 64);
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
