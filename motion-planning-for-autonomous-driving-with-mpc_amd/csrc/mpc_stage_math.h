@@ -241,13 +241,20 @@ MPC_HD double push_in(double v, double lo, double hi) {
 // IPOPT's Compare_le (IpUtils.cpp): lhs <= rhs up to 10 machine epsilons of a reference magnitude
 MPC_HD bool cmp_le(double lhs, double rhs, double base) { return lhs - rhs <= EPS10 * fabs(base); }
 
+// fraction-to-the-boundary bookkeeping: alpha_pr = min(1, min_i -tau gap_i/dg_i), alpha_du = min(1, min_i -tau z_i/dz_i).
+// The minimising side is selected by cross-multiplication and divided ONCE at the end (fp64 division costs ~13 issue
+// slots and there are ~22 bound sides per thread); for the selected side the value is the same expression as before.
+struct StepSel { double pg, pd, dn, dd; };
+MPC_HD void sel_init(StepSel& s, double tau) { s.pg = 1.0; s.pd = -tau; s.dn = 1.0; s.dd = -tau; }
+MPC_HD double sel_primal(const StepSel& s, double tau) { return -tau * s.pg / s.pd; }
+MPC_HD double sel_dual(const StepSel& s, double tau) { return -tau * s.dn / s.dd; }
 // multiplier step of one bound side and its fraction-to-the-boundary candidates.  gap > 0 is the distance to the
-// bound, dg its change along the step, z its multiplier; ig returns 1/gap (shared by the callers: one division per side)
-MPC_HD double side_step(double gap, double z, double dg, double mu, double tau, double& a_pr, double& a_du, double& ig) {
+// bound, dg its change along the step, z its multiplier; ig returns 1/gap (kept by the caller for the update phase)
+MPC_HD double side_step(double gap, double z, double dg, double mu, StepSel& s, double& ig) {
     ig = 1.0 / gap;
     const double dz = (mu - z * dg) * ig - z;               // mu/gap - z - (z/gap) dg
-    if (dg < 0) a_pr = fmin(a_pr, -tau * gap / dg);
-    if (dz < 0) a_du = fmin(a_du, -tau * z / dz);
+    if (dg < 0 && gap * s.pd > s.pg * dg) { s.pg = gap; s.pd = dg; }       // gap/(-dg) < pg/(-pd)
+    if (dz < 0 && z * s.dd > s.dn * dz) { s.dn = z; s.dd = dz; }          // z/(-dz) < dn/(-dd)
     return dz;
 }
 // new multiplier after the dual step, clamped to [mu/(kappa gap), kappa mu/gap] (IPOPT eq. (16)); ign = 1/gap_new
@@ -257,9 +264,9 @@ MPC_HD double side_update(double ig_old, double z, double dg, double mu, double 
     return fmin(fmax(z + a_du * dz, lo), hi);
 }
 // KKT bookkeeping of one bound side at the new iterate: sigma, barrier-gradient factor, complementarity, log product
-MPC_HD void side_kkt(double gap, double z, double sign, int mult, double& sg, double& gbb, double& rz, double& cmin, double& cmax,
-                     double& sz, double& gp) {
-    const double ig = 1.0 / gap;
+// (ig = 1/gap, handed over from the update phase when there was one)
+MPC_HD void side_kkt(double gap, double ig, double z, double sign, int mult, double& sg, double& gbb, double& rz, double& cmin,
+                     double& cmax, double& sz, double& gp) {
     sg += z * ig;
     gbb -= sign * ig;
     rz -= sign * z;
@@ -292,6 +299,7 @@ struct Ctx {
     double zl[NZ], zu[NZ];           // bound multipliers of (u_k, x_k), register resident across the phases (0 = no bound)
     double nuo[3], zlo[3], zuo[3];   // obstacle-row multipliers and their slack-bound multipliers
     double nuf, zlf, zuf;            // friction row (k == 0, only when the row is kept)
+    double igl[NZ], igu[NZ], iglo[3], iguo[3];   // 1/gap of every bound side: at the current iterate (phase 1 -> 3), then at the new one (3 -> 4)
     double dlam[NX];                 // step of the equality multipliers, -(P_k dx_k + p_k) - lambda_k
     double r0[NX];                   // r_0 (k == 0)
     double dfric0, gfr0[3];          // friction row value / gradient at the current iterate (k == 0, row kept)
@@ -708,39 +716,43 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     if (!c.active) return;
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double mu = c.mu, tau = c.tau;
-    double a_pr = 1.0, a_du = 1.0, dphi = 0.0;
+    double dphi = 0.0;
+    StepSel sel;
+    sel_init(sel, tau);
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
+        c.igl[i] = c.igu[i] = 0.0;
         if (isu && k == N) continue;
         const double zi = c.z[i], dv = c.dz[i];
         MPC_BOUNDS(k, i, lb, ub);
         double gradf = 0.0;
         if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
-        double gb = 0.0, ig;
-        if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
-        if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
+        double gb = 0.0;
+        if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
+        if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
         dphi += (gradf + gb) * dv;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j];
-        double gb = 0.0, ig;
-        if (P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
-        if (P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
+        double gb = 0.0;
+        c.iglo[j] = c.iguo[j] = 0.0;
+        if (P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
+        if (P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
         dphi += m * gb * ds;
     }
     if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf;
         double gb = 0.0, ig;
-        if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, tau, a_pr, a_du, ig); gb -= mu * ig; }
-        if (P.has_fu) { side_step(P.fu - s, c.zuf, -ds, mu, tau, a_pr, a_du, ig); gb += mu * ig; }
+        if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, sel, ig); gb -= mu * ig; }
+        if (P.has_fu) { side_step(P.fu - s, c.zuf, -ds, mu, sel, ig); gb += mu * ig; }
         dphi += gb * ds;
     } else {
         c.sf = c.dsf = c.nuf = c.zlf = c.zuf = 0.0;
     }
-    red.a_pr = a_pr;
-    red.a_du = a_du;
+    red.a_pr = sel_primal(sel, tau);
+    red.a_du = sel_dual(sel, tau);
     red.dphi = dphi;
 }
 
@@ -891,8 +903,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
         MPC_K(P.Z, NZ, 0, i) = zn;
-        if (has_lo(lb)) { c.zl[i] = side_update(1.0 / (zi - lb), c.zl[i], dv, mu, ad, 1.0 / (zn - lb)); MPC_K(P.ZL, NZ, 0, i) = c.zl[i]; }
-        if (has_hi(ub)) { c.zu[i] = side_update(1.0 / (ub - zi), c.zu[i], -dv, mu, ad, 1.0 / (ub - zn)); MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
+        if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; MPC_K(P.ZL, NZ, 0, i) = c.zl[i]; }
+        if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
         c.z[i] = zn;
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
@@ -906,15 +918,17 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
         double sg = 0.0, gb = 0.0;
         if (P.has_ol) {
-            const double ig = 1.0 / (s - P.ol);
+            const double ig = c.iglo[j], ign = 1.0 / (sn - P.ol);
             sg += c.zlo[j] * ig; gb -= mu * ig;
-            c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, 1.0 / (sn - P.ol));
+            c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
+            c.iglo[j] = ign;
             MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
         }
         if (P.has_ou) {
-            const double ig = 1.0 / (P.ou - s);
+            const double ig = c.iguo[j], ign = 1.0 / (P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
-            c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, 1.0 / (P.ou - sn));
+            c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
+            c.iguo[j] = ign;
             MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
         }
         c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
@@ -974,7 +988,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 // Phase 4: derivatives at the (new) iterate, KKT residuals, condensed Hessian blocks
 //          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
 // =========================================================================================================
-template <int NX>
+// REUSE: the update phase ran before and left 1/gap of every bound side at the new iterate in c.ig* (no division here)
+template <int NX, bool REUSE = false>
 MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
@@ -996,7 +1011,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         if (k >= N) c.xn[i] = 0.0;
     }
     ode_eval<NX>(P, x, u, f, sps, cps, td);
-    const double cd = cos(x[2]), secd2 = 1.0 / (cd * cd), v = x[3], il = 1.0 / P.wheelbase;
+    const double secd2 = 1.0 + td * td, v = x[3], il = 1.0 / P.wheelbase;      // sec^2 = 1 + tan^2 (td from ode_eval)
     // A = I + dt * df/dx : six off-identity entries
     const double a03 = dt * cps, a04 = -dt * v * sps, a13 = dt * sps, a14 = dt * v * cps;
     const double a42 = dt * v * secd2 * il, a43 = dt * td * il;
@@ -1066,8 +1081,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i];
         double sg = 0.0, gbb = 0.0, rz = 0.0;
-        if (has_lo(lb)) side_kkt(zi - lb, c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-        if (has_hi(ub)) side_kkt(ub - zi, c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+        if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+        if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
         if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
         else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
     }
@@ -1079,8 +1094,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], nu = c.nuo[j];
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_ol) side_kkt(s - P.ol, c.zlo[j], 1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
-        if (P.has_ou) side_kkt(P.ou - s, c.zuo[j], -1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_ol) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_ou) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
         dual = fmax(dual, fabs(rs));
         const double res = dist[j] - s;
         theta += m * fabs(res);
@@ -1105,8 +1120,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
         const double s = c.sf, nu = c.nuf;
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_fl) side_kkt(s - P.fl, c.zlf, 1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
-        if (P.has_fu) side_kkt(P.fu - s, c.zuf, -1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_fl) side_kkt(s - P.fl, 1.0 / (s - P.fl), c.zlf, 1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_fu) side_kkt(P.fu - s, 1.0 / (P.fu - s), c.zuf, -1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
         dual = fmax(dual, fabs(rs));
         const double res = dfr - s;
         theta += fabs(res);

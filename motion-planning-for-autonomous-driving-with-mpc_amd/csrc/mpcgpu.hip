@@ -84,27 +84,26 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
 
 // multiplier state that is not touched by the line search is parked in LDS while the search runs (registers of the
 // 256-thread variant are capped at 256 so that two workgroups share a CU): rows of STASH_ROWS x blockDim doubles
-#ifndef MPC_STAGE_OCC2
-#define MPC_STAGE_OCC2 0
-#endif
-template <int NX> struct Stash { static constexpr int ROWS = 2 * (NX + 2) + 3 * 3 + 2 * NX; };
+// state that the line search does not touch is parked in LDS while the search runs (LDS is idle at one workgroup per
+// CU; the registers it frees are the difference between a spill-free search loop and scratch traffic)
+template <int NX> struct Stash { static constexpr int ROWS = 4 * (NX + 2) + 5 * 3 + 2 * NX; };
 template <int NX, bool OUT>
 __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t) {
     int r = 0;
 #define MPC_ST(v) do { if (OUT) st[r * T + t] = (v); else (v) = st[r * T + t]; ++r; } while (0)
 #pragma unroll
-    for (int i = 0; i < NX + 2; ++i) { MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); }
+    for (int i = 0; i < NX + 2; ++i) { MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); MPC_ST(c.igl[i]); MPC_ST(c.igu[i]); }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { MPC_ST(c.nuo[j]); MPC_ST(c.zlo[j]); MPC_ST(c.zuo[j]); }
+    for (int j = 0; j < 3; ++j) { MPC_ST(c.nuo[j]); MPC_ST(c.zlo[j]); MPC_ST(c.zuo[j]); MPC_ST(c.iglo[j]); MPC_ST(c.iguo[j]); }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
 #undef MPC_ST
 }
 
 template <int NX, bool INIT, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MPC_STAGE_OCC2 && MAXT <= 256 ? 2 : 1)) k_stage(const Params P, const int n_mult, const int n_z) {
+__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr bool STASH = MPC_STAGE_OCC2 && MAXT <= 256;
+    constexpr bool STASH = MAXT <= 256;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
@@ -164,7 +163,7 @@ __global__ void __launch_bounds__(MAXT, (MPC_STAGE_OCC2 && MAXT <= 256 ? 2 : 1))
     }
     MPC_STAMP(7);
     Red3 r3;
-    phase_eval_assemble<NX>(P, c, r3);
+    phase_eval_assemble<NX, !INIT>(P, c, r3);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
@@ -724,7 +723,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
     // reductions + the larger of (stage exchange, multiplier stash of the 256-thread variant)
-    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)((MPC_STAGE_OCC2 && small_wg) ? Stash<NX>::ROWS : 2 * NX) * threads) * sizeof(double);
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)(small_wg ? Stash<NX>::ROWS : 2 * NX) * threads) * sizeof(double);
     const int rblk = (int)(Bp / 64);
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag

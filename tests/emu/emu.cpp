@@ -62,11 +62,11 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
             c.active = false;
         }
     };
-    auto eval_finish = [&]() {
+    auto eval_finish = [&](bool reuse) {
         // neighbour-stage exchange (LDS on the GPU): x_{k+1} and lambda_{k+1} at the new iterate
         for (int t = 0; t + bx < nthreads; ++t)
             for (int i = 0; i < NX; ++i) { ctx[t].xn[i] = ctx[t + bx].z[2 + i]; ctx[t].lamn[i] = ctx[t + bx].lam[i]; }
-        for (int t = 0; t < nthreads; ++t) phase_eval_assemble<NX>(P, ctx[t], r3[t]);
+        for (int t = 0; t < nthreads; ++t) { if (reuse) phase_eval_assemble<NX, true>(P, ctx[t], r3[t]); else phase_eval_assemble<NX, false>(P, ctx[t], r3[t]); }
         reduce_block(r3, bx, S);
         for (int t = 0; t < nthreads; ++t) phase_finish<NX>(P, ctx[t], r3[t], hp.n_mult, hp.n_z);
     };
@@ -79,7 +79,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         for (int t = 0; t < nthreads; ++t) phase_init_point<NX>(P, ctx[t], r0[t]);
         reduce_block(r0, bx, S);
         for (int t = 0; t < nthreads; ++t) phase_init_scalars<NX>(P, ctx[t], r0[t]);
-        eval_finish();
+        eval_finish(false);
     }
     auto record = [&](int it) {
         if (!trace || it >= trace_rows) return;
@@ -114,7 +114,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
                 for (int t = 0; t < nthreads; ++t) phase_linesearch_decide<NX>(P, ctx[t], r2[t]);
             }
             for (int t = 0; t < nthreads; ++t) phase_apply_update<NX>(P, ctx[t]);
-            eval_finish();
+            eval_finish(true);
         }
         record(it);
     }
