@@ -158,6 +158,12 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.R[0] = d.R[0]; P.R[1] = d.R[1];
     for (int i = 0; i < 6; ++i) P.obst[i] = d.obstacle[i];
     P.fl = hp.fl; P.fu = hp.fu; P.ol = hp.ol; P.ou = hp.ou;
+    P.lo_mask = P.hi_mask = 0;
+    for (size_t q = 0; q < hp.LB.size(); ++q) {
+        const int i = (int)(q % (size_t)hp.NZ());
+        if (hp.LB[q] > -1e300) P.lo_mask |= 1u << i;
+        if (hp.UB[q] < 1e300) P.hi_mask |= 1u << i;
+    }
     P.x0 = nullptr; P.p = nullptr; P.LB = dLB; P.UB = dUB;
     // every array pointer addresses its first row inside tile 0
     P.Z = base + w.Z * 64; P.ZL = base + w.ZL * 64; P.ZU = base + w.ZU * 64;

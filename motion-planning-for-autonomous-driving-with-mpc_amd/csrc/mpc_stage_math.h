@@ -81,6 +81,7 @@ struct Params {
     double dt, wheelbase, friction_div, ego_offset, tol;
     double Q[6], R[2], obst[6];
     double fl, fu, ol, ou;       // relaxed slack bounds of the friction / obstacle rows
+    uint32_t lo_mask, hi_mask;   // bit i: variable i of (u, x) has a finite lower / upper bound at SOME stage (multiplier rows of the others never move)
     const double* x0;            // [B][n_w] row-major (ABI input)
     const double* p;             // [B][n_w] row-major (ABI input)
     const double* LB;            // [(N+1)*NZ] relaxed variable bounds, -inf = absent
@@ -93,7 +94,7 @@ struct Params {
     double *PK;                  // [(N+1)*(NS+NX)][Bp]  cost-to-go P_k (upper triangle) and p_k
     double *KK;                  // [N*(2*NX+2)][Bp]     feedback gains K_k, k_k
     double *BLK;                 // [(N+1)*NBLK][Bp]     condensed stage blocks consumed by the Riccati sweep
-    double *EV;                  // [(N+1)*12][Bp]       circle distances (3) and their Jacobians (9) at the iterate
+    double *EV;                  // (unused: circle distances / Jacobians are recomputed from the iterate instead of passing through HBM)
     double *ROLL;                // [(N+1)*NX][Bp]       dynamics rollout of the warm-start controls (start-point safeguard)
     double *SC;                  // [SC_COUNT][Bp]
     double *FILT;                // [2*FILTER_MAX][Bp]
@@ -363,6 +364,7 @@ MPC_HD void obstacle_eval(const Params& P, const double* obst, double sx, double
         J[3 * j + 0] = ex;
         J[3 * j + 1] = ey;
         J[3 * j + 2] = ex * tx + ey * ty;
+        if (H == nullptr) continue;
         const double m00 = (1 - ex * ex) * ir, m01 = -ex * ey * ir, m11 = (1 - ey * ey) * ir;
         const double mt0 = m00 * tx + m01 * ty, mt1 = m01 * tx + m11 * ty;
         const double nxx = -sg * rho * cps, nyy = -sg * rho * sps;
@@ -649,13 +651,15 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
     if (!c.valid) return;
     const int N = P.N, k = c.k;
     load_obst(P, c);
-    double pk[D::NPK], lam[NX], ev[D::NEV];
+    double pk[D::NPK], lam[NX];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         c.z[i] = MPC_K(P.Z, NZ, 0, i);
         c.dz[i] = MPC_K(P.DZ, NZ, 0, i);
-        c.zl[i] = MPC_K(P.ZL, NZ, 0, i);
-        c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
+        // multipliers of bounds that exist nowhere are never read (a_0 has per-instance bounds: stage 0 always loads)
+        const bool a0 = (i == 1) && (k == 0);
+        c.zl[i] = (((P.lo_mask >> i) & 1u) || a0) ? (double)MPC_K(P.ZL, NZ, 0, i) : 0.0;
+        c.zu[i] = (((P.hi_mask >> i) & 1u) || a0) ? (double)MPC_K(P.ZU, NZ, 0, i) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -667,8 +671,6 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
     }
 #pragma unroll
     for (int i = 0; i < D::NPK; ++i) pk[i] = MPC_K(P.PK, D::NPK, 0, i);
-#pragma unroll
-    for (int i = 0; i < D::NEV; ++i) ev[i] = MPC_K(P.EV, D::NEV, 0, i);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         c.so[j] = MPC_K(P.SO, 3, 0, j);
@@ -689,13 +691,24 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
         c.gfr0[2] = MPC_S(P.SC, SC_GFR2);
     }
     // ---- arithmetic on loaded arrays only
+    // slack steps need the circle distances and their Jacobians at the iterate: recomputed here (the same evaluation
+    // phase 4 of the previous launch made, bit for bit) rather than stored and re-read -- the kernel is bandwidth bound
     const int oi[3] = {0, 1, 4};
+    {
+        double sps, cps, dist[3], J[9];
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos(c.z[2 + 4], &sps, &cps);
+#else
+        sps = sin(c.z[2 + 4]); cps = cos(c.z[2 + 4]);
+#endif
+        obstacle_eval(P, c.obst, c.z[2], c.z[3], sps, cps, dist, J, nullptr, true);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        double ds = ev[j] - c.so[j];
+        for (int j = 0; j < 3; ++j) {
+            double ds = dist[j] - c.so[j];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) ds += ev[3 + 3 * j + a] * c.dz[2 + oi[a]];
-        c.dso[j] = ds;
+            for (int a = 0; a < 3; ++a) ds += J[3 * j + a] * c.dz[2 + oi[a]];
+            c.dso[j] = ds;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1101,12 +1114,10 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         theta += m * fabs(res);
         prim = fmax(prim, fabs(res));
         smult += m * fabs(nu);
-        MPC_K(P.EV, D::NEV, 0, j) = dist[j];
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double ja = J[3 * j + a];
-            MPC_K(P.EV, D::NEV, 0, 3 + 3 * j + a) = ja;
             rx[oi[a]] += m * nu * ja;
             c.gxa[oi[a]] += ja * (m * sg * res);
             c.gxb[oi[a]] += ja * (m * gbb);
