@@ -81,6 +81,7 @@ struct Params {
     double dt, wheelbase, friction_div, ego_offset, tol;
     double Q[6], R[2], obst[6];
     double fl, fu, ol, ou;       // relaxed slack bounds of the friction / obstacle rows
+    uint32_t inv_S;              // ceil(2^32 / (N+1)): segment -> (row, stage) split of the LDS prefetch
     uint32_t lo_mask, hi_mask;   // bit i: variable i of (u, x) has a finite lower / upper bound at SOME stage (multiplier rows of the others never move)
     const double* x0;            // [B][n_w] row-major (ABI input)
     const double* p;             // [B][n_w] row-major (ABI input)
@@ -287,6 +288,14 @@ MPC_HD double zreset(double z, double gap, double mu) {
 }
 
 // per-thread context kept in registers across the phases of the stage kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) const double* mpc_lds_cptr;
+#else
+typedef const double* mpc_lds_cptr;
+#endif
+template <int NX>
+struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath (non-PF)
+
 template <int NX>
 struct Ctx {
     static constexpr int NZ = NX + 2;
@@ -318,6 +327,10 @@ struct Ctx {
     bool fric_row;   // stage-0 friction row kept as a row (false: presolved into the bounds a0lb/a0ub of a_0)
     double a0lb, a0ub;
     bool conv;       // fixed-iteration (benchmark) mode: tolerance already reached, steps are accepted as they come
+    // --- LDS image of the rows that only the update phase needs (PF kernels: fetched by global->LDS DMA while phase 1
+    //     and the line search run).  Element e of array A at stage k, column bl:  pf[A_base + e * pf_row + pf_col]
+    mpc_lds_cptr pf;
+    int pf_row, pf_col, pf_lam, pf_nuo;      // doubles: (N+1)*bx, k*bx + bl, first element of the LAM / NUO images
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
@@ -644,14 +657,13 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 
 // all array loads of the stage kernel in ONE batch (no dependence on the per-instance scalars), plus the arithmetic
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
-template <int NX>
-MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
+template <int NX, bool PF = false>
+MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
     load_obst(P, c);
-    double pk[D::NPK], lam[NX];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         c.z[i] = MPC_K(P.Z, NZ, 0, i);
@@ -666,15 +678,17 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
         c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
         c.xn[i] = (k < N) ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : 0.0;
         c.dxn[i] = (k < N) ? (double)MPC_K(P.DZ, NZ, 1, 2 + i) : 0.0;
-        lam[i] = MPC_K(P.LAM, NX, 0, i);
+        if (!PF) tmp.lam[i] = MPC_K(P.LAM, NX, 0, i);
         c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
     }
+    if (!PF) {
 #pragma unroll
-    for (int i = 0; i < D::NPK; ++i) pk[i] = MPC_K(P.PK, D::NPK, 0, i);
+        for (int i = 0; i < D::NPK; ++i) tmp.pk[i] = MPC_K(P.PK, D::NPK, 0, i);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         c.so[j] = MPC_K(P.SO, 3, 0, j);
-        c.nuo[j] = MPC_K(P.NUO, 3, 0, j);
+        c.nuo[j] = PF ? 0.0 : (double)MPC_K(P.NUO, 3, 0, j);
         c.zlo[j] = P.has_ol ? (double)MPC_K(P.ZLO, 3, 0, j) : 0.0;
         c.zuo[j] = P.has_ou ? (double)MPC_K(P.ZUO, 3, 0, j) : 0.0;
     }
@@ -690,7 +704,13 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
         c.gfr0[1] = MPC_S(P.SC, SC_GFR1);
         c.gfr0[2] = MPC_S(P.SC, SC_GFR2);
     }
-    // ---- arithmetic on loaded arrays only
+}
+
+// arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam
+template <int NX, bool PF = false>
+MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
+    using D = Dim<NX>;
+    if (!c.valid) return;
     // slack steps need the circle distances and their Jacobians at the iterate: recomputed here (the same evaluation
     // phase 4 of the previous launch made, bit for bit) rather than stored and re-read -- the kernel is bandwidth bound
     const int oi[3] = {0, 1, 4};
@@ -710,13 +730,15 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c) {
             c.dso[j] = ds;
         }
     }
+    if (!PF) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double s = pk[D::NS + i];
+        for (int i = 0; i < NX; ++i) {
+            double s = tmp.pk[D::NS + i];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
-        c.lam[i] = lam[i];
-        c.dlam[i] = -s - lam[i];
+            for (int j = 0; j < NX; ++j) s += tmp.pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
+            c.lam[i] = tmp.lam[i];
+            c.dlam[i] = -s - tmp.lam[i];
+        }
     }
     c.dsf = c.dfric0 - c.sf + c.gfr0[0] * c.dz[1] + c.gfr0[1] * c.dz[2 + 2] + c.gfr0[2] * c.dz[2 + 3];
 }
@@ -898,12 +920,25 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX>
+template <int NX, bool PF = false>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.active) return;
     const int N = P.N, k = c.k;
+    if (PF) {                               // rows parked in LDS by the prefetch: cost-to-go (P_k, p_k), lambda_k, nu_k
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double s = c.pf[(D::NS + i) * c.pf_row + c.pf_col];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) s += c.pf[((i <= j) ? D::sidx(i, j) : D::sidx(j, i)) * c.pf_row + c.pf_col] * c.dz[2 + j];
+            const double l = c.pf[c.pf_lam + i * c.pf_row + c.pf_col];
+            c.lam[i] = l;
+            c.dlam[i] = -s - l;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.nuo[j] = c.pf[c.pf_nuo + j * c.pf_row + c.pf_col];
+    }
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
         if (k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }

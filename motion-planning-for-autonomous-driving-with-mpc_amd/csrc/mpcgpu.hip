@@ -86,24 +86,75 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
 // 256-thread variant are capped at 256 so that two workgroups share a CU): rows of STASH_ROWS x blockDim doubles
 // state that the line search does not touch is parked in LDS while the search runs (LDS is idle at one workgroup per
 // CU; the registers it frees are the difference between a spill-free search loop and scratch traffic)
-template <int NX> struct Stash { static constexpr int ROWS = 4 * (NX + 2) + 5 * 3 + 2 * NX; };
-template <int NX, bool OUT>
-__device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t) {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef MPC_STAGE_STASH
+#define MPC_STAGE_STASH 1
+#endif
+template <int NX, bool PF> struct Stash {
+    __host__ __device__ static constexpr int rows(bool has_ou) { return 4 * (NX + 2) + 2 * 3 + (has_ou ? 2 * 3 : 0) + (PF ? 0 : 3 + 2 * NX); }
+};
+template <int NX, bool PF, bool OUT>
+__device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t, bool has_ou) {
     int r = 0;
 #define MPC_ST(v) do { if (OUT) st[r * T + t] = (v); else (v) = st[r * T + t]; ++r; } while (0)
 #pragma unroll
     for (int i = 0; i < NX + 2; ++i) { MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); MPC_ST(c.igl[i]); MPC_ST(c.igu[i]); }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { MPC_ST(c.nuo[j]); MPC_ST(c.zlo[j]); MPC_ST(c.zuo[j]); MPC_ST(c.iglo[j]); MPC_ST(c.iguo[j]); }
+    for (int j = 0; j < 3; ++j) { MPC_ST(c.zlo[j]); MPC_ST(c.iglo[j]); }
+    if (has_ou) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
+        for (int j = 0; j < 3; ++j) { MPC_ST(c.zuo[j]); MPC_ST(c.iguo[j]); }
+    }
+    if (!PF) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) MPC_ST(c.nuo[j]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
+    }
 #undef MPC_ST
 }
 
-template <int NX, bool INIT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z) {
+// LDS prefetch of the rows that only the update phase reads (cost-to-go P_k/p_k, lambda_k, nu_k): global->LDS DMA,
+// 16 bytes per lane.  A (row, stage) segment of the workgroup's bx instance columns is bx*8 contiguous bytes in HBM;
+// one wave instruction moves 128/bx segments and lands them back to back, so the LDS image of an array is
+// [row][stage][column] -- the element of thread (k, bl) in row e sits at (e*(N+1) + k)*bx + bl.
+template <int NX>
+struct PfLayout {
+    uint32_t nins[3], base[3], total;        // DMA instructions per array, first instruction (= KiB) of each image
+    __host__ __device__ PfLayout(int N, int bx) {
+        const uint32_t spi = 128u / (uint32_t)bx, S = (uint32_t)N + 1u;
+        const uint32_t rows[3] = {(uint32_t)Dim<NX>::NPK, (uint32_t)NX, 3u};
+        total = 0;
+        for (int a = 0; a < 3; ++a) { nins[a] = (rows[a] * S + spi - 1) / spi; base[a] = total; total += nins[a]; }
+    }
+};
+template <int NX>
+__device__ __forceinline__ void stage_prefetch(const Params& P, uint32_t b0, char* lds_pf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const PfLayout<NX> L(P.N, P.bx);
+    const uint32_t S = (uint32_t)P.N + 1u, lps = (uint32_t)P.bx >> 1, spi = 128u / (uint32_t)P.bx;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6, lane = threadIdx.x & 63u;
+    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    const uint32_t col_off = ((b0 >> 6) * P.tile_elems + (b0 & 63u)) * 8u + (lane % lps) * 16u;
+    const double* arrs[3] = {P.PK, P.LAM, P.NUO};
+    const uint32_t rows[3] = {(uint32_t)Dim<NX>::NPK, (uint32_t)NX, 3u};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t aoff = (uint32_t)(uintptr_t)arrs[a] - (uint32_t)(uintptr_t)P.WS + col_off, R = rows[a], nseg = R * S;
+        for (uint32_t i = wave; i < L.nins[a]; i += nw) {
+            const uint32_t sg = i * spi + lane / lps;
+            const uint32_t e = __umulhi(sg, P.inv_S), k = sg - e * S;
+            const uint32_t goff = sg < nseg ? aoff + (k * R + e) * 512u : 0xFFFFFFF0u;      // out of range: dropped by the bounds check
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_pf + (L.base[a] + i) * 1024u), 16, (int)goff, 0, 0, 0);
+        }
+    }
+#endif
+}
+
+template <int NX, bool INIT, int MAXT, bool PF>
+__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr bool STASH = MAXT <= 256;
+    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
@@ -125,9 +176,23 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         phase_init_scalars<NX>(P, c, r0);
     } else {
         phase_load_scalars<NX>(P, c);
-        phase_preload<NX>(P, c);                       // every array load of the kernel is in flight before the first wait
+        PreTmp<NX> tmp;
+        phase_preload<NX, PF>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
+        char* pfb = reinterpret_cast<char*>(lds + (blockDim.x >> 6) * 10 * bx + stash_rows * (int)blockDim.x);
+        if (PF) {
+            const PfLayout<NX> L(P.N, bx);
+            c.pf = (mpc_lds_cptr)(lds_ptr_t)pfb;
+            c.pf_row = (P.N + 1) * bx;
+            c.pf_col = c.k * bx + (t & (bx - 1));
+            c.pf_lam = (int)L.base[1] * 128;
+            c.pf_nuo = (int)L.base[2] * 128;
+        }
+        phase_premath<NX, PF>(P, c, tmp);
         MPC_STAMP(1);
         if (!__syncthreads_or(c.active ? 1 : 0)) return;
+        // the rows of the update phase stream into LDS while phase 1 and the line search compute (issued only now: the
+        // memory system serves requests in no particular order, an earlier issue just competes with the loads above)
+        if (PF) stage_prefetch<NX>(P, (blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx, pfb);
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX>(P, c, r1);
@@ -136,16 +201,17 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
         double* stash = lds + (blockDim.x >> 6) * 10 * bx;     // shares the exchange region (each thread touches its own column only)
-        if (STASH) stash_xfer<NX, true>(c, stash, blockDim.x, t);
+        if (STASH) stash_xfer<NX, PF, true>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the prefetch has landed; the barrier below publishes it
         while (__syncthreads_or((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
-        if (STASH) stash_xfer<NX, false>(c, stash, blockDim.x, t);
+        if (STASH) stash_xfer<NX, PF, false>(c, stash, blockDim.x, t, P.has_ou != 0);
         MPC_STAMP(5);
-        phase_apply_update<NX>(P, c);
+        phase_apply_update<NX, PF>(P, c);
         MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
@@ -184,7 +250,6 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 // mpc_stage_math.h (shared with the CPU emulation harness).  Inertia correction: if some lane finds an indefinite
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 22 KiB each)
 constexpr int RIC_DEPTH_F = 6;      // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead
 
@@ -723,8 +788,17 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const bool stage_timing = getenv("MPCGPU_STAGE_TIMING") != nullptr;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
-    // reductions + the larger of (stage exchange, multiplier stash of the 256-thread variant)
-    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)(small_wg ? Stash<NX>::ROWS : 2 * NX) * threads) * sizeof(double);
+    // LDS: reductions | the larger of (stage exchange, multiplier stash of the 256-thread variant) | prefetch images
+    const bool has_ou = h->hp.has_ou != 0;
+    const size_t lds_max = 160 * 1024 - 1024;          // the kernels also hold a few hundred bytes of static LDS
+    const PfLayout<NX> pfl(d.N, bx);
+    // opt-in (MPCGPU_PREFETCH=1): measured neutral on MI355X at B = 4096 (59.5 us without, 60.2 us with) -- the kernel is
+    // bound by the per-workgroup latency chain, not by the load burst the prefetch spreads out
+    bool use_pf = small_wg && getenv("MPCGPU_PREFETCH") != nullptr;
+    int stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, true>::rows(has_ou), 2 * NX) : 2 * NX;
+    if (use_pf && ((size_t)nw * 10 * bx + (size_t)stash_rows * threads) * sizeof(double) + (size_t)pfl.total * 1024 > lds_max) use_pf = false;
+    if (!use_pf) stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, false>::rows(has_ou), 2 * NX) : 2 * NX;
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)stash_rows * threads) * sizeof(double) + (use_pf ? (size_t)pfl.total * 1024 : 0);
     const int rblk = (int)(Bp / 64);
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
@@ -732,6 +806,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         static bool attr_set[2] = {false, false};
         if (!attr_set[NX - 5]) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             attr_set[NX - 5] = true;
         }
     }
@@ -769,11 +848,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Pg.tile0 = q.tile0;
         if (!init && stage_timing && P.DBG) Pg.DBG = P.DBG;
         if (small_wg) {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
-            else hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (use_pf) hipLaunchKernelGGL((k_stage<NX, false, 256, true>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else hipLaunchKernelGGL((k_stage<NX, false, 256, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
-            else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else hipLaunchKernelGGL((k_stage<NX, false, 512, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
     for (int g = 0; g < G; ++g) {

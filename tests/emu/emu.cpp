@@ -100,7 +100,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         for (int blk = 0; blk < nblocks; ++blk) {
             setup(blk);
             bool any = false;
-            for (int t = 0; t < nthreads; ++t) { phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX>(P, ctx[t]); any |= ctx[t].active; }
+            for (int t = 0; t < nthreads; ++t) { PreTmp<NX> tmp; phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX>(P, ctx[t], tmp); phase_premath<NX>(P, ctx[t], tmp); any |= ctx[t].active; }
             if (!any) continue;
             for (int t = 0; t < nthreads; ++t) phase_step_candidates<NX>(P, ctx[t], r1[t]);
             reduce_block(r1, bx, S);

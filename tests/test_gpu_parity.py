@@ -59,6 +59,19 @@ def test_ragged_batch_sizes(B):
     assert np.array_equal(part.x, full.x[:B]) and np.array_equal(part.iters, full.iters[:B])
 
 
+@pytest.mark.parametrize("env", ["MPCGPU_PREFETCH", "MPCGPU_BIG_WG", "MPCGPU_GROUPS"])
+def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
+    """The opt-in variants (LDS prefetch of the update-phase rows, 512-thread stage workgroups, sub-batch streams) run
+    the same arithmetic: results must equal the default path bit for bit."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 600, **kw)
+    s = make_solver(cfg)
+    ref = s.solve(x0, p)
+    monkeypatch.setenv(env, "2" if env == "MPCGPU_GROUPS" else "1")
+    alt = s.solve(x0, p)
+    assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
+
+
 def test_full_size_batch_properties():
     """BASELINE metric size: N = 30, nx = 6, B = 4096.  Size-independent properties: every instance converged;
     permuting instances permutes results bit-exactly; splitting the batch changes nothing; the returned points
