@@ -37,6 +37,25 @@ namespace {
 // bx * (N + 1) <= 256 with bx >= 8 instances, else 512 threads
 constexpr int STAGE_MAX_THREADS = 512;
 
+// Workgroup barrier WITHOUT the release fence of __syncthreads(): that fence is `s_waitcnt vmcnt(0)`, i.e. every barrier
+// would wait until all of the wave's outstanding global stores are acknowledged by memory (microseconds under load).
+// The barriers of these kernels only order LDS traffic, so draining the LDS/scalar counter is all that is needed;
+// results written to HBM are consumed by later kernels.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// workgroup-wide OR of a predicate with one such barrier (slots double-buffered by call parity)
+__device__ __forceinline__ int block_or(int pred, int (*slots)[8], int& parity) {
+    const int any = __any(pred) ? 1 : 0;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) slots[parity][wave] = any;
+    lds_barrier();
+    int r = 0;
+    for (int w = 0; w < nw; ++w) r |= slots[parity][w];
+    parity ^= 1;
+    return r;
+}
+
 template <typename R>
 __device__ __forceinline__ R shfl_xor_struct(const R& r, int mask) {
     constexpr int NQ = sizeof(R) / sizeof(double);
@@ -65,7 +84,7 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) lds[(wave * NQ + q) * bx + lane] = mine[q];
         }
-        __syncthreads();
+        lds_barrier();
         R acc;
         double* a = reinterpret_cast<double*>(&acc);
 #pragma unroll
@@ -78,7 +97,7 @@ __device__ __forceinline__ void block_reduce(R& r, int bx, double* lds) {
             red_combine(acc, o);
         }
         r = acc;
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -154,6 +173,8 @@ __device__ __forceinline__ void stage_prefetch(const Params& P, uint32_t b0, cha
 template <int NX, bool INIT, int MAXT, bool PF>
 __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int or_slots[2][8];
+    int or_parity = 0;
     constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
@@ -189,7 +210,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         }
         phase_premath<NX, PF>(P, c, tmp);
         MPC_STAMP(1);
-        if (!__syncthreads_or(c.active ? 1 : 0)) return;
+        if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
         // the rows of the update phase stream into LDS while phase 1 and the line search compute (issued only now: the
         // memory system serves requests in no particular order, an earlier issue just competes with the loads above)
         if (PF) stage_prefetch<NX>(P, (blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx, pfb);
@@ -203,7 +224,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         double* stash = lds + (blockDim.x >> 6) * 10 * bx;     // shares the exchange region (each thread touches its own column only)
         if (STASH) stash_xfer<NX, PF, true>(c, stash, blockDim.x, t, P.has_ou != 0);
         if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the prefetch has landed; the barrier below publishes it
-        while (__syncthreads_or((c.active && c.searching) ? 1 : 0)) {
+        while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
@@ -220,7 +241,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         const int T = blockDim.x;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { ex[i * T + t] = c.z[2 + i]; ex[(NX + i) * T + t] = c.lam[i]; }
-        __syncthreads();
+        lds_barrier();
         const int tn = t + bx;
         if (tn < T) {
 #pragma unroll
@@ -251,7 +272,8 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 22 KiB each)
-constexpr int RIC_DEPTH_F = 6;      // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead
+constexpr int RIC_DEPTH_F = 10;     // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead --
+                                    // fed by TWO loader waves (even / odd stages), each limited to 4 stages in flight by the 6-bit vmcnt
 
 template <int NCH>
 __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
@@ -264,7 +286,7 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 }
 
 template <int NX>
-__global__ void __launch_bounds__(128) k_riccati(const Params P) {
+__global__ void __launch_bounds__(192) k_riccati(const Params P) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
@@ -274,7 +296,7 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
     constexpr int KK_CHUNKS = (D::NKK * 512u + 1023u) / 1024u;
     constexpr int FWD_CHUNKS = KK_CHUNKS + 6;                      // gains + A rows + defect rows
     constexpr uint32_t FSLOT = FWD_CHUNKS * 1024u;
-    static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4 && 4 * FWD_CHUNKS <= 63 && RIC_DEPTH_F == 6, "vmcnt is a 6-bit counter");
+    static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4 && 4 * FWD_CHUNKS <= 63 && RIC_DEPTH_F == 10, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t RING_BYTES = (RIC_DEPTH * SLOT > RIC_DEPTH_F * FSLOT) ? RIC_DEPTH * SLOT : RIC_DEPTH_F * FSLOT;
     int* flag = reinterpret_cast<int*>(smem + RING_BYTES);
@@ -319,13 +341,15 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
         if (active) { delta_last = MPC_U(P.SC, (uint32_t)SC_DLAST); hux0 = MPC_U(P.SC, (uint32_t)SC_HUX0); hux1 = MPC_U(P.SC, (uint32_t)SC_HUX1); }
     }
     for (;;) {
-        if (wave == 1) {
+        if (wave == 2) {
+            for (int t = 0; t <= N; ++t) lds_barrier();             // second loader: idle in the backward sweep
+        } else if (wave == 1) {
             // ---------------- loader: stages N, N-1, ... ; stage N-t lives in slot t % RIC_DEPTH
             for (int j = 0; j < RIC_DEPTH - 1 && j <= N; ++j) dma(blk_base + (uint32_t)(N - j) * BLK_BYTES, (uint32_t)j * SLOT, BLK_CHUNKS);
             for (int t = 0; t <= N; ++t) {
                 const int k = N - t;
                 wait_dma_behind<BLK_CHUNKS>(k < RIC_DEPTH - 2 ? k : RIC_DEPTH - 2);       // stage k has landed
-                __syncthreads();                                                           // compute: go on stage k (and is done with k+1)
+                lds_barrier();                                                           // compute: go on stage k (and is done with k+1)
                 const int kn = k - (RIC_DEPTH - 1);
                 if (kn >= 0) dma(blk_base + (uint32_t)kn * BLK_BYTES, (uint32_t)((t + RIC_DEPTH - 1) % RIC_DEPTH) * SLOT, BLK_CHUNKS);
             }
@@ -336,7 +360,7 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             for (int t = 0; t <= N; ++t) {
                 const int k = N - t;
                 if (t == 15) RIC_STAMP(3);
-                __syncthreads();
+                lds_barrier();
                 if (t == 15) RIC_STAMP(4);
                 RicStage<NX> s;
                 read_stage((uint32_t)(t % RIC_DEPTH) * SLOT, s);
@@ -367,27 +391,32 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // gains / cost-to-go are out
             if (lane == 0) *flag = again;
         }
-        __syncthreads();
+        lds_barrier();
         const int again = *flag;
-        __syncthreads();
+        lds_barrier();
         if (!again) break;
     }
     RIC_STAMP(1);
     // ================================================================ forward sweep
     const bool go = (wave == 0) && active && !failed;
-    if (wave == 1) {
+    if (wave >= 1) {
+        // two loaders: wave 1 owns the even stages, wave 2 the odd ones.  Stage k lives in slot k % RIC_DEPTH_F; the slot
+        // of stage k-1 is free once the compute wave has reached barrier k, and gets stage k-1+RIC_DEPTH_F.
+        const int par = wave - 1;
         auto dma_fwd = [&](int k, uint32_t dst) {
             dma(kk_base + (uint32_t)k * (D::NKK * 512u), dst, KK_CHUNKS);
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_A * 512u, dst + KK_CHUNKS * 1024u, 3);
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_CN * 512u, dst + (KK_CHUNKS + 3) * 1024u, 3);
         };
-        for (int j = 0; j < RIC_DEPTH_F - 1 && j < N; ++j) dma_fwd(j, (uint32_t)j * FSLOT);
+        for (int j = par; j < RIC_DEPTH_F - 1 && j < N; j += 2) dma_fwd(j, (uint32_t)j * FSLOT);
         for (int k = 0; k < N; ++k) {
-            const int left = N - 1 - k;                                                    // stages after k already requested
-            wait_dma_behind<FWD_CHUNKS>(left < RIC_DEPTH_F - 2 ? left : RIC_DEPTH_F - 2);
-            __syncthreads();
+            if ((k & 1) == par) {
+                const int last = (N - 1 < k + RIC_DEPTH_F - 2) ? N - 1 : k + RIC_DEPTH_F - 2;    // newest stage requested so far
+                wait_dma_behind<FWD_CHUNKS>((last - k) >> 1);                                     // my stages after k in flight
+            }
+            lds_barrier();
             const int kn = k + RIC_DEPTH_F - 1;
-            if (kn < N) dma_fwd(kn, (uint32_t)((k + RIC_DEPTH_F - 1) % RIC_DEPTH_F) * FSLOT);
+            if (kn < N && (kn & 1) == par) dma_fwd(kn, (uint32_t)(kn % RIC_DEPTH_F) * FSLOT);
         }
     } else {
         if (active && failed) MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7;
@@ -401,7 +430,7 @@ __global__ void __launch_bounds__(128) k_riccati(const Params P) {
         for (int k = 0; k < N; ++k) {
             const uint32_t slot = (uint32_t)(k % RIC_DEPTH_F) * FSLOT;
             if (k == 15) RIC_STAMP(6);
-            __syncthreads();
+            lds_barrier();
             if (k == 15) RIC_STAMP(7);
             FwdStage<NX> f;
 #pragma unroll
@@ -897,7 +926,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 Pg.tile0 = q.tile0;
                 prof.begin(0, q.st);
                 if (stage_timing && it + j == 3) Pg.DBG = d_dbg + (size_t)8 * nblk;   // Riccati stamps of the 4th iteration
-                hipLaunchKernelGGL((k_riccati<NX>), dim3(q.ntl), dim3(128), ric_lds, q.st, Pg);
+                hipLaunchKernelGGL((k_riccati<NX>), dim3(q.ntl), dim3(192), ric_lds, q.st, Pg);
                 Pg.DBG = nullptr;
                 prof.end(q.st);
                 prof.begin(1, q.st);
