@@ -330,15 +330,25 @@ struct Ctx {
     // --- LDS image of the rows that only the update phase needs (PF kernels: fetched by global->LDS DMA while phase 1
     //     and the line search run).  Element e of array A at stage k, column bl:  pf[A_base + e * pf_row + pf_col]
     mpc_lds_cptr pf;
+    mpc_lds_cptr bnd;                        // LDS copy of the bounds table [LB (N+1)*NZ | UB (N+1)*NZ] (device)
+    int bnd_ub;
     int pf_row, pf_col, pf_lam, pf_nuo;      // doubles: (N+1)*bx, k*bx + bl, first element of the LAM / NUO images
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
 
 // bounds of variable i of stage k; a_0 (k = 0, i = 1) carries the per-instance presolved friction bound
+// (device: from the workgroup's LDS copy of the table, c.bnd = [LB | UB] -- a global load here would sit behind the
+//  kernel's own stores in the shared vmcnt counter and stall until all of them are acknowledged)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_BOUNDS(k, i, lb, ub)                                    \
+    double lb = c.bnd[(k) * NZ + (i)], ub = c.bnd[c.bnd_ub + (k) * NZ + (i)];    \
+    if ((k) == 0 && (i) == 1) { lb = c.a0lb; ub = c.a0ub; }
+#else
 #define MPC_BOUNDS(k, i, lb, ub)                                    \
     double lb = MPC_GP(P.LB, (k) * NZ + (i)), ub = MPC_GP(P.UB, (k) * NZ + (i));    \
     if ((k) == 0 && (i) == 1) { lb = c.a0lb; ub = c.a0ub; }
+#endif
 
 // ---- model pieces ----------------------------------------------------------------------------------------
 // kinematic single-track ODE, configuration.py:353-368

@@ -190,6 +190,14 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     c.iters = 0;
 #define MPC_STAMP(i) do { if (P.DBG && t == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
+    // LDS: [reduction scratch | bounds table | exchange / stash rows | prefetch images]
+    double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
+    const int nb = (P.N + 1) * (NX + 2);
+    double* lds_x = lds_b + 2 * nb;
+    for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
+    c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
+    c.bnd_ub = nb;
+    if (INIT) lds_barrier();                           // (the iteration kernel passes a barrier before its first use anyway)
     if (INIT) {
         Red0 r0;
         phase_init_point<NX>(P, c, r0);
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
         phase_preload<NX, PF>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
-        char* pfb = reinterpret_cast<char*>(lds + (blockDim.x >> 6) * 10 * bx + stash_rows * (int)blockDim.x);
+        char* pfb = reinterpret_cast<char*>(lds_x + stash_rows * (int)blockDim.x);
         if (PF) {
             const PfLayout<NX> L(P.N, bx);
             c.pf = (mpc_lds_cptr)(lds_ptr_t)pfb;
@@ -221,7 +229,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         block_reduce(r1, bx, lds);
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
-        double* stash = lds + (blockDim.x >> 6) * 10 * bx;     // shares the exchange region (each thread touches its own column only)
+        double* stash = lds_x;                                 // shares the exchange region (each thread touches its own column only)
         if (STASH) stash_xfer<NX, PF, true>(c, stash, blockDim.x, t, P.has_ou != 0);
         if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the prefetch has landed; the barrier below publishes it
         while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
@@ -237,7 +245,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
     {
-        double* ex = lds + (blockDim.x >> 6) * 10 * bx;       // behind the reduction scratch
+        double* ex = lds_x;                                   // behind the reduction scratch and the bounds table
         const int T = blockDim.x;
 #pragma unroll
         for (int i = 0; i < NX; ++i) { ex[i * T + t] = c.z[2 + i]; ex[(NX + i) * T + t] = c.lam[i]; }
@@ -825,9 +833,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // bound by the per-workgroup latency chain, not by the load burst the prefetch spreads out
     bool use_pf = small_wg && getenv("MPCGPU_PREFETCH") != nullptr;
     int stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, true>::rows(has_ou), 2 * NX) : 2 * NX;
-    if (use_pf && ((size_t)nw * 10 * bx + (size_t)stash_rows * threads) * sizeof(double) + (size_t)pfl.total * 1024 > lds_max) use_pf = false;
+    if (use_pf && ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double) + (size_t)pfl.total * 1024 > lds_max) use_pf = false;
     if (!use_pf) stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, false>::rows(has_ou), 2 * NX) : 2 * NX;
-    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)stash_rows * threads) * sizeof(double) + (use_pf ? (size_t)pfl.total * 1024 : 0);
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double) + (use_pf ? (size_t)pfl.total * 1024 : 0);
     const int rblk = (int)(Bp / 64);
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
