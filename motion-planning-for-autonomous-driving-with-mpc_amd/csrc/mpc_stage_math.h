@@ -450,20 +450,18 @@ MPC_HD void ingest_instance(const Params& P, int b) {
     }
 }
 
-template <int NX>
-MPC_HD void prestart_instance(const Params& P, int b) {
-    constexpr int NZ = NX + 2;
-    const int N = P.N;
-    const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;
-    // the caller's rows were transposed into the workspace by the ingest kernel: Z holds the raw x0, REF holds X_ref
 #define X0U(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + (uint32_t)(i_)))
 #define X0X(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + 2u + (uint32_t)(i_)))
 #define PRX(k_, i_) ((double)MPC_U(P.REF, (uint32_t)(k_) * NX + (uint32_t)(i_)))
-    // presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
-    // by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
-    // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
-    // start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
-    double a0lb = MPC_GP(P.LB, 1), a0ub = MPC_GP(P.UB, 1);
+// presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
+// by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
+// lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
+// start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
+template <int NX>
+MPC_HD int prestart_a0(const Params& P, int b, double& a0lb, double& a0ub) {
+    const uint32_t bb = (uint32_t)b;
+    a0lb = MPC_GP(P.LB, 1);
+    a0ub = MPC_GP(P.UB, 1);
     int frow = 1;
     if (!P.has_fl && P.has_fu) {
         const double dl0 = PRX(0, 2), v0 = PRX(0, 3);
@@ -476,41 +474,79 @@ MPC_HD void prestart_instance(const Params& P, int b) {
             frow = 0;
         }
     }
-    MPC_U(P.SC, (uint32_t)SC_A0LB) = a0lb;
-    MPC_U(P.SC, (uint32_t)SC_A0UB) = a0ub;
-    MPC_U(P.ISC, (uint32_t)IS_FROW) = frow;
-    double xg[NX], xr[NX], f[NX], u[2], s, c, td;
-    double th_g = 0.0, th_r = 0.0;
+    return frow;
+}
+// The two chains of the start-point safeguard are independent of each other (the GPU runs them in two wavefronts):
+//   ROLLOUT = true : forward rollout of the caller's control guess from r_0, stored in ROLL; returns its clipping defect
+//   ROLLOUT = false: returns the dynamics defect of the caller's state guess
+// The loads of stage k+1 are issued before the arithmetic of stage k (the chain is otherwise load-latency bound).
+template <int NX, bool ROLLOUT>
+MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
+    constexpr int NZ = NX + 2;
+    const int N = P.N;
+    const uint32_t bb = (uint32_t)b;
+    double x[NX], f[NX], u[2], un[2], gnext[NX], s, c, td;
+    double th = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const double r0 = PRX(0, i);
-        xg[i] = push_in(X0X(0, i), MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
-        xr[i] = push_in(r0, MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
-        th_g += fabs(xg[i] - r0);
-        th_r += fabs(xr[i] - r0);
-        MPC_U(P.ROLL, (uint32_t)i) = xr[i];
+        x[i] = push_in(ROLLOUT ? r0 : X0X(0, i), MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
+        th += fabs(x[i] - r0);
+        if (ROLLOUT) MPC_U(P.ROLL, (uint32_t)i) = x[i];
+        gnext[i] = ROLLOUT ? 0.0 : X0X(1, i);
     }
+    un[0] = X0U(0, 0);
+    un[1] = X0U(0, 1);
     for (int k = 0; k < N; ++k) {
-        u[0] = push_in(X0U(k, 0), MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
-        u[1] = push_in(X0U(k, 1), (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
-        double fr[NX];
-        ode_eval<NX>(P, xg, u, f, s, c, td);
-        ode_eval<NX>(P, xr, u, fr, s, c, td);
+        u[0] = push_in(un[0], MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
+        u[1] = push_in(un[1], (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
+        double graw[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) graw[i] = gnext[i];
+        if (k + 1 < N) {                                   // next stage's inputs: in flight during this stage's arithmetic
+            un[0] = X0U(k + 1, 0);
+            un[1] = X0U(k + 1, 1);
+            if (!ROLLOUT) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) gnext[i] = X0X(k + 2, i);
+            }
+        }
+        ode_eval<NX>(P, x, u, f, s, c, td);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double lb = MPC_GP(P.LB, (k + 1) * NZ + 2 + i), ub = MPC_GP(P.UB, (k + 1) * NZ + 2 + i);
-            const double gn = push_in(X0X(k + 1, i), lb, ub);
-            th_g += fabs(gn - (f[i] * P.dt + xg[i]));
-            xg[i] = gn;
-            const double rraw = fr[i] * P.dt + xr[i];
-            const double rn = push_in(rraw, lb, ub);
-            th_r += fabs(rn - rraw);
-            xr[i] = rn;
-            MPC_U(P.ROLL, ((uint32_t)(k + 1) * NX + i)) = rn;
+            const double raw = f[i] * P.dt + x[i];
+            if (ROLLOUT) {
+                const double rn = push_in(raw, lb, ub);
+                th += fabs(rn - raw);
+                x[i] = rn;
+                MPC_U(P.ROLL, ((uint32_t)(k + 1) * NX + i)) = rn;
+            } else {
+                const double gn = push_in(graw[i], lb, ub);
+                th += fabs(gn - raw);
+                x[i] = gn;
+            }
         }
     }
+    return th;
+}
+template <int NX>
+MPC_HD void prestart_decide(const Params& P, int b, int frow, double a0lb, double a0ub, double th_g, double th_r) {
+    const uint32_t bb = (uint32_t)b;
+    MPC_U(P.SC, (uint32_t)SC_A0LB) = a0lb;
+    MPC_U(P.SC, (uint32_t)SC_A0UB) = a0ub;
+    MPC_U(P.ISC, (uint32_t)IS_FROW) = frow;
     const bool use = !(th_g <= ROLLOUT_FACTOR * fmax(1.0, th_r));      // also true when th_g is NaN
     MPC_U(P.ISC, (uint32_t)IS_ROLL) = use ? 1 : 0;
+}
+template <int NX>
+MPC_HD void prestart_instance(const Params& P, int b) {
+    // the caller's rows were transposed into the workspace by the ingest kernel: Z holds the raw x0, REF holds X_ref
+    double a0lb, a0ub;
+    const int frow = prestart_a0<NX>(P, b, a0lb, a0ub);
+    const double th_r = prestart_chain<NX, true>(P, b, a0lb, a0ub);
+    const double th_g = prestart_chain<NX, false>(P, b, a0lb, a0ub);
+    prestart_decide<NX>(P, b, frow, a0lb, a0ub, th_g, th_r);
 }
 #undef X0U
 #undef X0X

@@ -469,10 +469,22 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
 #endif
 }
 
+// start-point safeguard: one tile of 64 instances per workgroup, two wavefronts -- wave 0 rolls the control guess out,
+// wave 1 measures the dynamics defect of the caller's state guess (both are 30-stage dependent chains of sin/cos/tan)
 template <int NX>
-__global__ void __launch_bounds__(64) k_prestart(const Params P) {
-    const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + threadIdx.x;
-    if (b < P.B) prestart_instance<NX>(P, b);
+__global__ void __launch_bounds__(128) k_prestart(const Params P) {
+    __shared__ double th_guess[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + lane;
+    double a0lb = 0.0, a0ub = 0.0, th = 0.0;
+    int frow = 1;
+    if (b < P.B) {
+        frow = prestart_a0<NX>(P, b, a0lb, a0ub);
+        th = (wave == 0) ? prestart_chain<NX, true>(P, b, a0lb, a0ub) : prestart_chain<NX, false>(P, b, a0lb, a0ub);
+    }
+    if (wave == 1) th_guess[lane] = th;
+    __syncthreads();
+    if (wave == 0 && b < P.B) prestart_decide<NX>(P, b, frow, a0lb, a0ub, th_guess[lane], th);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -489,6 +501,7 @@ __device__ __forceinline__ uint32_t zrow_of_col(int col, int N) {          // de
     return (uint32_t)(cx / NX) * NZ + 2u + (uint32_t)(cx % NX);
 }
 
+// grid = (tiles, 64-column chunks): every workgroup moves one 64 x 64 block, so a batch of 64 tiles is ~450 workgroups
 template <int NX>
 __global__ void __launch_bounds__(256) k_ingest(const Params P) {
     __shared__ double tile[64][65];
@@ -497,28 +510,26 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double* Zt = P.Z + (size_t)tl * P.tile_elems;
     double* Rt = P.REF + (size_t)tl * P.tile_elems;
-    for (int pass = 0; pass < 2; ++pass) {
-        const double* src = pass == 0 ? P.x0 : P.p;
-        for (int c0 = (pass == 0 ? 0 : 2 * N); c0 < nw; c0 += 64) {
-            for (int r = w; r < 64; r += 4) {
-                const int col = c0 + lane;
-                const uint32_t b = t0 + (uint32_t)r;
-                tile[r][lane] = (col < nw && b < (uint32_t)P.B) ? src[(size_t)b * nw + col] : 0.0;
-            }
-            __syncthreads();
-            for (int cc = w; cc < 64; cc += 4) {
-                const int col = c0 + cc;
-                if (col < nw) {
-                    if (pass == 0) Zt[zrow_of_col<NX>(col, N) * 64u + lane] = tile[lane][cc];
-                    else Rt[(uint32_t)(col - 2 * N) * 64u + lane] = tile[lane][cc];
-                }
-            }
-            __syncthreads();
+    const int nc0 = (nw + 63) / 64;                          // chunks of x0; the rest are chunks of the X_ref part of p
+    const int pass = (int)blockIdx.y < nc0 ? 0 : 1;
+    const int c0 = pass == 0 ? (int)blockIdx.y * 64 : 2 * N + ((int)blockIdx.y - nc0) * 64;
+    const double* src = pass == 0 ? P.x0 : P.p;
+    for (int r = w; r < 64; r += 4) {
+        const int col = c0 + lane;
+        const uint32_t b = t0 + (uint32_t)r;
+        tile[r][lane] = (col < nw && b < (uint32_t)P.B) ? src[(size_t)b * nw + col] : 0.0;
+    }
+    __syncthreads();
+    for (int cc = w; cc < 64; cc += 4) {
+        const int col = c0 + cc;
+        if (col < nw) {
+            if (pass == 0) Zt[zrow_of_col<NX>(col, N) * 64u + lane] = tile[lane][cc];
+            else Rt[(uint32_t)(col - 2 * N) * 64u + lane] = tile[lane][cc];
         }
     }
     // u rows of the terminal stage do not exist in x0
     constexpr int NZ = NX + 2;
-    if (threadIdx.x < 128) Zt[((uint32_t)N * NZ + (threadIdx.x >> 6)) * 64u + lane] = 0.0;
+    if (blockIdx.y == 0 && threadIdx.x < 128) Zt[((uint32_t)N * NZ + (threadIdx.x >> 6)) * 64u + lane] = 0.0;
 }
 
 template <int NX>
@@ -528,19 +539,18 @@ __global__ void __launch_bounds__(256) k_egest(const Params P) {
     const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const double* Zt = P.Z + (size_t)tl * P.tile_elems;
-    for (int c0 = 0; c0 < nw; c0 += 64) {
-        for (int cc = w; cc < 64; cc += 4) {
-            const int col = c0 + cc;
-            tile[lane][cc] = (col < nw) ? Zt[zrow_of_col<NX>(col, N) * 64u + lane] : 0.0;
-        }
-        __syncthreads();
-        for (int r = w; r < 64; r += 4) {
-            const int col = c0 + lane;
-            const uint32_t b = t0 + (uint32_t)r;
-            if (col < nw && b < (uint32_t)P.B) P.x_out[(size_t)b * nw + col] = tile[r][lane];
-        }
-        __syncthreads();
+    const int c0 = (int)blockIdx.y * 64;
+    for (int cc = w; cc < 64; cc += 4) {
+        const int col = c0 + cc;
+        tile[lane][cc] = (col < nw) ? Zt[zrow_of_col<NX>(col, N) * 64u + lane] : 0.0;
     }
+    __syncthreads();
+    for (int r = w; r < 64; r += 4) {
+        const int col = c0 + lane;
+        const uint32_t b = t0 + (uint32_t)r;
+        if (col < nw && b < (uint32_t)P.B) P.x_out[(size_t)b * nw + col] = tile[r][lane];
+    }
+    if (blockIdx.y != 0) return;
     if (threadIdx.x < 64) {
         const uint32_t b = t0 + (uint32_t)lane;
         if (b < (uint32_t)P.B) {
@@ -899,8 +909,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Params Pg = P;
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
-        hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl), dim3(256), 0, q.st, Pg);
-        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(64), 0, q.st, Pg);
+        const int n_w = 2 * d.N + NX * (d.N + 1);
+        hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
+        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), 0, q.st, Pg);
         launch_stage(q, true);
         prof.end(q.st);
     }
@@ -1004,7 +1015,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Params Pg = P;
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl), dim3(256), 0, q.st, Pg);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg);
         prof.end(q.st);
         if (G > 1) {
             HIP_TRY(h, hipEventRecord(h->ev_join[g], q.st));
