@@ -47,6 +47,18 @@ def algorithmic_bytes(N, nx, nu=2):
     return dict(K=K, I=I, b_iter=b_iter, b_io=b_io, b_riccati=b_riccati, b_stage=b_stage)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes over this very
+    command, tools/pmc_run.sh + tools/pmc_summary.py; counters cannot be read from inside the timed process)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))[kernel]["hbm_bytes_per_launch_mean"]
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +156,7 @@ def main():
                           gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9, total_ms_per_step=ms / args.steps)
     dom = max(kern, key=lambda k: kern[k]["total_ms_per_step"])
     roofline = dict(bound="hbm", kernel=dom, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=None,
+                    frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=pmc_traffic(dom),
                     avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
                     algorithmic_bytes_per_launch=kern[dom]["bytes_per_launch"],
                     other_kernel={k: v for k, v in kern.items() if k != dom},

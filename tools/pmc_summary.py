@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection CSVs: per kernel name, mean counter value per dispatch.
-usage: python tools/pmc_summary.py <dir with p*/p*_counter_collection.csv>"""
+usage: python tools/pmc_summary.py <dir with p*/p*_counter_collection.csv> [--json profiles/pmc_traffic.json]
+
+HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE counts 64 B per 128-B request
+(MI355X_MICROARCH.md, HBM section); verified for this code's 8-byte-per-lane pattern with tools/ubench/ldpat.hip
+(145.2 MB read -> FETCH_SIZE 71 553 KiB; 145.2 MB written -> WRITE_SIZE 143 884 KiB incl. the 1 MB result array)."""
 import csv
 import glob
 import os
@@ -8,7 +12,7 @@ import sys
 from collections import defaultdict
 
 
-def main(d):
+def main(d, json_out=None):
     acc = defaultdict(lambda: defaultdict(list))
     for f in sorted(glob.glob(os.path.join(d, "p*", "*_counter_collection.csv"))):
         with open(f) as fh:
@@ -27,5 +31,29 @@ def main(d):
             print(f"   {c:28s} n={len(vv):4d} mean={sum(vv) / len(vv):16.1f} max={mx:16.1f}")
 
 
+    if json_out:
+        import json
+        out = {}
+        for k, cs in acc.items():
+            if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+                continue
+            name = "k_stage" if "k_stage" in k and "true" not in k.split(",")[1] else ("k_riccati" if "k_riccati" in k else None)
+            if name is None:
+                continue
+
+            def live(v):
+                mx = max(v)
+                return [x for x in v if x > 0.1 * mx] or v
+            fe, wr = live(cs["FETCH_SIZE"]), live(cs["WRITE_SIZE"])
+            out[name] = dict(fetch_size_kib_mean=sum(fe) / len(fe), write_size_kib_mean=sum(wr) / len(wr),
+                             fetch_size_kib_max=max(fe), write_size_kib_max=max(wr),
+                             hbm_bytes_per_launch_mean=(2 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024,
+                             hbm_bytes_per_launch_full=(2 * max(fe) + max(wr)) * 1024,
+                             note="2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes over `python bench.py --steps 2 --warmup 1` "
+                                  "(converged mode; launches below 10% of the maximum, i.e. early exits, excluded)")
+        json.dump(out, open(json_out, "w"), indent=1)
+        print("wrote", json_out)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--json" else None)
