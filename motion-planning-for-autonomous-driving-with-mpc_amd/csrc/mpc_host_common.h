@@ -159,6 +159,8 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     for (int i = 0; i < 6; ++i) P.obst[i] = d.obstacle[i];
     P.fl = hp.fl; P.fu = hp.fu; P.ol = hp.ol; P.ou = hp.ou;
     P.inv_S = (uint32_t)((0x100000000ull + (uint64_t)d.N) / (uint64_t)(d.N + 1));
+    P.run_counter = nullptr;
+    P.tile_mask = nullptr;
     P.lo_mask = P.hi_mask = 0;
     for (size_t q = 0; q < hp.LB.size(); ++q) {
         const int i = (int)(q % (size_t)hp.NZ());

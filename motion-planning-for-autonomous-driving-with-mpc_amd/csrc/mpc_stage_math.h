@@ -81,6 +81,8 @@ struct Params {
     double dt, wheelbase, friction_div, ego_offset, tol;
     double Q[6], R[2], obst[6];
     double fl, fu, ol, ou;       // relaxed slack bounds of the friction / obstacle rows
+    unsigned long long* tile_mask;   // [tiles] bit l: instance l of the tile was iterating when the last Riccati launch started (stage workgroups with no such instance leave before touching HBM)
+    int32_t* run_counter;        // device counter of this launch: += instances still iterating after it (nullptr: none)
     uint32_t inv_S;              // ceil(2^32 / (N+1)): segment -> (row, stage) split of the LDS prefetch
     uint32_t lo_mask, hi_mask;   // bit i: variable i of (u, x) has a finite lower / upper bound at SOME stage (multiplier rows of the others never move)
     const double* x0;            // [B][n_w] row-major (ABI input)

@@ -190,6 +190,13 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     c.iters = 0;
 #define MPC_STAMP(i) do { if (P.DBG && t == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
+    if (!INIT) {
+        if (P.tile_mask != nullptr) {                  // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
+            const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
+            const unsigned long long m = P.tile_mask[b0 >> 6] >> (b0 & 63u);
+            if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
+        }
+    }
     // LDS: [reduction scratch | bounds table | exchange / stash rows | prefetch images]
     double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
     const int nb = (P.N + 1) * (NX + 2);
@@ -264,6 +271,11 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     MPC_STAMP(9);
     phase_finish<NX>(P, c, r3, n_mult, n_z);
     MPC_STAMP(10);
+    // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
+    if (P.run_counter != nullptr && t < 64) {
+        const int cnt = __popcll(__ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0));
+        if (t == 0 && cnt) atomicAdd(P.run_counter, cnt);
+    }
 #undef MPC_STAMP
 }
 
@@ -315,7 +327,9 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
     const uint32_t bb = (uint32_t)b;
     const int N = P.N;
     const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
-    if (!__any(active ? 1 : 0)) return;                             // both waves see the same 64 instances
+    const unsigned long long act_mask = __ballot(active ? 1 : 0);
+    if (P.tile_mask != nullptr && threadIdx.x == 0) P.tile_mask[tile] = act_mask;
+    if (!__any(active ? 1 : 0)) return;                             // all waves see the same 64 instances
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
@@ -629,8 +643,12 @@ struct mpc_handle {
     double* d_ws = nullptr;
     int32_t* d_iws = nullptr;
     double *d_LB = nullptr, *d_UB = nullptr;
-    int32_t* d_counter = nullptr;
-    int32_t* h_counter = nullptr;      // pinned
+    static constexpr int MAX_POLL_IT = 1024;
+    unsigned long long* d_tile_mask = nullptr;
+    size_t tile_mask_cap = 0;
+    int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
+    int32_t* h_counter = nullptr;      // pinned, [MAX_GROUPS][2] (double-buffered per poll)
+    hipEvent_t ev_poll[4][2] = {};
     // staging buffers of the host entry point
     size_t cap_io = 0;
     double *d_x0 = nullptr, *d_p = nullptr, *d_xout = nullptr, *d_kkt = nullptr, *d_obst = nullptr;
@@ -699,13 +717,15 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     h->hp.desc = *desc;
     h->device = desc->device;
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS) != hipSuccess ||
-        hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS) != hipSuccess) {
+        hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT) != hipSuccess ||
+        hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess) {
         g_create_error = "HIP stream/counter allocation failed";
         delete h;
         return MPC_ERR_HIP;
     }
     bool ok_streams = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g)
+        for (int q = 0; q < 2; ++q) ok_streams = ok_streams && hipEventCreateWithFlags(&h->ev_poll[g][q], hipEventDisableTiming) == hipSuccess;
     for (int g = 0; g < mpc_handle::MAX_GROUPS && ok_streams; ++g)
         ok_streams = hipStreamCreateWithFlags(&h->sub_stream[g], hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming) == hipSuccess;
@@ -724,9 +744,12 @@ int mpc_destroy(mpc_handle* h) {
     if (h->d_LB) (void)hipFree(h->d_LB);
     if (h->d_UB) (void)hipFree(h->d_UB);
     if (h->d_counter) (void)hipFree(h->d_counter);
+    if (h->d_tile_mask) (void)hipFree(h->d_tile_mask);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g)
+        for (int q = 0; q < 2; ++q) if (h->ev_poll[g][q]) (void)hipEventDestroy(h->ev_poll[g][q]);
     for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g) {
         if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
         if (h->sub_stream[g]) (void)hipStreamDestroy(h->sub_stream[g]);
@@ -932,7 +955,27 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         HIP_TRY(h, hipMalloc(&d_dbg, sizeof(unsigned long long) * 16 * (size_t)nblk));
         HIP_TRY(h, hipMemset(d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)nblk));
     }
-    int it = 0;
+    // Convergence polling: every stage launch adds the number of instances it leaves running to its own device counter;
+    // after each chunk the last counter is copied to pinned memory.  The host looks at the poll of chunk c-1 only after
+    // chunk c is enqueued, so the GPU never idles on a host round trip; the price is one chunk of early-exit launches
+    // (a few microseconds each) at the very end.
+    if (h->tile_mask_cap < (size_t)ntiles) {
+        if (h->d_tile_mask) (void)hipFree(h->d_tile_mask);
+        h->d_tile_mask = nullptr;
+        HIP_TRY(h, hipMalloc(&h->d_tile_mask, sizeof(unsigned long long) * (size_t)ntiles));
+        h->tile_mask_cap = (size_t)ntiles;
+    }
+    P.tile_mask = h->d_tile_mask;
+    const bool polled = d.fixed_iters <= 0 && !trace;
+    if (polled) {
+        if (cap > mpc_handle::MAX_POLL_IT) { h->err = "max_iter exceeds the poll table (1024)"; return MPC_ERR_INVALID; }
+        HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT, stream));
+        if (G > 1) {     // the sub-streams were forked before this memset was enqueued
+            HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
+            for (int g = 0; g < G; ++g) HIP_TRY(h, hipStreamWaitEvent(h->sub_stream[g], h->ev_fork, 0));
+        }
+    }
+    int it = 0, chunk_id = 0;
     while (it < cap) {
         const int n = std::min(trace ? 1 : chunk, cap - it);
         bool any = false;
@@ -950,30 +993,44 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 prof.end(q.st);
                 prof.begin(1, q.st);
                 P.DBG = (stage_timing && it + j == 2) ? d_dbg : nullptr;      // stamp the third iteration
+                P.run_counter = polled ? h->d_counter + (size_t)g * mpc_handle::MAX_POLL_IT + (it + j) : nullptr;
                 launch_stage(q, false);
+                P.run_counter = nullptr;
                 prof.end(q.st);
             }
             if (trace) { rc = record_trace(it + j); if (rc) return rc; }
         }
         it += n;
-        if (!any || d.fixed_iters > 0) { if (d.fixed_iters > 0 && it < cap) continue; break; }
-        // convergence poll, one 4-byte counter per group
+        if (!any) break;
+        if (!polled) {
+            if (trace) {                                  // trace mode: exact stop, one synchronous count per iteration
+                HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t), stream));
+                hipLaunchKernelGGL(k_count_running, dim3((B + 255) / 256), dim3(256), 0, stream, h->d_iws, (uint32_t)w.itile_elems, 0, B, h->d_counter);
+                HIP_TRY(h, hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(h, hipStreamSynchronize(stream));
+                if (h->h_counter[0] == 0) break;
+            }
+            continue;
+        }
+        const int slot = chunk_id & 1;
         for (int g = 0; g < G; ++g) {
             const Group& q = grp[g];
             if (!q.running) continue;
-            HIP_TRY(h, hipMemsetAsync(h->d_counter + g, 0, sizeof(int32_t), q.st));
-            hipLaunchKernelGGL(k_count_running, dim3((q.b1 - q.b0 + 255) / 256), dim3(256), 0, q.st, h->d_iws, (uint32_t)w.itile_elems, q.b0, q.b1,
-                               h->d_counter + g);
-            HIP_TRY(h, hipMemcpyAsync(h->h_counter + g, h->d_counter + g, sizeof(int32_t), hipMemcpyDeviceToHost, q.st));
+            HIP_TRY(h, hipMemcpyAsync(h->h_counter + 2 * g + slot, h->d_counter + (size_t)g * mpc_handle::MAX_POLL_IT + (it - 1), sizeof(int32_t),
+                                      hipMemcpyDeviceToHost, q.st));
+            HIP_TRY(h, hipEventRecord(h->ev_poll[g][slot], q.st));
         }
-        bool still = false;
-        for (int g = 0; g < G; ++g) {
-            Group& q = grp[g];
-            if (!q.running) continue;
-            HIP_TRY(h, hipStreamSynchronize(q.st));
-            if (h->h_counter[g] == 0) q.running = false; else still = true;
+        if (chunk_id >= 1) {                              // look at the PREVIOUS chunk's poll (this chunk is already in the queue)
+            bool still = false;
+            for (int g = 0; g < G; ++g) {
+                Group& q = grp[g];
+                if (!q.running) continue;
+                HIP_TRY(h, hipEventSynchronize(h->ev_poll[g][slot ^ 1]));
+                if (h->h_counter[2 * g + (slot ^ 1)] == 0) q.running = false; else still = true;
+            }
+            if (!still) break;
         }
-        if (!still) break;
+        ++chunk_id;
     }
     P.DBG = nullptr;
     if (trace) { rc = record_trace(it); if (rc) return rc; (void)hipFree(d_trace); }
