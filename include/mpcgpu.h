@@ -109,6 +109,20 @@ int mpc_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const doub
  * optimizer.py:649-650) or one RK4 step (integrator 1, optimizer.py:97-98).  x: [B, nx], u: [B, 2] host. */
 int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x, const double* u, double* x_next);
 
+/* Closed-loop driver (scope row f1): the loop body of CasadiOptimizer.optimize (optimizer.py:596-631) run for B egos
+ * without host round trips between the solves -- per step: mpc_solve_batch_dev, first control, forward-Euler plant
+ * step (shift_movement, optimizer.py:645-655), shifted warm start in the layouts the reference produces
+ * (optimizer.py:602), next reference window incl. the frozen tail (desired_command_and_trajectory, :657-702).
+ * nx = 5 only.  init_state [B,5] = (x, y, 0, v, psi) (optimizer.py:575); path [B,Lp,2], orient [B,Lp]: resampled path
+ * points and orientation of every ego, Lp >= L = iter_length >= N; vdes [B].  Outputs: traj [B,L,5] (row i = state
+ * before step i: what optimize() returns as its first array), ctrl [B,L,2] (second array), step_status [B,L] or NULL
+ * (solver status of every step; the reference ignores it).  No noise (`noised: False`).                           */
+int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
+                          const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status);
+int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
+                              const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl,
+                              int32_t* d_step_status, void* stream);
+
 /* ---- measurement helpers (bench.py / tests) ---------------------------------------------------------- */
 /* kernel timing of the LAST mpc_solve_batch[_dev] call, measured with HIP events on the solve stream when
  * profiling is enabled: out[0] = total ms in the Riccati factor/solve kernel, out[1] = its launch count,

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "mpc_host_common.h"
+#include "mpc_closed_loop.h"
 
 using namespace mpc;
 
@@ -600,6 +601,16 @@ __global__ void k_gather_trace(const double* SC /*rows of tile 0*/, uint32_t til
     for (int q = 0; q < 8; ++q) out[(size_t)q * B + b] = SC[((uint32_t)b >> 6) * tile_elems + (uint32_t)rows[q] * 64u + ((uint32_t)b & 63u)];
 }
 
+// closed-loop driver around the solve (row f1): one instance per thread, row-major buffers
+__global__ void k_loop_setup(const LoopArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) loop_setup_instance(A, b);
+}
+__global__ void k_loop_advance(const Params P, const LoopArgs A, const int i) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) loop_advance_instance(P, A, b, i);
+}
+
 template <int NX>
 __global__ void k_plant_step(const Params P, const double* x, const double* u, double* xn, int B, int integrator) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,6 +656,8 @@ struct mpc_handle {
     double *d_LB = nullptr, *d_UB = nullptr;
     static constexpr int MAX_POLL_IT = 1024;
     unsigned long long* d_tile_mask = nullptr;
+    double* d_state = nullptr;         // [B,5] plant state of the closed-loop driver
+    size_t cap_state = 0;
     size_t tile_mask_cap = 0;
     int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
     int32_t* h_counter = nullptr;      // pinned, [MAX_GROUPS][2] (double-buffered per poll)
@@ -745,6 +758,7 @@ int mpc_destroy(mpc_handle* h) {
     if (h->d_UB) (void)hipFree(h->d_UB);
     if (h->d_counter) (void)hipFree(h->d_counter);
     if (h->d_tile_mask) (void)hipFree(h->d_tile_mask);
+    if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1174,6 +1188,80 @@ int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x
     HIP_TRY(h, hipMemcpy(x_next, dn, (size_t)B * nx * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
     return MPC_OK;
+}
+
+int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
+                              const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl, int32_t* d_step_status,
+                              void* stream_) {
+    if (!h) return MPC_ERR_INVALID;
+    const mpc_problem_desc& d = h->hp.desc;
+    if (d.nx != 5) { h->err = "the closed loop of optimizer.py:562-643 is defined for the 5-state CasADi formulation (nx = 5)"; return MPC_ERR_INVALID; }
+    if (B <= 0 || L <= 0 || Lp < L || L < d.N || !d_init_state || !d_path || !d_orient || !d_vdes || !d_traj || !d_ctrl) {
+        h->err = "closed loop: B > 0, L >= N, Lp >= L and all of init_state, path, orient, vdes, traj, ctrl are required";
+        return MPC_ERR_INVALID;
+    }
+    if (!h->hp.bounds_set) { h->err = "mpc_set_bounds has not been called"; return MPC_ERR_STATE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_io(h, (size_t)B);
+    if (rc) return rc;
+    if (h->cap_state < (size_t)B) {
+        if (h->d_state) (void)hipFree(h->d_state);
+        h->d_state = nullptr;
+        HIP_TRY(h, hipMalloc(&h->d_state, (size_t)B * 5 * sizeof(double)));
+        h->cap_state = (size_t)B;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    LoopArgs A{};
+    A.B = B; A.N = d.N; A.L = L; A.Lp = Lp;
+    A.init_state = d_init_state; A.path = d_path; A.orient = d_orient; A.vdes = d_vdes;
+    A.state = h->d_state; A.x0 = h->d_x0; A.p = h->d_p; A.x_out = h->d_xout; A.status = h->d_status;
+    A.traj = d_traj; A.ctrl = d_ctrl; A.step_status = d_step_status;
+    Params P{};
+    P.dt = d.dt; P.wheelbase = d.wheelbase; P.nx = 5;
+    const dim3 grid((B + 127) / 128), block(128);
+    hipLaunchKernelGGL(k_loop_setup, grid, block, 0, stream, A);
+    for (int i = 0; i < L; ++i) {
+        rc = solve_dev(h, B, h->d_x0, h->d_p, nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, stream, nullptr, 0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_loop_advance, grid, block, 0, stream, P, A, i);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
+                          const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L <= 0 || Lp <= 0 || !init_state || !path || !orient || !vdes || !traj || !ctrl) { h->err = "closed loop: null or empty argument"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    double *di = nullptr, *dp = nullptr, *dor = nullptr, *dv = nullptr, *dt_ = nullptr, *dc = nullptr;
+    int32_t* ds = nullptr;
+    const size_t nB = (size_t)B;
+    auto cleanup = [&]() { (void)hipFree(di); (void)hipFree(dp); (void)hipFree(dor); (void)hipFree(dv); (void)hipFree(dt_); (void)hipFree(dc); (void)hipFree(ds); };
+    if (hipMalloc(&di, nB * 5 * 8) != hipSuccess || hipMalloc(&dp, nB * Lp * 2 * 8) != hipSuccess || hipMalloc(&dor, nB * Lp * 8) != hipSuccess ||
+        hipMalloc(&dv, nB * 8) != hipSuccess || hipMalloc(&dt_, nB * L * 5 * 8) != hipSuccess || hipMalloc(&dc, nB * L * 2 * 8) != hipSuccess ||
+        hipMalloc(&ds, nB * L * 4) != hipSuccess) {
+        cleanup();
+        h->err = "closed loop: out of device memory";
+        return MPC_ERR_HIP;
+    }
+    hipStream_t s = h->own_stream;
+    int rc = MPC_OK;
+    if (hipMemcpyAsync(di, init_state, nB * 5 * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(dp, path, nB * Lp * 2 * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(dor, orient, nB * Lp * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(dv, vdes, nB * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+        h->err = "closed loop: host to device copy failed";
+        rc = MPC_ERR_HIP;
+    }
+    if (!rc) rc = mpc_closed_loop_batch_dev(h, B, L, Lp, di, dp, dor, dv, dt_, dc, ds, (void*)s);
+    if (!rc) {
+        if (hipMemcpyAsync(traj, dt_, nB * L * 5 * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(ctrl, dc, nB * L * 2 * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            (step_status && hipMemcpyAsync(step_status, ds, nB * L * 4, hipMemcpyDeviceToHost, s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess) {
+            h->err = "closed loop: device to host copy failed";
+            rc = MPC_ERR_HIP;
+        }
+    }
+    cleanup();
+    return rc;
 }
 
 }  // extern "C"

@@ -231,9 +231,24 @@ class CasadiOptimizer(Optimizer):
         return self._sol, self._f
 
     # -- closed loop: optimizer.py:562-643 -----------------------------------------------------------------------
+    # set to False to run the step-by-step host loop below even when the backend has an on-device driver
+    use_device_loop = True
+
     def optimize(self):
         num_states, num_controls, N = 5, 2, self.predict_horizon
         lbg, ubg, lbx, ubx = self.inequal_constraints()
+        sol, _ = self.solver()
+        backend = getattr(sol, "_backend", None)
+        if self.use_device_loop and not self.configuration.noised and hasattr(backend, "closed_loop"):
+            # the whole loop of optimizer.py:596-631 on the device (mpc_closed_loop_batch): no host round trip per step
+            t_ = time.time()
+            backend.set_bounds(lbx, ubx, lbg, ubg)
+            init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation])
+            traj, ctrl, st = backend.closed_loop(init_state, self.resampled_path_points, self.orientation, self.desired_velocity,
+                                                 self.iter_length)
+            ok = bool(np.all(st == 1))
+            sol._stats = dict(status=st[0].copy(), success=ok, return_status="Solve_Succeeded" if ok else "Not_Converged")
+            return traj[0], ctrl[0], np.full(self.iter_length, (time.time() - t_) / self.iter_length)
         t0 = 0.0
         init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation]).reshape(-1, 1)
         current_state = init_state.copy()

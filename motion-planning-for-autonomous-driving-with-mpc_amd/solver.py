@@ -150,6 +150,26 @@ class BatchedMPCSolver:
                                              _abi.as_dp(out)))
         return out[0] if single else out
 
+    def closed_loop(self, init_state, path, orient, vdes, steps):
+        """B egos through `steps` receding-horizon steps on the device (include/mpcgpu.h: mpc_closed_loop_batch; the loop
+        body of CasadiOptimizer.optimize, optimizer.py:596-631).  init_state [B,5], path [B,Lp,2], orient [B,Lp],
+        vdes [B] -> (traj [B,steps,5], ctrl [B,steps,2], step_status [B,steps])."""
+        init_state = _abi.f64(init_state)
+        if init_state.ndim == 1:
+            init_state = init_state[None]
+        B = init_state.shape[0]
+        path = _abi.f64(path).reshape(B, -1, 2)
+        Lp = path.shape[1]
+        orient = _abi.f64(orient).reshape(B, Lp)
+        vdes = _abi.f64(np.broadcast_to(np.asarray(vdes, dtype=np.float64), (B,)))
+        steps = int(steps)
+        traj = np.empty((B, steps, 5))
+        ctrl = np.empty((B, steps, 2))
+        st = np.empty((B, steps), np.int32)
+        self._check(self._lib.mpc_closed_loop_batch(self._h, B, steps, Lp, _abi.as_dp(init_state), _abi.as_dp(path), _abi.as_dp(orient),
+                                                    _abi.as_dp(vdes), _abi.as_dp(traj), _abi.as_dp(ctrl), _abi.as_ip(st)))
+        return traj, ctrl, st
+
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
 

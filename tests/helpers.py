@@ -73,6 +73,9 @@ def emu_lib():
                                       C.c_int32, ip, C.c_int32]
         L.emu_solve_batch.restype = C.c_int
         L.emu_default_desc.argtypes = [C.POINTER(abi.MpcProblemDesc), C.c_int32, C.c_int32]
+        L.emu_closed_loop_piece.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp, ip]
+        L.emu_closed_loop_piece.restype = C.c_int
         _emu = L
     return _emu
 

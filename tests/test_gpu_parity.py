@@ -190,3 +190,36 @@ def test_casadi_optimizer_closed_loop_on_gpu():
     assert abs(us[0, 1] + np.sqrt(11.5)) < 1e-5
     assert np.abs(xs - xo).max() < 1e-6 and np.abs(us - uo).max() < 1e-6
     assert og.solver()[0].stats()["success"]
+
+
+def test_device_closed_loop_matches_host_loop():
+    """row f1: mpc_closed_loop_batch (all steps on the device) against the step-by-step host loop of the optimizer.py
+    mirror, both with GPU solves; plus a batch of shifted egos through the same driver."""
+    N, L = 10, 30
+    path, orient = straight_path(L, 29.9948, -1.1501, 0.03495, 20.0)
+    conf = make_configuration(path, orient, 20.0, WEIGHTS_YAML_ZAM_LF)
+    init_values = (np.array([29.9948, -1.1501]), 20.0, 0.0, 0.03495)
+    host = opt.CasadiOptimizer(configuration=conf, init_values=init_values, predict_horizon=N)
+    host.use_device_loop = False
+    hs, hc, _ = host.optimize()
+    dev = opt.CasadiOptimizer(configuration=conf, init_values=init_values, predict_horizon=N)
+    ds, dc, dt_ = dev.optimize()
+    assert ds.shape == (L, 5) and dc.shape == (L, 2) and dt_.shape == (L,)
+    assert np.abs(ds - hs).max() < 1e-7 and np.abs(dc - hc).max() < 1e-7
+    assert abs(dc[0, 1] + np.sqrt(11.5)) < 1e-5                      # step 0 brakes at the friction cap (SURVEY App. C-3)
+    # a batch of egos with lateral / speed offsets through the same path: all steps converge, all merge onto the path
+    sol, _ = dev.solver()
+    be = sol._backend
+    B = 96
+    rng = np.random.default_rng(3)
+    init = np.tile([29.9948, -1.1501, 0.0, 20.0, 0.03495], (B, 1))
+    init[:, 1] += rng.uniform(-0.5, 0.5, B)
+    init[:, 3] *= rng.uniform(0.9, 1.1, B)
+    traj, ctrl, st = be.closed_loop(init, np.tile(path, (B, 1, 1)), np.tile(orient, (B, 1)), np.full(B, 20.0), L)
+    assert np.all(st == 1)
+    lateral = (traj[:, -1, 1] - path[-1, 1]) * np.cos(0.03495) - (traj[:, -1, 0] - path[-1, 0]) * np.sin(0.03495)
+    assert np.abs(lateral).max() < 0.3
+    l = 2.5789128
+    x, u = traj[:, :-1], ctrl[:, :-1]
+    xn = x + 0.1 * np.stack([x[..., 3] * np.cos(x[..., 4]), x[..., 3] * np.sin(x[..., 4]), u[..., 0], u[..., 1], x[..., 3] / l * np.tan(x[..., 2])], -1)
+    assert np.abs(traj[:, 1:] - xn).max() < 1e-12

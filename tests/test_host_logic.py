@@ -133,3 +133,52 @@ def test_tighter_bounds_are_respected():
     assert np.all(r["status"] == 1)
     a = r["x"][:, 1:20:2]
     assert a.max() <= 0.5 + 1e-7 and a.min() >= -0.5 - 1e-7
+
+
+def test_closed_loop_driver_pieces_match_the_python_loop():
+    """mpc_closed_loop.h (the on-device driver: setup / advance per step) stepped on the CPU with oracle solves in
+    between must reproduce CasadiOptimizer.optimize()'s host loop -- warm-start layouts with their transposition
+    quirks, the reference window and its frozen tail, the Euler plant step."""
+    import ctypes as C
+    from helpers import emu_lib
+    N, L = 10, 30
+    o = make_casadi_optimizer(N=N, L=L)
+    o.use_device_loop = False
+    calls = []
+    be = o._sol._backend
+    orig_solve = be.solve
+
+    def spy(x0, p):
+        calls.append((np.array(x0, copy=True), np.array(p, copy=True)))
+        return orig_solve(x0, p)
+    be.solve = spy
+    states, controls, _ = o.optimize()
+
+    lib = emu_lib()
+    nw = 2 * N + 5 * (N + 1)
+    B = 2                                                   # two egos: the reference one and a laterally shifted copy
+    init = np.array([[29.9948, -1.1501, 0.0, 20.0, 0.03495], [29.9948, -0.9, 0.0, 19.0, 0.03495]])
+    path = np.stack([o.resampled_path_points, o.resampled_path_points])
+    orient = np.stack([o.orientation, o.orientation])
+    vdes = np.array([20.0, 20.0])
+    state, x0, p, xo = np.zeros((B, 5)), np.zeros((B, nw)), np.zeros((B, nw)), np.zeros((B, nw))
+    st = np.ones(B, np.int32)
+    traj, ctrl, sst = np.zeros((B, L, 5)), np.zeros((B, L, 2)), np.zeros((B, L), np.int32)
+
+    def piece(mode, i):
+        rc = lib.emu_closed_loop_piece(mode, i, C.c_double(0.1), C.c_double(2.5789128), B, N, L, L, abi.as_dp(init), abi.as_dp(path),
+                                       abi.as_dp(orient), abi.as_dp(vdes), abi.as_dp(state), abi.as_dp(x0), abi.as_dp(p), abi.as_dp(xo),
+                                       abi.as_ip(st), abi.as_dp(traj), abi.as_dp(ctrl), abi.as_ip(sst))
+        assert rc == 0
+    piece(0, 0)
+    for i in range(L):
+        # identical inputs to the solve as the Python loop built (bit for bit at step 0, to round-off afterwards)
+        assert np.allclose(x0[0], calls[i][0].ravel(), rtol=0, atol=1e-9), i
+        assert np.allclose(p[0], calls[i][1].ravel(), rtol=0, atol=1e-9), i
+        r = orig_solve(x0, p)
+        xo[:] = r.x
+        st[:] = r.status
+        piece(1, i)
+    assert np.allclose(traj[0], states, rtol=0, atol=1e-8) and np.allclose(ctrl[0], controls, rtol=0, atol=1e-8)
+    assert np.all(sst == 1)
+    assert np.abs(traj[1, -1, 1] - path[1, -1, 1]) < 0.3          # the shifted ego has merged onto the path
