@@ -63,6 +63,12 @@ constexpr double ROLLOUT_FACTOR = 10.0;   // start-point safeguard, see prestart
 constexpr double THETA_FLOOR = 1e-10;
 constexpr double EPS10 = 10.0 * 2.220446049250313e-16;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) const double* mpc_lds_cptr;
+#else
+typedef const double* mpc_lds_cptr;
+#endif
+
 // ---- per-instance scalar rows ----------------------------------------------------------------------------
 enum ScRow {
     SC_MU = 0, SC_TAU, SC_DF, SC_THETA, SC_FCOST, SC_LOGSUM, SC_THMAX, SC_THMIN, SC_DLAST, SC_DELTA, SC_E0,
@@ -290,11 +296,6 @@ MPC_HD double zreset(double z, double gap, double mu) {
 }
 
 // per-thread context kept in registers across the phases of the stage kernel
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) const double* mpc_lds_cptr;
-#else
-typedef const double* mpc_lds_cptr;
-#endif
 template <int NX>
 struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath (non-PF)
 
@@ -483,7 +484,17 @@ MPC_HD int prestart_a0(const Params& P, int b, double& a0lb, double& a0ub) {
 //   ROLLOUT = false: returns the dynamics defect of the caller's state guess
 // The loads of stage k+1 are issued before the arithmetic of stage k (the chain is otherwise load-latency bound).
 template <int NX, bool ROLLOUT>
-MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
+MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub, mpc_lds_cptr bnd) {
+    // bnd: LDS copy of the bounds table [LB | UB] on the device (a global load per stage would expose its latency in
+    // the dependent chain), nullptr on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PS_LB(q) bnd[(q)]
+#define PS_UB(q) bnd[(P.N + 1) * NZ + (q)]
+#else
+#define PS_LB(q) MPC_GP(P.LB, (q))
+#define PS_UB(q) MPC_GP(P.UB, (q))
+    (void)bnd;
+#endif
     constexpr int NZ = NX + 2;
     const int N = P.N;
     const uint32_t bb = (uint32_t)b;
@@ -492,7 +503,7 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const double r0 = PRX(0, i);
-        x[i] = push_in(ROLLOUT ? r0 : X0X(0, i), MPC_GP(P.LB, 2 + i), MPC_GP(P.UB, 2 + i));
+        x[i] = push_in(ROLLOUT ? r0 : X0X(0, i), PS_LB(2 + i), PS_UB(2 + i));
         th += fabs(x[i] - r0);
         if (ROLLOUT) MPC_U(P.ROLL, (uint32_t)i) = x[i];
         gnext[i] = ROLLOUT ? 0.0 : X0X(1, i);
@@ -500,8 +511,8 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
     un[0] = X0U(0, 0);
     un[1] = X0U(0, 1);
     for (int k = 0; k < N; ++k) {
-        u[0] = push_in(un[0], MPC_GP(P.LB, k * NZ), MPC_GP(P.UB, k * NZ));
-        u[1] = push_in(un[1], (k == 0) ? a0lb : MPC_GP(P.LB, k * NZ + 1), (k == 0) ? a0ub : MPC_GP(P.UB, k * NZ + 1));
+        u[0] = push_in(un[0], PS_LB(k * NZ), PS_UB(k * NZ));
+        u[1] = push_in(un[1], (k == 0) ? a0lb : PS_LB(k * NZ + 1), (k == 0) ? a0ub : PS_UB(k * NZ + 1));
         double graw[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) graw[i] = gnext[i];
@@ -516,7 +527,7 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
         ode_eval<NX>(P, x, u, f, s, c, td);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const double lb = MPC_GP(P.LB, (k + 1) * NZ + 2 + i), ub = MPC_GP(P.UB, (k + 1) * NZ + 2 + i);
+            const double lb = PS_LB((k + 1) * NZ + 2 + i), ub = PS_UB((k + 1) * NZ + 2 + i);
             const double raw = f[i] * P.dt + x[i];
             if (ROLLOUT) {
                 const double rn = push_in(raw, lb, ub);
@@ -531,6 +542,8 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub) {
         }
     }
     return th;
+#undef PS_LB
+#undef PS_UB
 }
 template <int NX>
 MPC_HD void prestart_decide(const Params& P, int b, int frow, double a0lb, double a0ub, double th_g, double th_r) {
@@ -546,8 +559,8 @@ MPC_HD void prestart_instance(const Params& P, int b) {
     // the caller's rows were transposed into the workspace by the ingest kernel: Z holds the raw x0, REF holds X_ref
     double a0lb, a0ub;
     const int frow = prestart_a0<NX>(P, b, a0lb, a0ub);
-    const double th_r = prestart_chain<NX, true>(P, b, a0lb, a0ub);
-    const double th_g = prestart_chain<NX, false>(P, b, a0lb, a0ub);
+    const double th_r = prestart_chain<NX, true>(P, b, a0lb, a0ub, nullptr);
+    const double th_g = prestart_chain<NX, false>(P, b, a0lb, a0ub, nullptr);
     prestart_decide<NX>(P, b, frow, a0lb, a0ub, th_g, th_r);
 }
 #undef X0U

@@ -489,13 +489,18 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
 template <int NX>
 __global__ void __launch_bounds__(128) k_prestart(const Params P) {
     __shared__ double th_guess[64];
+    extern __shared__ __attribute__((aligned(16))) double bnd_tab[];            // [LB | UB], (N+1)*NZ doubles each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = (P.N + 1) * (NX + 2);
+    for (int q = threadIdx.x; q < nb; q += 128) { bnd_tab[q] = MPC_GP(P.LB, q); bnd_tab[nb + q] = MPC_GP(P.UB, q); }
+    __syncthreads();
+    const mpc_lds_cptr bnd = (mpc_lds_cptr)(lds_ptr_t)bnd_tab;
     const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + lane;
     double a0lb = 0.0, a0ub = 0.0, th = 0.0;
     int frow = 1;
     if (b < P.B) {
         frow = prestart_a0<NX>(P, b, a0lb, a0ub);
-        th = (wave == 0) ? prestart_chain<NX, true>(P, b, a0lb, a0ub) : prestart_chain<NX, false>(P, b, a0lb, a0ub);
+        th = (wave == 0) ? prestart_chain<NX, true>(P, b, a0lb, a0ub, bnd) : prestart_chain<NX, false>(P, b, a0lb, a0ub, bnd);
     }
     if (wave == 1) th_guess[lane] = th;
     __syncthreads();
@@ -948,7 +953,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         prof.begin(2, q.st);
         const int n_w = 2 * d.N + NX * (d.N + 1);
         hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
-        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), 0, q.st, Pg);
+        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
         launch_stage(q, true);
         prof.end(q.st);
     }
