@@ -119,6 +119,16 @@ int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x
  * (solver status of every step; the reference ignores it).  No noise (`noised: False`).                           */
 int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
                           const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status);
+/* Post-hoc trajectory metrics (scope row f4) for B planned trajectories traj [B,L,5] (host buffers, any output may be NULL):
+ *   deviation [B,L]  distance to the nearest point of origin_path [B,Lo,2]   (plot_deviation_euclidean_dis,
+ *                    mpc_planner.py:184-199; find_closest_point, configuration.py:26-37)
+ *   rmsd [B,2]       sqrt(sum_i (ref_path[i] - x[i])^2 / (L-1)) of x and y   (compute_rmsd, mpc_planner.py:279-292)
+ *   clearance [B]    min over steps and circle pairs of distance - r_sum; all_pairs = 0: the three pairs (ego circle j,
+ *                    obstacle circle j) that optimizer.py:395-403 constrains (each three times), all_pairs = 1: all nine
+ *                    pairs; circle centres of the handle's problem template                                          */
+int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* traj, const double* ref_path,
+                      const double* origin_path, double r_sum, int32_t all_pairs, double* deviation, double* rmsd,
+                      double* clearance);
 int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
                               const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl,
                               int32_t* d_step_status, void* stream);

@@ -606,6 +606,73 @@ __global__ void k_gather_trace(const double* SC /*rows of tile 0*/, uint32_t til
     for (int q = 0; q < 8; ++q) out[(size_t)q * B + b] = SC[((uint32_t)b >> 6) * tile_elems + (uint32_t)rows[q] * 64u + ((uint32_t)b & 63u)];
 }
 
+// correctly rounded square root: the library sqrt is within 1 ulp; one residual correction r += (x - r*r) / (2r) with a
+// fused residual makes it match the IEEE result numpy produces
+__device__ __forceinline__ double sqrt_cr(double x) {
+    const double r = sqrt(x);
+    if (!(r > 0.0) || !isfinite(r)) return r;
+    return fma(fma(-r, r, x), 0.5 / r, r);
+}
+
+// post-hoc trajectory metrics (row f4; mpc_planner.py:184-199, 279-292, configuration.py:26-37): one workgroup per ego.
+// Every operation is a separately rounded IEEE operation (fp contraction off: no fused multiply-add), in the
+// reference's order, so the results are bit-identical to the numpy expressions.
+__global__ void __launch_bounds__(256) k_metrics(int L, int Lo, const double* traj, const double* ref_path, const double* origin_path,
+                                                 const double* obst, double ego_offset, double r_sum, int all_pairs, double* deviation,
+                                                 double* rmsd, double* clearance) {
+#pragma clang fp contract(off)         // plain operators below, each rounded separately (HIP's rn-intrinsics are plain operators that get fused after inlining)
+    __shared__ double red[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double* x = traj + (size_t)b * L * 5;
+    if (deviation != nullptr && origin_path != nullptr) {
+        const double* op = origin_path + (size_t)b * Lo * 2;
+        for (int i = t; i < L; i += 256) {
+            const double px = x[i * 5], py = x[i * 5 + 1];
+            double best = INFINITY;
+            int arg = 0;
+            for (int q = 0; q < Lo; ++q) {                       // np.argmin: first index of the minimum
+                const double dx = op[2 * q] - px, dy = op[2 * q + 1] - py;
+                const double sq = dx * dx + dy * dy;
+                if (sq < best) { best = sq; arg = q; }
+            }
+            const double ex = op[2 * arg] - px, ey = op[2 * arg + 1] - py;
+            deviation[(size_t)b * L + i] = sqrt_cr(ex * ex + ey * ey);
+        }
+    }
+    if (rmsd != nullptr && ref_path != nullptr && t == 0) {       // sequential sums in the reference's order
+        const double* rp = ref_path + (size_t)b * L * 2;
+        double sx = 0.0, sy = 0.0;
+        for (int i = 0; i < L; ++i) {
+            const double dx = rp[2 * i] - x[i * 5], dy = rp[2 * i + 1] - x[i * 5 + 1];
+            sx = sx + dx * dx;
+            sy = sy + dy * dy;
+        }
+        rmsd[(size_t)b * 2] = sqrt_cr(sx / (double)(L - 1));
+        rmsd[(size_t)b * 2 + 1] = sqrt_cr(sy / (double)(L - 1));
+    }
+    if (clearance != nullptr) {
+        double best = INFINITY;
+        for (int i = t; i < L; i += 256) {
+            const double sx = x[i * 5], sy = x[i * 5 + 1], psi = x[i * 5 + 4];
+            double sn, cs;
+            sincos(psi, &sn, &cs);
+            for (int e = 0; e < 3; ++e) {
+                const double sg = (e == 0) ? 0.0 : (e == 1 ? 1.0 : -1.0);
+                const double ex = sx + sg * ego_offset * cs, ey = sy + sg * ego_offset * sn;
+                for (int j = 0; j < 3; ++j) {
+                    if (!all_pairs && j != e) continue;           // the NLP constrains circle e against circle e only (optimizer.py:395-403)
+                    const double dx = ex - obst[2 * j], dy = ey - obst[2 * j + 1];
+                    best = fmin(best, sqrt(dx * dx + dy * dy) - r_sum);
+                }
+            }
+        }
+        red[t] = best;
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) { if (t < m) red[t] = fmin(red[t], red[t + m]); __syncthreads(); }
+        if (t == 0) clearance[b] = red[0];
+    }
+}
+
 // closed-loop driver around the solve (row f1): one instance per thread, row-major buffers
 __global__ void k_loop_setup(const LoopArgs A) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1267,6 +1334,36 @@ int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const
     }
     cleanup();
     return rc;
+}
+
+int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* traj, const double* ref_path, const double* origin_path,
+                      double r_sum, int32_t all_pairs, double* deviation, double* rmsd, double* clearance) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L < 2 || !traj || (deviation && (!origin_path || Lo <= 0))) { h->err = "metrics: B > 0, L >= 2, traj (and origin_path with deviation) are required"; return MPC_ERR_INVALID; }
+    if (rmsd && !ref_path) { h->err = "metrics: rmsd needs ref_path"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nB = (size_t)B;
+    double *dt_ = nullptr, *dr = nullptr, *dorig = nullptr, *dob = nullptr, *ddev = nullptr, *drm = nullptr, *dcl = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dt_); (void)hipFree(dr); (void)hipFree(dorig); (void)hipFree(dob); (void)hipFree(ddev); (void)hipFree(drm); (void)hipFree(dcl); };
+    hipStream_t s = h->own_stream;
+    bool ok = hipMalloc(&dt_, nB * L * 5 * 8) == hipSuccess && hipMalloc(&dob, 6 * 8) == hipSuccess &&
+              hipMemcpyAsync(dt_, traj, nB * L * 5 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dob, h->hp.desc.obstacle, 6 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok && rmsd) ok = hipMalloc(&dr, nB * L * 2 * 8) == hipSuccess && hipMalloc(&drm, nB * 2 * 8) == hipSuccess &&
+                         hipMemcpyAsync(dr, ref_path, nB * L * 2 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok && deviation) ok = hipMalloc(&dorig, nB * Lo * 2 * 8) == hipSuccess && hipMalloc(&ddev, nB * L * 8) == hipSuccess &&
+                              hipMemcpyAsync(dorig, origin_path, nB * Lo * 2 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok && clearance) ok = hipMalloc(&dcl, nB * 8) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_metrics, dim3(B), dim3(256), 0, s, L, Lo, dt_, dr, dorig, dob, h->hp.desc.ego_offset, r_sum, (int)all_pairs, ddev, drm, dcl);
+        if (deviation) ok = ok && hipMemcpyAsync(deviation, ddev, nB * L * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (rmsd) ok = ok && hipMemcpyAsync(rmsd, drm, nB * 2 * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (clearance) ok = ok && hipMemcpyAsync(clearance, dcl, nB * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    }
+    cleanup();
+    if (!ok) { h->err = "metrics: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
+    return MPC_OK;
 }
 
 }  // extern "C"

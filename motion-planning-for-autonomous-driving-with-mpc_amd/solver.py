@@ -170,6 +170,29 @@ class BatchedMPCSolver:
                                                     _abi.as_dp(vdes), _abi.as_dp(traj), _abi.as_dp(ctrl), _abi.as_ip(st)))
         return traj, ctrl, st
 
+    def metrics(self, traj, ref_path=None, origin_path=None, r_sum=None, all_pairs=False):
+        """Post-hoc metrics of B planned trajectories [B,L,5] on the device (mpc_metrics_batch; mpc_planner.py:184-199,
+        279-292): dict(deviation [B,L] | None, rmsd [B,2] | None, clearance [B] | None)."""
+        traj = _abi.f64(traj)
+        if traj.ndim == 2:
+            traj = traj[None]
+        B, L = traj.shape[0], traj.shape[1]
+        dev = rm = cl = None
+        Lo = 0
+        if origin_path is not None:
+            origin_path = _abi.f64(np.broadcast_to(np.asarray(origin_path, dtype=np.float64), (B,) + np.asarray(origin_path).shape[-2:]))
+            Lo = origin_path.shape[1]
+            dev = np.empty((B, L))
+        if ref_path is not None:
+            ref_path = _abi.f64(np.broadcast_to(np.asarray(ref_path, dtype=np.float64)[..., :L, :], (B, L, 2)))
+            rm = np.empty((B, 2))
+        if r_sum is not None:
+            cl = np.empty(B)
+        self._check(self._lib.mpc_metrics_batch(self._h, B, L, Lo, _abi.as_dp(traj), _abi.as_dp(ref_path), _abi.as_dp(origin_path),
+                                                C.c_double(0.0 if r_sum is None else float(r_sum)), 1 if all_pairs else 0, _abi.as_dp(dev), _abi.as_dp(rm),
+                                                _abi.as_dp(cl)))
+        return dict(deviation=dev, rmsd=rm, clearance=cl)
+
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
 
