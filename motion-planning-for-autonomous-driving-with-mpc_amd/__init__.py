@@ -5,6 +5,8 @@ TGoldC/Motion-Planning-for-Autonomous-Driving-with-MPC (MPC_Planner/optimizer.py
   solver.BatchedMPCSolver ....... owner of the C-ABI handle (include/mpcgpu.h -> csrc/libmpcgpu.so, HIP/gfx950)
   optimizer.CasadiOptimizer ..... look-alike of the reference class (constructor, solver(), optimize())
   optimizer.ForcesproOptimizer .. call-surface twin (solver.solve(problem))
+  metrics ....................... deviation / RMSD / circle clearance of planned trajectories (mpc_planner.py:184-199, 279-292)
+  scenario ...................... CommonRoad XML + settings -> planning configuration (configuration.py:400-623) on numpy
 
 The directory name contains hyphens (it is fixed by the build contract); import it with
 `importlib.import_module("motion-planning-for-autonomous-driving-with-mpc_amd")` or through the `mpc_amd` shim
@@ -12,5 +14,5 @@ at the repository root.
 """
 from ._abi import MpcLibraryError, load_library  # noqa: F401
 from .solver import BatchedMPCSolver, MpcError, SolveResult  # noqa: F401
-from . import optimizer, sharding  # noqa: E402,F401
+from . import metrics, optimizer, scenario, sharding  # noqa: E402,F401
 from .optimizer import CasadiOptimizer, ForcesproOptimizer  # noqa: E402,F401
