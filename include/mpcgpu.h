@@ -119,6 +119,16 @@ int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x
  * (solver status of every step; the reference ignores it).  No noise (`noised: False`).                           */
 int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
                           const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status);
+/* FORCES-mode stage functions (scope row a11): what `FORCESNLPsolver_casadi2forces` evaluates per stage
+ * (test/FORCESNLPsolver/FORCESNLPsolver_interface.c:41-198 -> casadi_f0..f9, FORCESNLPsolver_model.c:75-1756; the model
+ * of ForcesproOptimizer, optimizer.py:91-245) for B independent (z, p) pairs.  z [B,7] = (deltaDot, aLong, x, y, delta, v,
+ * psi), p [B,10] = (x_ref, y_ref, v_des, psi_ref, obstacle centre / front / rear circle).  Outputs, row-major, any may be
+ * NULL: f [B], grad_f [B,7], c [B,5] (one RK4 step of length dt), jac_c [B,5,7], h [B,10] (friction circle, nine squared
+ * circle distances), jac_h [B,10,7].  terminal != 0: the last stage (terminal weights P, no input cost, no c).
+ * Weights: Q / R / P of the handle's descriptor; dt, wheelbase (ODE), friction_div (2.578 in psi_dot), ego_offset too. */
+int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const double* z, const double* p, double* f,
+                          double* grad_f, double* c, double* jac_c, double* hval, double* jac_h);
+
 /* Post-hoc trajectory metrics (scope row f4) for B planned trajectories traj [B,L,5] (host buffers, any output may be NULL):
  *   deviation [B,L]  distance to the nearest point of origin_path [B,Lo,2]   (plot_deviation_euclidean_dis,
  *                    mpc_planner.py:184-199; find_closest_point, configuration.py:26-37)

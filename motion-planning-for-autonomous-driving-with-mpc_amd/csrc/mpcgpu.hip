@@ -673,6 +673,140 @@ __global__ void __launch_bounds__(256) k_metrics(int L, int Lo, const double* tr
     }
 }
 
+// FORCES-mode stage functions (row a11; FORCESNLPsolver_interface.c:41-198 / FORCESNLPsolver_model.c:75-1756, the model of
+// optimizer.py:91-245): per instance  z = [deltaDot, aLong, x, y, delta, v, psi],  p = [x_ref, y_ref, v_des, psi_ref, 3 obstacle
+// circle centres]  ->  stage cost f and gradient (7), one RK4 step c (5) with Jacobian (5x7, forward sensitivities through
+// the four stages), inequality functions h (10: friction circle, 9 squared circle distances) with Jacobian (10x7).
+// One thread per instance; row-major outputs.
+struct ForcesArgs {
+    int32_t B, terminal;
+    double dt, l, wb, rho, Q[5], R[2], Pt[5];
+    const double *z, *p;
+    double *f, *grad_f, *c, *jac_c, *h, *jac_h;
+};
+__device__ __forceinline__ void forces_ode(const double* x, const double* u, double l, double* f, double* F /*[4]: (0,3),(0,4),(1,3),(1,4)*/, double& F42, double& F43) {
+    double sn, cs;
+    sincos(x[4], &sn, &cs);
+    const double td = tan(x[2]);
+    f[0] = x[3] * cs; f[1] = x[3] * sn; f[2] = u[0]; f[3] = u[1]; f[4] = x[3] / l * td;
+    F[0] = cs; F[1] = -x[3] * sn; F[2] = sn; F[3] = x[3] * cs;
+    F42 = x[3] / l * (1.0 + td * td);
+    F43 = td / l;
+}
+__global__ void __launch_bounds__(128) k_forces_stage(const ForcesArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.B) return;
+    double z[7], p[10];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) z[i] = A.z[(size_t)b * 7 + i];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) p[i] = A.p[(size_t)b * 10 + i];
+    // ---- cost (optimizer.py:158-194)
+    const double* w = A.terminal ? A.Pt : A.Q;
+    const double r[5] = {z[2] - p[0], z[3] - p[1], z[4], z[5] - p[2], z[6] - p[3]};
+    double f = 0.0, gf[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { f += w[i] * r[i] * r[i]; gf[2 + i] = 2.0 * w[i] * r[i]; }
+    if (!A.terminal) {
+        f += A.R[0] * z[0] * z[0] + A.R[1] * z[1] * z[1];
+        gf[0] = 2.0 * A.R[0] * z[0];
+        gf[1] = 2.0 * A.R[1] * z[1];
+    }
+    if (A.f) A.f[b] = f;
+    if (A.grad_f) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) A.grad_f[(size_t)b * 7 + i] = gf[i];
+    }
+    // ---- RK4 step and its Jacobian (optimizer.py:91-98): tangents T = d(.)/dz, 5 x 7
+    if (!A.terminal && (A.c || A.jac_c)) {
+        const double* u = z;
+        const double* x = z + 2;
+        double xs[5], k[5], acc[5], dk[5][7], dacc[5][7], dxs[5][7];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            xs[i] = x[i];
+            acc[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { dxs[i][j] = (j == i + 2) ? 1.0 : 0.0; dacc[i][j] = 0.0; dk[i][j] = 0.0; }
+        }
+        const double aw[4] = {0.0, 0.5, 0.5, 1.0}, bw[4] = {1.0, 2.0, 2.0, 1.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s > 0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    xs[i] = x[i] + aw[s] * A.dt * k[i];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) dxs[i][j] = ((j == i + 2) ? 1.0 : 0.0) + aw[s] * A.dt * dk[i][j];
+                }
+            }
+            double F[4], F42, F43;
+            forces_ode(xs, u, A.l, k, F, F42, F43);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                dk[0][j] = F[0] * dxs[3][j] + F[1] * dxs[4][j];
+                dk[1][j] = F[2] * dxs[3][j] + F[3] * dxs[4][j];
+                dk[2][j] = (j == 0) ? 1.0 : 0.0;
+                dk[3][j] = (j == 1) ? 1.0 : 0.0;
+                dk[4][j] = F42 * dxs[2][j] + F43 * dxs[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                acc[i] += bw[s] * k[i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) dacc[i][j] += bw[s] * dk[i][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (A.c) A.c[(size_t)b * 5 + i] = x[i] + A.dt / 6.0 * acc[i];
+            if (A.jac_c) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) A.jac_c[((size_t)b * 5 + i) * 7 + j] = ((j == i + 2) ? 1.0 : 0.0) + A.dt / 6.0 * dacc[i][j];
+            }
+        }
+    }
+    // ---- inequalities (optimizer.py:121-149)
+    if (A.h || A.jac_h) {
+        double h[10], jh[10][7];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) jh[i][j] = 0.0;
+        }
+        const double td = tan(z[4]);
+        const double q = z[5] * z[5] * td / A.wb;                 // v * psi_dot
+        h[0] = z[1] * z[1] + q * q;
+        jh[0][1] = 2.0 * z[1];
+        jh[0][4] = 2.0 * q * z[5] * z[5] * (1.0 + td * td) / A.wb;
+        jh[0][5] = 2.0 * q * 2.0 * z[5] * td / A.wb;
+        double sn, cs;
+        sincos(z[6], &sn, &cs);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double sg = (e == 0) ? 0.0 : (e == 1 ? 1.0 : -1.0);
+            const double ex = z[2] + sg * A.rho * cs, ey = z[3] + sg * A.rho * sn;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double dx = ex - p[4 + 2 * j], dy = ey - p[5 + 2 * j];
+                const int row = 1 + 3 * e + j;
+                h[row] = dx * dx + dy * dy;
+                jh[row][2] = 2.0 * dx;
+                jh[row][3] = 2.0 * dy;
+                jh[row][6] = 2.0 * dx * (-sg * A.rho * sn) + 2.0 * dy * (sg * A.rho * cs);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if (A.h) A.h[(size_t)b * 10 + i] = h[i];
+            if (A.jac_h) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) A.jac_h[((size_t)b * 10 + i) * 7 + j] = jh[i][j];
+            }
+        }
+    }
+}
+
 // closed-loop driver around the solve (row f1): one instance per thread, row-major buffers
 __global__ void k_loop_setup(const LoopArgs A) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1363,6 +1497,38 @@ int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const dou
     }
     cleanup();
     if (!ok) { h->err = "metrics: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
+    return MPC_OK;
+}
+
+int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const double* z, const double* p, double* f, double* grad_f,
+                          double* c, double* jac_c, double* hval, double* jac_h) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !z || !p) { h->err = "forces stage eval: B > 0, z and p are required"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const mpc_problem_desc& d = h->hp.desc;
+    const size_t nB = (size_t)B;
+    const size_t sz[8] = {nB * 7, nB * 10, nB, nB * 7, nB * 5, nB * 35, nB * 10, nB * 70};
+    double* host[8] = {const_cast<double*>(z), const_cast<double*>(p), f, grad_f, terminal ? nullptr : c, terminal ? nullptr : jac_c, hval, jac_h};
+    double* dev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t s = h->own_stream;
+    bool ok = true;
+    for (int i = 0; i < 8 && ok; ++i)
+        if (host[i]) ok = hipMalloc(&dev[i], sz[i] * sizeof(double)) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipMemcpyAsync(dev[i], host[i], sz[i] * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        ForcesArgs A{};
+        A.B = B; A.terminal = terminal ? 1 : 0;
+        A.dt = d.dt; A.l = d.wheelbase; A.wb = d.friction_div; A.rho = d.ego_offset;
+        for (int i = 0; i < 5; ++i) { A.Q[i] = d.Q[i]; A.Pt[i] = d.P[i]; }
+        A.R[0] = d.R[0]; A.R[1] = d.R[1];
+        A.z = dev[0]; A.p = dev[1]; A.f = dev[2]; A.grad_f = dev[3]; A.c = dev[4]; A.jac_c = dev[5]; A.h = dev[6]; A.jac_h = dev[7];
+        hipLaunchKernelGGL(k_forces_stage, dim3((B + 127) / 128), dim3(128), 0, s, A);
+        for (int i = 2; i < 8 && ok; ++i)
+            if (host[i]) ok = hipMemcpyAsync(host[i], dev[i], sz[i] * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    }
+    for (int i = 0; i < 8; ++i) (void)hipFree(dev[i]);
+    if (!ok) { h->err = "forces stage eval: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
     return MPC_OK;
 }
 

@@ -193,6 +193,19 @@ class BatchedMPCSolver:
                                                 _abi.as_dp(cl)))
         return dict(deviation=dev, rmsd=rm, clearance=cl)
 
+    def forces_stage_eval(self, z, p, terminal=False):
+        """FORCES-mode stage functions of B (z, p) pairs on the device (mpc_forces_stage_eval; the generated
+        FORCESNLPsolver_model.c of the reference): dict(f, grad_f, c, jac_c, h, jac_h); c / jac_c are None at the last stage."""
+        z = _abi.f64(z).reshape(-1, 7)
+        p = _abi.f64(p).reshape(-1, 10)
+        B = z.shape[0]
+        f, gf = np.empty(B), np.empty((B, 7))
+        c, jc = (None, None) if terminal else (np.empty((B, 5)), np.empty((B, 5, 7)))
+        hv, jh = np.empty((B, 10)), np.empty((B, 10, 7))
+        self._check(self._lib.mpc_forces_stage_eval(self._h, B, 1 if terminal else 0, _abi.as_dp(z), _abi.as_dp(p), _abi.as_dp(f),
+                                                    _abi.as_dp(gf), _abi.as_dp(c), _abi.as_dp(jc), _abi.as_dp(hv), _abi.as_dp(jh)))
+        return dict(f=f, grad_f=gf, c=c, jac_c=jc, h=hv, jac_h=jh)
+
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
 
