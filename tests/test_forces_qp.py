@@ -1,0 +1,93 @@
+"""Row f3: the FORCES-mode SQP step (one stage-structured QP per call).
+CPU: the numpy oracle (dense KKT) against scipy on the same QP; the kernels' stage-wise (Riccati) solver, stepped by the
+emulation harness, against the oracle.  GPU: mpc_forces_solve_batch against the oracle, and the ForcesproOptimizer call
+surface end to end."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import WEIGHTS_YAML_ZAM_LF, abi, emu_lib, make_configuration, pkg, straight_path
+from oracle import forces_model_numpy as FM
+from oracle import forces_qp_numpy as Q
+
+N = 10
+LB = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])           # optimizer.py:100-110
+UB = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
+HL = np.concatenate(([0.0], np.full(9, 3.3 ** 2)))
+HU = np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
+OBST = [59.948, 0.08323, 60.945, 0.16074, 58.951, 0.00572]                      # ZAM_Over-1_1 obstacle circles
+
+
+def family(B, seed=0, obstacle_every=2):
+    rng = np.random.default_rng(seed)
+    zbar, params, xinit = np.zeros((B, N, 7)), np.zeros((B, N, 10)), np.zeros((B, 5))
+    for b in range(B):
+        zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 20.0, 0.03495])
+        zi[3] += rng.uniform(-0.5, 0.5)
+        zi[5] *= rng.uniform(0.8, 0.98)
+        zbar[b] = np.tile(zi, (N, 1))
+        xinit[b] = zi[2:]
+        k = np.arange(1, N + 1)
+        path = np.stack([zi[2] + k * 2 * np.cos(0.03495), -1.1501 + k * 2 * np.sin(0.03495)], 1)
+        ob = OBST if (obstacle_every and b % obstacle_every) else [-100.0, 0, -100, 0, -100, 0]
+        params[b] = np.hstack([path, np.full((N, 1), 20.0), np.full((N, 1), 0.03495), np.tile(ob, (N, 1))])
+    return zbar, params, xinit
+
+
+def emu_forces(zbar, params, xinit, w=FM.WEIGHTS_MODEL_C):
+    B = zbar.shape[0]
+    big = lambda a: np.where(np.isfinite(a), a, np.sign(a) * 1e308)             # noqa: E731
+    zo, it, st, kk = np.zeros_like(zbar), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+    dp = abi.as_dp
+    rc = emu_lib().emu_forces_solve(B, N, C.c_double(0.1), C.c_double(FM.WHEELBASE_ODE), C.c_double(2.578), C.c_double(0.75),
+                                    dp(np.array(w["Q"], float)), dp(np.array(w["R"], float)), dp(np.array(w["P"], float)),
+                                    dp(big(LB)), dp(big(UB)), dp(big(HL)), dp(big(HU)), dp(zbar), dp(params), dp(xinit), dp(zo),
+                                    abi.as_ip(it), abi.as_ip(st), dp(kk))
+    assert rc == 0
+    return zo, it, st, kk
+
+
+def test_oracle_qp_against_scipy():
+    from scipy.optimize import minimize
+    zbar, params, xinit = family(4, seed=1)
+    for b in (0, 1):
+        st = Q.build_qp(zbar[b], params[b], xinit[b], LB, UB, HL, HU)
+        dz, it, conv, kkt = Q.solve_qp(st, zbar[b], xinit[b])
+        assert conv and it < 20
+        g = np.concatenate([s["g"] for s in st])
+        cons = [dict(type="eq", fun=lambda x, b=b: x.reshape(N, 7)[0, 2:] - (xinit[b] - zbar[b, 0, 2:]))]
+        for k in range(N - 1):
+            cons.append(dict(type="eq", fun=lambda x, k=k, b=b: x.reshape(N, 7)[k + 1, 2:] - (st[k]["C"] @ x.reshape(N, 7)[k] + st[k]["c"] - zbar[b, k + 1, 2:])))
+        for k in range(N):
+            cons.append(dict(type="ineq", fun=lambda x, k=k: st[k]["d"] - st[k]["G"] @ x.reshape(N, 7)[k]))
+        r = minimize(lambda x: g @ x + 0.5 * Q.H_DIAG * x @ x, dz.ravel() * 0.0, jac=lambda x: g + Q.H_DIAG * x, constraints=cons,
+                     method="SLSQP", options=dict(ftol=1e-10, maxiter=300))
+        assert r.status in (0, 9)                                                # 9: iteration limit, still a feasible descent sequence
+        f_ipm = g @ dz.ravel() + 0.5 * Q.H_DIAG * dz.ravel() @ dz.ravel()
+        assert abs(f_ipm - r.fun) < 1e-5 * max(1.0, abs(r.fun))                  # same optimal value (strictly convex: same point)
+        assert np.abs(r.x.reshape(N, 7) - dz).max() < 5e-3
+
+
+def test_stagewise_solver_matches_dense_oracle():
+    zbar, params, xinit = family(24, seed=2)
+    zo, it, st, kk = emu_forces(zbar, params, xinit)
+    n_ok = 0
+    for b in range(zbar.shape[0]):
+        zp, ito, conv, kkt = Q.sqp_step(zbar[b], params[b], xinit[b], LB, UB, HL, HU)
+        assert (st[b] == 1) == conv
+        if conv:
+            n_ok += 1
+            assert it[b] == ito
+            assert np.abs(zp - zo[b]).max() < 1e-7
+            assert np.allclose(zo[b, 0, 2:], xinit[b], rtol=0, atol=1e-4)       # initial condition (to the residual tolerance)
+            assert zo[b, :, 0].min() > -0.4 - 1e-6 and zo[b, :, 1].max() < 11.5 + 1e-6
+    assert n_ok >= 20
+    # inconsistent linearised constraints (the obstacle constraint linearised 15 m away caps the travel below what the
+    # brakes allow) are reported, not hidden
+    zb, pr, xi = family(2, seed=3)
+    pr[:, :, 4:] = OBST
+    xi[:, 3] = 21.5                                                              # 30 m before the obstacle at 21.5 m/s:
+    zb[:, :, 5] = 21.5                                                           # linearised there, it allows 14.8 m of travel
+    _, _, st2, _ = emu_forces(zb, pr, xi)
+    assert np.all(st2 != 1)
