@@ -129,6 +129,20 @@ int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const
 int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const double* z, const double* p, double* f,
                           double* grad_f, double* c, double* jac_c, double* hval, double* jac_h);
 
+/* FORCES-mode solve (scope row f3): `output, exitflag, info = solver.solve(problem)` of ForcesproOptimizer
+ * (optimizer.py:326; C side FORCESNLPsolver_solve, test/FORCESNLPsolver/include/FORCESNLPsolver.h:117-219) for B independent
+ * problems: ONE step of sequential quadratic programming from the guess x0, as the reference configures FORCESPRO
+ * (sqp_nlp.maxqps = 1, BFGS initialised to 2.5 I, reg_hessian 5e-6; optimizer.py:225-240).  Horizon N = the descriptor's
+ * N, weights Q / R / P of the descriptor.  x0 [B,N,7] = problem["x0"], xinit [B,5], all_parameters [B,N,10] (optimizer.py:
+ * 124-127, 313-318); lb/ub [7], hl/hu [10] = inequal_constraint() (optimizer.py:100-119; +-inf or |v| >= 1e300 = absent).
+ * hessian_mode 0: QP Hessian = exact Hessian of the least-squares cost (Gauss-Newton SQP, default); 1: the literal
+ * `bfgs_init = 2.5 I` (see csrc/mpc_forces_qp.h: forces_hessian_diag for why that is not the default).
+ * Outputs: x_out [B,N,7] = output["x01".."xN"]; exitflag [B] (1 solved, 0 iteration limit, -6 NaN, -7 inconsistent
+ * linearised constraints; FORCESNLPsolver.h:68-106); it [B] interior-point iterations; res [B] final residual.          */
+int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* xinit, const double* all_parameters,
+                           const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
+                           double* x_out, int32_t* exitflag, int32_t* it, double* res);
+
 /* Post-hoc trajectory metrics (scope row f4) for B planned trajectories traj [B,L,5] (host buffers, any output may be NULL):
  *   deviation [B,L]  distance to the nearest point of origin_path [B,Lo,2]   (plot_deviation_euclidean_dis,
  *                    mpc_planner.py:184-199; find_closest_point, configuration.py:26-37)

@@ -6,7 +6,7 @@
 // point method (Mehrotra predictor-corrector) whose Newton systems are eliminated stage by stage (Riccati recursion with
 // the dense RK4 sensitivities A_k (5x5), B_k (5x2)):
 //
-//    min_dz  sum_k grad f_k(zbar_k)' dz_k + 1/2 (2.5 + 5e-6) |dz_k|^2
+//    min_dz  sum_k grad f_k(zbar_k)' dz_k + 1/2 dz_k' H_k dz_k        (H_k diagonal: forces_hessian_diag)
 //    s.t.    x_1 = xinit,   x_{k+1} = c(zbar_k) + C_k dz_k,   lb <= zbar + dz <= ub,   hl <= h(zbar_k) + J_k dz_k <= hu
 //
 // (z = [deltaDot, aLong, x, y, delta, v, psi]; stage functions: forces_stage_functions below = FORCESNLPsolver_model.c, row a11.)
@@ -22,7 +22,8 @@ namespace mpc {
 
 struct ForcesQpArgs {
     int32_t B, Bp, N, max_it;
-    double dt, l, wb, rho, hdiag, tol, tol_mu;      // converged: residuals <= tol and complementarity gap <= tol_mu
+    double dt, l, wb, rho, tol, tol_mu;             // converged: residuals <= tol and complementarity gap <= tol_mu
+    double hd[7], hdN[7];                           // diagonal QP Hessian of a stage / of the last stage (see forces_hessian_diag)
     double Q[5], R[2], Pt[5];
     double lb[7], ub[7], hl[10], hu[10];          // +-1e300 and beyond = absent
     const double* zbar;                           // [B, N, 7]  problem["x0"]
@@ -59,6 +60,21 @@ enum FqpRow {
     FQ_ROWS = FQ_DPI + 5
 };
 constexpr int FQ_MI = 34;
+
+// Diagonal Hessian of the QP.  mode 0 (default): the exact Hessian of the reference's least-squares cost, 2 diag(R, Q) per
+// stage and 2 diag(0, P) at the last one (Gauss-Newton SQP: the constraint curvature is dropped), plus the reference's
+// regularisation 5e-6.  mode 1: the literal FORCESPRO options of optimizer.py:234-236, `bfgs_init = 2.5 I` -- with one QP
+// per call and a guess that is never refreshed (optimizer.py:264-274) the BFGS matrix would stay at its initial value;
+// that Hessian under-weights the tracking terms by two orders of magnitude and the closed loop runs away at full throttle,
+// which the recorded forcespro runs do not do -- the binary evidently does something else, so the default is mode 0.
+inline void forces_hessian_diag(int mode, const double* Q, const double* R, const double* Pt, double* hd, double* hdN) {
+    const double reg = 5e-6;
+    for (int i = 0; i < 7; ++i) {
+        if (mode == 1) { hd[i] = 2.5 + reg; hdN[i] = 2.5 + reg; continue; }
+        hd[i] = (i < 2 ? 2.0 * R[i] : 2.0 * Q[i - 2]) + reg;
+        hdN[i] = (i < 2 ? 0.0 : 2.0 * Pt[i - 2]) + reg;
+    }
+}
 
 MPC_HD bool fq_fin_lo(double v) { return v > -1e300; }
 MPC_HD bool fq_fin_hi(double v) { return v < 1e300; }
@@ -183,10 +199,11 @@ MPC_HD void fq_newton(const ForcesQpArgs& A, int b, bool corr, double sigma_mu) 
     for (int k = N - 1; k >= 0; --k) {
         double w[7], rho[7], Phi[28];                       // Phi: symmetric 7x7, upper, index i*7 - i(i-1)/2 + (j-i)
         for (int i = 0; i < 7; ++i) w[i] = FQW(k, FQ_W + i);
-        for (int i = 0; i < 7; ++i) rho[i] = A.hdiag * w[i] + (double)FQW(k, FQ_G + i);
+        const double* hd = (k == N - 1) ? A.hdN : A.hd;
+        for (int i = 0; i < 7; ++i) rho[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i);
         if (!corr) {
             for (int i = 0; i < 28; ++i) Phi[i] = 0.0;
-            for (int i = 0; i < 7; ++i) Phi[i * 7 - i * (i - 1) / 2] = A.hdiag;
+            for (int i = 0; i < 7; ++i) Phi[i * 7 - i * (i - 1) / 2] = hd[i];
         }
         for (int q = 0; q < FQ_MI; ++q) {
             if (!fq_row_on(A, k, q)) continue;
@@ -407,7 +424,8 @@ MPC_HD void forces_qp_instance(const ForcesQpArgs& A, int b) {
         int M = 0;
         for (int k = 0; k < N; ++k) {
             double w[7], rd[7];
-            for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); rd[i] = A.hdiag * w[i] + (double)FQW(k, FQ_G + i); }
+            const double* hd = (k == N - 1) ? A.hdN : A.hd;
+            for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); rd[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i); }
             for (int i = 0; i < 5; ++i) rd[2 + i] += (double)FQW(k, FQ_PI + i);
             if (k < N - 1)
                 for (int j = 0; j < 7; ++j) {

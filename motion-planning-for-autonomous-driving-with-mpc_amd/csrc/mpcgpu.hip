@@ -28,6 +28,7 @@
 
 #include "mpc_host_common.h"
 #include "mpc_closed_loop.h"
+#include "mpc_forces_qp.h"
 
 using namespace mpc;
 
@@ -807,6 +808,12 @@ __global__ void __launch_bounds__(128) k_forces_stage(const ForcesArgs A) {
     }
 }
 
+// FORCES-mode SQP step (row f3): one instance per thread, workspace [row][Bp] (mpc_forces_qp.h)
+__global__ void __launch_bounds__(64) k_forces_qp(const ForcesQpArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) forces_qp_instance(A, b);
+}
+
 // closed-loop driver around the solve (row f1): one instance per thread, row-major buffers
 __global__ void k_loop_setup(const LoopArgs A) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1529,6 +1536,49 @@ int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const doub
     }
     for (int i = 0; i < 8; ++i) (void)hipFree(dev[i]);
     if (!ok) { h->err = "forces stage eval: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
+    return MPC_OK;
+}
+
+int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* xinit, const double* all_parameters,
+                           const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
+                           double* x_out, int32_t* exitflag, int32_t* it, double* res) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !x0 || !xinit || !all_parameters || !lb || !ub || !hl || !hu || !x_out) { h->err = "forces solve: null or empty argument"; return MPC_ERR_INVALID; }
+    const mpc_problem_desc& d = h->hp.desc;
+    if (d.nx != 5) { h->err = "the FORCES formulation has 5 states (z = [deltaDot, aLong, x, y, delta, v, psi])"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int N = d.N;
+    const size_t nB = (size_t)B, Bp = (nB + 63) / 64 * 64;
+    double *dz = nullptr, *dxi = nullptr, *dpar = nullptr, *dout = nullptr, *dres = nullptr, *dws = nullptr;
+    int32_t *dflag = nullptr, *dit = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dz); (void)hipFree(dxi); (void)hipFree(dpar); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dws); (void)hipFree(dflag); (void)hipFree(dit); };
+    hipStream_t s = h->own_stream;
+    bool ok = hipMalloc(&dz, nB * N * 7 * 8) == hipSuccess && hipMalloc(&dxi, nB * 5 * 8) == hipSuccess && hipMalloc(&dpar, nB * N * 10 * 8) == hipSuccess &&
+              hipMalloc(&dout, nB * N * 7 * 8) == hipSuccess && hipMalloc(&dres, nB * 8) == hipSuccess && hipMalloc(&dflag, nB * 4) == hipSuccess &&
+              hipMalloc(&dit, nB * 4) == hipSuccess && hipMalloc(&dws, (size_t)FQ_ROWS * N * Bp * 8) == hipSuccess;
+    ok = ok && hipMemcpyAsync(dz, x0, nB * N * 7 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(dxi, xinit, nB * 5 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(dpar, all_parameters, nB * N * 10 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        ForcesQpArgs A{};
+        A.B = B; A.Bp = (int32_t)Bp; A.N = N; A.max_it = 60;
+        A.dt = d.dt; A.l = d.wheelbase; A.wb = d.friction_div; A.rho = d.ego_offset;
+        A.tol = 1e-4; A.tol_mu = 1e-6;
+        for (int i = 0; i < 5; ++i) { A.Q[i] = d.Q[i]; A.Pt[i] = d.P[i]; }
+        A.R[0] = d.R[0]; A.R[1] = d.R[1];
+        forces_hessian_diag(hessian_mode, A.Q, A.R, A.Pt, A.hd, A.hdN);
+        for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
+        for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
+        A.zbar = dz; A.params = dpar; A.xinit = dxi; A.z_out = dout; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws;
+        hipLaunchKernelGGL(k_forces_qp, dim3((B + 63) / 64), dim3(64), 0, s, A);
+        ok = hipMemcpyAsync(x_out, dout, nB * N * 7 * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (exitflag) ok = ok && hipMemcpyAsync(exitflag, dflag, nB * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (it) ok = ok && hipMemcpyAsync(it, dit, nB * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (res) ok = ok && hipMemcpyAsync(res, dres, nB * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    }
+    cleanup();
+    if (!ok) { h->err = "forces solve: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
     return MPC_OK;
 }
 

@@ -308,17 +308,77 @@ class CasadiOptimizer(Optimizer):
         return np.array(x_).reshape(N_ + 1, -1), np.array(u_).reshape(N_, -1)
 
 
+class ForcesInfo(object):
+    """`info` of `solver.solve(problem)` (struct FORCESNLPsolver_info, FORCESNLPsolver.h:151-203): the fields the reference
+    reads are `it` and `solvetime` (optimizer.py:331,355)."""
+
+    def __init__(self, it, solvetime, res_eq, pobj=float("nan")):
+        self.it = int(it)
+        self.it2opt = int(it)
+        self.solvetime = float(solvetime)
+        self.fevalstime = 0.0
+        self.QPtime = float(solvetime)
+        self.res_eq = float(res_eq)
+        self.rsnorm = float(res_eq)
+        self.pobj = float(pobj)
+
+
+class ForcesModel(object):
+    """the fields of `forcespro.nlp.SymbolicModel` that optimizer.py:203-222 sets and the closed loop reads"""
+
+    def __init__(self, N, backend, lb, ub, hl, hu):
+        self.N, self.nvar, self.neq, self.nh, self.npar = N, 7, 5, 10, 10
+        self.lb, self.ub, self.hl, self.hu = lb, ub, hl, hu
+        self.E = np.concatenate([np.zeros((5, 2)), np.eye(5)], axis=1)
+        self.xinitidx = range(2, 7)
+        self._backend = backend
+
+    def eq(self, z):
+        """one RK4 step of the vehicle ODE from x = z[2:7] with u = z[0:2] (optimizer.py:91-98), on the device"""
+        z = np.asarray(z, dtype=np.float64).ravel()
+        return self._backend.plant_step(z[2:7], z[0:2], "rk4")
+
+
+class ForcesSolverHandle(object):
+    """`solver` of `model, solver = self.solver()`: `solver.solve(problem)` -> (output, exitflag, info)
+    (test/FORCESNLPsolver/interface/FORCESNLPsolver_py.py:181-300), one SQP step per call on the device."""
+
+    def __init__(self, backend, model):
+        self._backend, self._model = backend, model
+
+    def solve(self, problem):
+        N = self._model.N
+        x0 = np.asarray(problem["x0"], dtype=np.float64)
+        batched = x0.ndim == 3
+        x0 = x0.reshape(-1, N, 7) if batched else x0.reshape(1, N, 7)
+        B = x0.shape[0]
+        xinit = np.asarray(problem["xinit"], dtype=np.float64).reshape(B, 5)
+        par = np.asarray(problem["all_parameters"], dtype=np.float64).reshape(B, N, 10)
+        t_ = time.time()
+        m = self._model
+        x, flag, it, res = self._backend.forces_solve(x0, xinit, par, m.lb, m.ub, m.hl, m.hu)
+        dt = time.time() - t_
+        fmt = "x{0:02d}" if N >= 10 else "x{0:1d}"
+        if batched:
+            output = {fmt.format(i + 1): x[:, i, :] for i in range(N)}
+            return output, flag, [ForcesInfo(it[b], dt / B, res[b]) for b in range(B)]
+        output = {fmt.format(i + 1): x[0, i, :] for i in range(N)}
+        return output, int(flag[0]), ForcesInfo(it[0], dt, res[0])
+
+
 class ForcesproOptimizer(Optimizer):
-    """Call-surface twin of optimizer.py:86-366 (`model, solver = self.solver(); solver.solve(problem)`).
+    """optimizer.py:86-366 with the FORCES-mode solve on the GPU (scope row f3).
 
-    The FORCESPRO formulation (RK4 shooting, per-stage friction circle, 3x3 squared circle distances, terminal
-    weights, SQP with BFGS) is row f3 of the scope table -- scheduled after the CasADi path; its
-    numerics in the reference live in a closed, licence-expired binary (FORCESNLPsolver.h:209-210), so there is
-    nothing to be bit-compatible with.  Until the FORCES-mode kernels land, `solver()` raises instead of silently
-    substituting the Euler formulation."""
+    The formulation is the reference's: z = [deltaDot, aLong, x, y, delta, v, psi], RK4 shooting, friction circle and nine
+    squared circle distances per stage, terminal weights, `xinit` on the first stage, ten run-time parameters per stage, ONE
+    quadratic programme per call (SQP with `maxqps = 1`, BFGS initialised to 2.5 I).  The reference's solver for it is a
+    generated, licence-locked binary (FORCESNLPsolver.h:209-210): its numerics cannot be matched, only its formulation
+    (stage functions pinned against the generated C, row a11) and its call surface."""
 
-    def __init__(self, configuration, init_values, predict_horizon):
+    def __init__(self, configuration, init_values, predict_horizon, device=0):
         super(ForcesproOptimizer, self).__init__(configuration, init_values, predict_horizon)
+        self._device = device
+        self._pair = None
 
     def inequal_constraint(self):
         """optimizer.py:100-119."""
@@ -329,13 +389,70 @@ class ForcesproOptimizer(Optimizer):
         return z_low_bound, z_upper_bound, lo, hi
 
     def solver(self):
-        raise NotImplementedError(
-            "ForcesproOptimizer: the FORCES (RK4 / SQP) formulation is not built yet (scope row f3); "
-            "use CasadiOptimizer (framework_name: casadi).")
+        """optimizer.py:196-245: (model, solver); the device handle is created once and cached."""
+        if self._pair is None:
+            w = self.weights_setting
+            Q = [w["weight_x"], w["weight_y"], w["weight_steering_angle"], w["weight_velocity"], w["weight_heading_angle"]]
+            R = [w["weight_velocity_steering_angle"], w["weight_long_acceleration"]]
+            Pt = [w["weight_x_terminate"], w["weight_y_terminate"], w["weight_steering_angle_terminate"],
+                  w["weight_velocity_terminate"], w["weight_heading_angle_terminate"]]
+            _, disc_distance = compute_approximating_circle_radius(self.configuration.p.l, self.configuration.p.w)
+            backend = BatchedMPCSolver(self.predict_horizon, 5, dt=0.1, Q=Q, R=R, P=Pt,            # integrator_stepsize = 0.1, optimizer.py:97
+                                       friction_div=self.configuration.wheelbase, ego_offset=(disc_distance / 2) / 2, device=self._device)
+            lb, ub, hl, hu = self.inequal_constraint()
+            model = ForcesModel(self.predict_horizon, backend, lb, ub, hl, hu)
+            self._pair = (model, ForcesSolverHandle(backend, model))
+        return self._pair
+
+    def runtime_parameters(self, k, N):
+        """the (10, N) parameter block of step k (optimizer.py:292-318): next N path points, desired velocities ramping to 0
+        over the last N steps, next N path orientations (all replenished with the last entry), obstacle circle centres"""
+        L = self.iter_length
+        v_all = np.hstack((np.ones(L - N) * self.desired_velocity, np.linspace(self.desired_velocity, 0, N)))
+        v = v_all[k + 1:k + 1 + N]
+        pts = self.resampled_path_points.T[:, k + 1:k + 1 + N]
+        ori = np.asarray(self.orientation)[k + 1:k + 1 + N]
+        while pts.shape[1] != N:
+            pts = np.hstack((pts, self.resampled_path_points[-1].reshape(2, -1)))
+            ori = np.hstack((ori, self.orientation[-1]))
+            v = np.hstack((v, v_all[-1]))
+        oc = np.array(self.obstacle_circles_centers_tuple, dtype=np.float64).reshape(6, 1)
+        return np.vstack((pts, v, ori, np.tile(oc, (1, N))))
 
     def optimize(self):
-        self.solver()
+        """optimizer.py:246-366"""
+        model, solver = self.solver()
+        L = self.iter_length
+        x = np.zeros((5, L + 1))
+        u = np.zeros((2, L))
+        solve_time = np.zeros(L)
+        x0i = np.array([0.0, self.init_acceleration, self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation])
+        x0 = np.transpose(np.tile(x0i, (1, model.N)))
+        xinit = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation])
+        x[:, 0] = xinit
+        # (the reference never refreshes problem["x0"]: every call linearises at the tiled initial guess, optimizer.py:264-274)
+        problem = {"x0": x0.reshape(model.N, 7), "xinit": xinit, "ToleranceEqualities": 1e-1, "ToleranceInequalities": 1e-1}
+        for k in range(L):
+            problem["xinit"] = x[:, k]
+            params = self.runtime_parameters(k, model.N)
+            problem["all_parameters"] = np.reshape(np.transpose(params), (10 * model.N, 1))
+            output, exitflag, info = solver.solve(problem)
+            assert exitflag == 1, "bad exitflag"                                  # optimizer.py:330
+            temp = np.zeros((model.nvar, model.N))
+            for i in range(model.N):
+                key = "x{0:1d}".format(i + 1)
+                temp[:, i] = output[key] if key in output else output["x{0:02d}".format(i + 1)]
+            pred_u = temp[0:2, :]
+            if not self.configuration.noised:
+                u[:, k] = pred_u[:, 0]
+            else:
+                sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05
+                u[:, k] = pred_u[:, 0] + np.random.normal(np.array([0, 0]), np.array([sigma, sigma]), (2,))
+            x[:, k + 1] = np.transpose(model.eq(np.concatenate((u[:, k], x[:, k]))))
+            solve_time[k] = info.solvetime
+        x = np.delete(x, -1, axis=1)
+        return x.T, u.T, solve_time
 
 
-__all__ = ["CasadiOptimizer", "ForcesproOptimizer", "Optimizer", "NlpSolverHandle", "DMLike", "VehicleDynamics", "ca", "np",
+__all__ = ["CasadiOptimizer", "ForcesproOptimizer", "ForcesSolverHandle", "ForcesModel", "ForcesInfo", "Optimizer", "NlpSolverHandle", "DMLike", "VehicleDynamics", "ca", "np",
            "find_closest_point", "compute_approximating_circle_radius", "compute_centers_of_approximation_circles"]

@@ -206,6 +206,25 @@ class BatchedMPCSolver:
                                                     _abi.as_dp(gf), _abi.as_dp(c), _abi.as_dp(jc), _abi.as_dp(hv), _abi.as_dp(jh)))
         return dict(f=f, grad_f=gf, c=c, jac_c=jc, h=hv, jac_h=jh)
 
+    def forces_solve(self, x0, xinit, all_parameters, lb, ub, hl, hu, hessian_mode=0):
+        """FORCES-mode SQP step for B problems (mpc_forces_solve_batch): x0 [B,N,7], xinit [B,5], all_parameters [B,N,10]
+        -> (x [B,N,7], exitflag [B], it [B], res [B])."""
+        N = self.N
+        x0 = _abi.f64(x0).reshape(-1, N, 7)
+        B = x0.shape[0]
+        xinit = _abi.f64(xinit).reshape(B, 5)
+        par = _abi.f64(all_parameters).reshape(B, N, 10)
+
+        def big(a, n):
+            a = np.asarray(a, dtype=np.float64).reshape(n)
+            return _abi.f64(np.where(np.isfinite(a), a, np.sign(a) * 1e308))
+        out = np.empty_like(x0)
+        flag, it, res = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B)
+        self._check(self._lib.mpc_forces_solve_batch(self._h, B, _abi.as_dp(x0), _abi.as_dp(xinit), _abi.as_dp(par), _abi.as_dp(big(lb, 7)),
+                                                     _abi.as_dp(big(ub, 7)), _abi.as_dp(big(hl, 10)), _abi.as_dp(big(hu, 10)), int(hessian_mode), _abi.as_dp(out),
+                                                     _abi.as_ip(flag), _abi.as_ip(it), _abi.as_dp(res)))
+        return out, flag, it, res
+
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
 

@@ -6,7 +6,7 @@ programme per call (`sqp_nlp.maxqps = 1`), a BFGS Hessian initialised to 2.5 I (
 updated) and Hessian regularisation 5e-6; the generated solver itself is a closed, licence-locked binary.  One call is
 therefore one step of sequential quadratic programming from the caller's guess zbar = problem["x0"]:
 
-    min_dz  sum_k  grad f_k(zbar_k)' dz_k + 1/2 dz_k' (2.5 + 5e-6) I dz_k
+    min_dz  sum_k  grad f_k(zbar_k)' dz_k + 1/2 dz_k' H_k dz_k     (H_k diagonal, see hessian_diag)
     s.t.    x_1 = xinit                                   (xinitidx = z[2:7], optimizer.py:222)
             x_{k+1} = c(zbar_k) + C_k dz_k,  k = 1..N-1    (RK4 dynamics, E = [0 I], optimizer.py:91-98, 219)
             lb <= zbar_k + dz_k <= ub                      (optimizer.py:100-110; the states of stage 1 are fixed by xinit)
@@ -23,7 +23,22 @@ import numpy as np
 
 from . import forces_model_numpy as FM
 
-H_DIAG = 2.5 + 5e-6
+REG_HESSIAN = 5e-6
+
+
+def hessian_diag(weights, N, mode=0):
+    """(N,7) diagonal QP Hessian; mode 0: exact Hessian of the least-squares cost (Gauss-Newton), mode 1: the literal
+    `bfgs_init = 2.5 I` of optimizer.py:234 (see csrc/mpc_forces_qp.h: forces_hessian_diag)."""
+    H = np.zeros((N, 7))
+    for k in range(N):
+        if mode == 1:
+            H[k] = 2.5
+        elif k < N - 1:
+            H[k] = 2.0 * np.concatenate((weights["R"], weights["Q"]))
+        else:
+            H[k] = 2.0 * np.concatenate(([0.0, 0.0], weights["P"]))
+    return H + REG_HESSIAN
+
 IPM_MAX_IT = 60
 IPM_TOL = 1e-4          # residuals (dual, primal, equality); the accuracy an SQP step needs, see csrc/mpc_forces_qp.h
 IPM_TOL_MU = 1e-6       # complementarity gap
@@ -62,7 +77,7 @@ def build_qp(zbar, params, xinit, lb, ub, hl, hu, weights=FM.WEIGHTS_MODEL_C, dt
     return st
 
 
-def solve_qp(st, zbar, xinit, max_it=IPM_MAX_IT, tol=IPM_TOL, tol_mu=IPM_TOL_MU):
+def solve_qp(st, zbar, xinit, Hd, max_it=IPM_MAX_IT, tol=IPM_TOL, tol_mu=IPM_TOL_MU):
     """Mehrotra predictor-corrector on the stage-structured QP; returns (dz (N,7), iterations, converged, kkt)."""
     N = len(st)
     nz = 7 * N
@@ -88,13 +103,14 @@ def solve_qp(st, zbar, xinit, max_it=IPM_MAX_IT, tol=IPM_TOL, tol_mu=IPM_TOL_MU)
         d[o:o + m[k]] = st[k]["d"]
         g[7 * k:7 * k + 7] = st[k]["g"]
         o += m[k]
+    hvec = np.asarray(Hd, dtype=np.float64).ravel()
     x = np.zeros(nz)
     s = np.maximum(d, 1.0)
     lam = 1.0 / s                                             # centred start: s * lam = 1 on every row
     pi = np.zeros(ne)
     it, conv, kkt = 0, False, np.inf
     for it in range(max_it + 1):
-        rd = H_DIAG * x + g + G.T @ lam + A.T @ pi
+        rd = hvec * x + g + G.T @ lam + A.T @ pi
         rp = G @ x + s - d
         re = A @ x - b
         mu = float(s @ lam) / M
@@ -111,7 +127,7 @@ def solve_qp(st, zbar, xinit, max_it=IPM_MAX_IT, tol=IPM_TOL, tol_mu=IPM_TOL_MU)
             break
         D = lam / s
         K = np.zeros((nz + ne, nz + ne))
-        K[:nz, :nz] = H_DIAG * np.eye(nz) + G.T @ (D[:, None] * G)
+        K[:nz, :nz] = np.diag(hvec) + G.T @ (D[:, None] * G)
         K[:nz, nz:] = A.T
         K[nz:, :nz] = A
 
@@ -144,7 +160,7 @@ def solve_qp(st, zbar, xinit, max_it=IPM_MAX_IT, tol=IPM_TOL, tol_mu=IPM_TOL_MU)
     return x.reshape(N, 7), it, conv, kkt
 
 
-def sqp_step(zbar, params, xinit, lb, ub, hl, hu, weights=FM.WEIGHTS_MODEL_C, dt=0.1):
+def sqp_step(zbar, params, xinit, lb, ub, hl, hu, weights=FM.WEIGHTS_MODEL_C, dt=0.1, mode=0):
     st = build_qp(zbar, params, xinit, lb, ub, hl, hu, weights, dt)
-    dz, it, conv, kkt = solve_qp(st, zbar, xinit)
+    dz, it, conv, kkt = solve_qp(st, zbar, xinit, hessian_diag(weights, zbar.shape[0], mode))
     return zbar + dz, it, conv, kkt

@@ -163,14 +163,15 @@ extern "C" int emu_closed_loop_piece(int32_t mode, int32_t i, double dt, double 
 
 // FORCES-mode SQP step (mpc_forces_qp.h), one instance after the other on host arrays
 extern "C" int emu_forces_solve(int32_t B, int32_t N, double dt, double l, double wb, double rho, const double* Q, const double* R,
-                                const double* Pt, const double* lb, const double* ub, const double* hl, const double* hu,
+                                const double* Pt, const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
                                 const double* zbar, const double* params, const double* xinit, double* z_out, int32_t* iters,
                                 int32_t* status, double* kkt) {
     ForcesQpArgs A{};
     A.B = B; A.Bp = B; A.N = N; A.max_it = 60;
-    A.dt = dt; A.l = l; A.wb = wb; A.rho = rho; A.hdiag = 2.5 + 5e-6; A.tol = 1e-4; A.tol_mu = 1e-6;
+    A.dt = dt; A.l = l; A.wb = wb; A.rho = rho; A.tol = 1e-4; A.tol_mu = 1e-6;
     for (int i = 0; i < 5; ++i) { A.Q[i] = Q[i]; A.Pt[i] = Pt[i]; }
     A.R[0] = R[0]; A.R[1] = R[1];
+    forces_hessian_diag(hessian_mode, A.Q, A.R, A.Pt, A.hd, A.hdN);
     for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
     for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
     A.zbar = zbar; A.params = params; A.xinit = xinit; A.z_out = z_out; A.iters = iters; A.status = status; A.kkt = kkt;

@@ -76,7 +76,7 @@ def emu_lib():
         L.emu_closed_loop_piece.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp, ip]
         L.emu_closed_loop_piece.restype = C.c_int
-        L.emu_forces_solve.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double] + [dp] * 10 + [dp, ip, ip, dp]
+        L.emu_forces_solve.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double] + [dp] * 7 + [C.c_int32] + [dp] * 3 + [dp, ip, ip, dp]
         L.emu_forces_solve.restype = C.c_int
         _emu = L
     return _emu
@@ -168,3 +168,35 @@ def straight_path(L, x0, y0, psi, v_des, dt=0.1):
     k = np.arange(L)
     path = np.stack([x0 + k * v_des * dt * np.cos(psi), y0 + k * v_des * dt * np.sin(psi)], axis=1)
     return path, np.full(L, psi)
+
+
+class EmuForcesBackend:
+    """TEST ONLY stand-in for BatchedMPCSolver in FORCES mode: the kernels' own QP code stepped on the CPU by the emulation
+    harness (tests/emu) and the oracle's RK4 plant step.  The product never constructs this."""
+
+    def __init__(self, N, weights, friction_div=2.578, ego_offset=0.75):
+        from oracle.binding import OracleSolver
+        from oracle.nlp_numpy import NLPConfig
+        self.N, self.w = N, weights
+        self.friction_div, self.ego_offset = friction_div, ego_offset
+        self._o = OracleSolver(NLPConfig(N=N, nx=5))
+        self.calls = 0
+
+    def plant_step(self, x, u, integrator="euler"):
+        return self._o.plant_step(np.asarray(x, float), np.asarray(u, float), integrator)
+
+    def forces_solve(self, x0, xinit, par, lb, ub, hl, hu, hessian_mode=0):
+        self.calls += 1
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, self.N, 7)
+        B = x0.shape[0]
+        xinit = np.ascontiguousarray(xinit, dtype=np.float64).reshape(B, 5)
+        par = np.ascontiguousarray(par, dtype=np.float64).reshape(B, self.N, 10)
+        big = lambda a: np.ascontiguousarray(np.where(np.isfinite(a), a, np.sign(a) * 1e308), dtype=np.float64)     # noqa: E731
+        zo, it, st, kk = np.zeros_like(x0), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+        dp = abi.as_dp
+        rc = emu_lib().emu_forces_solve(B, self.N, C.c_double(0.1), C.c_double(2.5789128), C.c_double(self.friction_div), C.c_double(self.ego_offset),
+                                        dp(np.array(self.w["Q"], float)), dp(np.array(self.w["R"], float)), dp(np.array(self.w["P"], float)),
+                                        dp(big(np.asarray(lb, float))), dp(big(np.asarray(ub, float))), dp(big(np.asarray(hl, float))), dp(big(np.asarray(hu, float))), int(hessian_mode),
+                                        dp(x0), dp(par), dp(xinit), dp(zo), abi.as_ip(it), abi.as_ip(st), dp(kk))
+        assert rc == 0
+        return zo, st, it, kk

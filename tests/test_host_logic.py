@@ -90,14 +90,51 @@ def test_sol_call_surface_single_and_batch():
     assert sol.stats()["success"]
 
 
-def test_forcespro_surface_is_explicitly_unbuilt():
-    path, orient = straight_path(30, 0, 0, 0, 10.0)
-    conf = make_configuration(path, orient, 10.0, WEIGHTS_YAML_ZAM_LF)
-    o = opt.ForcesproOptimizer(configuration=conf, init_values=(np.zeros(2), 10.0, 0.0, 0.0), predict_horizon=10)
+def make_forces_optimizer(N=10, L=30):
+    from helpers import EmuForcesBackend
+    path, orient = straight_path(L, 29.9948, -1.1501, 0.03495, 20.0)
+    conf = make_configuration(path, orient, 20.0, WEIGHTS_YAML_ZAM_LF)
+    o = opt.ForcesproOptimizer(configuration=conf, init_values=(np.array([29.9948, -1.1501]), 20.0, 0.0, 0.03495), predict_horizon=N)
+    w = WEIGHTS_YAML_ZAM_LF
+    weights = dict(Q=[w["weight_x"], w["weight_y"], w["weight_steering_angle"], w["weight_velocity"], w["weight_heading_angle"]],
+                   R=[w["weight_velocity_steering_angle"], w["weight_long_acceleration"]],
+                   P=[w["weight_x_terminate"], w["weight_y_terminate"], w["weight_steering_angle_terminate"], w["weight_velocity_terminate"],
+                      w["weight_heading_angle_terminate"]])
+    be = EmuForcesBackend(N, weights)
+    model = opt.ForcesModel(N, be, *o.inequal_constraint())
+    o._pair = (model, opt.ForcesSolverHandle(be, model))
+    return o
+
+
+def test_forcespro_surface_and_closed_loop_with_standin_backend():
+    """ForcesproOptimizer (optimizer.py:86-366): bounds, run-time parameter block incl. the replenished tail and the velocity
+    ramp, `solver.solve(problem)` call surface, 30-step closed loop (the QP code of the kernels stepped on the CPU)."""
+    o = make_forces_optimizer()
     lo, hi, hl, hu = o.inequal_constraint()
-    assert lo.shape == (7,) and hl.shape == (10,) and hu[0] == 11.5 ** 2
-    with pytest.raises(NotImplementedError):
-        o.solver()
+    assert lo.shape == (7,) and hl.shape == (10,) and hu[0] == 11.5 ** 2 and hl[1] == (o.radius_ego + o.radius_obstacle) ** 2
+    p0 = o.runtime_parameters(0, 10)
+    assert p0.shape == (10, 10) and np.array_equal(p0[0:2, 0], o.resampled_path_points[1]) and np.all(p0[2] == 20.0)
+    assert np.array_equal(p0[4:, 3], np.array(o.obstacle_circles_centers_tuple).ravel())
+    p25 = o.runtime_parameters(25, 10)                       # only 4 path points left: the rest repeats the last one
+    assert np.array_equal(p25[0:2, 3], o.resampled_path_points[-1]) and np.array_equal(p25[0:2, 9], o.resampled_path_points[-1])
+    ramp = np.linspace(20.0, 0, 10)
+    assert np.allclose(p25[2, :4], ramp[6:10]) and np.all(p25[2, 4:] == 0.0)
+    model, solver = o.solver()
+    assert (model.N, model.nvar, model.neq, model.nh, model.npar) == (10, 7, 5, 10, 10)
+    x0i = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 20.0, 0.03495])
+    problem = {"x0": np.tile(x0i, (10, 1)), "xinit": x0i[2:], "all_parameters": np.reshape(np.transpose(p0), (100, 1))}
+    output, exitflag, info = solver.solve(problem)
+    assert exitflag == 1 and sorted(output)[0] == "x01" and output["x10"].shape == (7,) and info.it > 0 and info.solvetime > 0
+    assert np.allclose(output["x01"][2:], x0i[2:], atol=1e-4)                      # xinit is imposed on the first stage
+    assert np.allclose(model.eq(np.concatenate(([0.0, 1.0], x0i[2:])))[3], 20.1)   # RK4 plant step: v + dt * a
+    states, controls, t = o.optimize()
+    assert states.shape == (30, 5) and controls.shape == (30, 2) and t.shape == (30,)
+    assert np.array_equal(states[0], x0i[2:])
+    p0_, psi = o.resampled_path_points[0], 0.03495
+    lateral = (states[:, 1] - p0_[1]) * np.cos(psi) - (states[:, 0] - p0_[0]) * np.sin(psi)
+    assert np.abs(lateral).max() < 0.3                                              # stays on the lane (the recorded run: RMSD_y 0.26 m)
+    assert np.all(np.abs(controls[:, 0]) <= 0.4 + 1e-6) and np.all(np.abs(controls[:, 1]) <= 11.5 + 1e-6)
+    assert states[-1, 3] < 19.0                                                     # decelerates towards the ramped-down desired velocity
 
 
 def test_casadi_shim_namespace():
