@@ -121,7 +121,7 @@ struct WsLayout {
 
 inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     const size_t NZ = nx + 2, NS = (size_t)nx * (nx + 1) / 2, S = N + 1;
-    const size_t NBLK = NS + 10 + 2 * nx, NPK = NS + nx, NKK = 2 * nx + 2;
+    const size_t NBLK = (nx + 5) + 10 + 2 * nx, NPK = NS + nx, NKK = 2 * nx + 2;      // Dim<NX>::NBLK: sparse H (NX + 5 entries)
     WsLayout w{};
     size_t off = 0;
     auto take = [&](size_t rows) { const size_t o = off; off += rows; return o; };

@@ -200,9 +200,17 @@ struct Dim {
     static constexpr int NU = 2;
     static constexpr int NZ = NX + 2;
     static constexpr int NS = NX * (NX + 1) / 2;
+    // Structural nonzeros of the condensed state Hessian: the diagonal (cost, bound barriers) plus (x,y), (x,psi), (y,psi)
+    // from the circle rows, (delta,v) from the dynamics / friction row and (v,psi) from the dynamics; the other 10 entries
+    // of the upper triangle are identically zero and are neither stored nor read nor added.
+    static constexpr int NH = NX + 5;
+    MPC_HD static constexpr int hrow(int i, int j) {     // i <= j: row inside the H part of a stage block, -1 = structural zero
+        return i == j ? i : (i == 0 && j == 1) ? NX : (i == 0 && j == 4) ? NX + 1 : (i == 1 && j == 4) ? NX + 2
+             : (i == 2 && j == 3) ? NX + 3 : (i == 3 && j == 4) ? NX + 4 : -1;
+    }
     // BLK rows per stage
-    static constexpr int B_H = 0, B_RUU = NS, B_A = NS + 2, B_GX = NS + 8, B_GU = NS + 8 + NX, B_CN = NS + 10 + NX;
-    static constexpr int NBLK = NS + 10 + 2 * NX;
+    static constexpr int B_H = 0, B_RUU = NH, B_A = NH + 2, B_GX = NH + 8, B_GU = NH + 8 + NX, B_CN = NH + 10 + NX;
+    static constexpr int NBLK = NH + 10 + 2 * NX;
     static constexpr int NPK = NS + NX;
     static constexpr int NKK = 2 * NX + 2;
     static constexpr int NEV = 12;
@@ -1261,7 +1269,11 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     // stage blocks that do not depend on the barrier parameter
     const int base = k * D::NBLK;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_H + i) = H[i];
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = i; j < NX; ++j)
+            if (D::hrow(i, j) >= 0) MPC_K(P.BLK, D::NBLK, 0, D::B_H + D::hrow(i, j)) = H[D::sidx(i, j)];
+    }
     MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 0) = ruu[0];
     MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 1) = ruu[1];
     MPC_K(P.BLK, D::NBLK, 0, D::B_A + 0) = a03;
@@ -1351,7 +1363,10 @@ MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
     const uint32_t base = (uint32_t)k * D::NBLK;
 #define RL(row) MPC_UB(P.BLK, base + (row), b)
 #pragma unroll
-    for (int i = 0; i < D::NS; ++i) s.H[i] = RL(D::B_H + i);
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = i; j < NX; ++j) s.H[D::sidx(i, j)] = (D::hrow(i, j) >= 0) ? (double)RL(D::B_H + (D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0)) : 0.0;
+    }
     s.ruu[0] = RL(D::B_RUU); s.ruu[1] = RL(D::B_RUU + 1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) s.a[i] = RL(D::B_A + i);
@@ -1443,7 +1458,9 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
         for (int j = i; j < NX; ++j) {
-            double t = Ps[D::sidx(i, j)] + s.H[D::sidx(i, j)] + G0[i] * K0[j] + G1[i] * K1[j];
+            double t = Ps[D::sidx(i, j)];
+            if (D::hrow(i, j) >= 0) t += s.H[D::sidx(i, j)];
+            t += G0[i] * K0[j] + G1[i] * K1[j];
             if (j >= 2 && j <= 4) t += W[i][j - 2];
             if (i >= 2 && i <= 4) t += W[j][i - 2];
             if (i >= 2 && i <= 4 && j >= 2 && j <= 4) {          // ((dtF)'W)[i][j], rows/cols (delta, v, psi)

@@ -347,7 +347,11 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
     auto lds_d = [&](uint32_t off) { return *reinterpret_cast<const double*>(smem + off + (uint32_t)lane * 8u); };
     auto read_stage = [&](uint32_t slot, RicStage<NX>& s) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) s.H[i] = lds_d(slot + (D::B_H + i) * 512u);
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = i; j < NX; ++j)
+                s.H[D::sidx(i, j)] = (D::hrow(i, j) >= 0) ? lds_d(slot + (D::B_H + (D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0)) * 512u) : 0.0;
+        }
         s.ruu[0] = lds_d(slot + (D::B_RUU) * 512u);
         s.ruu[1] = lds_d(slot + (D::B_RUU + 1) * 512u);
 #pragma unroll
