@@ -1380,26 +1380,25 @@ MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
 template <int NX>
 MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>::sidx(i, j) : Dim<NX>::sidx(j, i)]; }
 
-// one backward step of the recursion: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go.
+// One backward step of the recursion, in two halves that only meet through (P+, G, Lam^-1):
+//   ric_matrix_step  P+ -> P_k, gains K            (the critical chain: the next stage needs P_k)
+//   ric_vector_step  p+ -> p_k, feed-forward kff   (needs P+, G, Lam^-1 of the same stage; nothing waits for it)
+// The GPU kernel runs them on two wavefronts, the vector half one stage behind the matrix half; riccati_backward_step below
+// chains them for the one-thread-per-instance paths.
 // With A = I + dtF (F has 7 nonzeros) the products are organised around W = P+ (dtF), which has only three nonzero
 // columns (delta, v, psi):   A'P+A = P+ + W + W' + (dtF)'W,   P+A = P+ + W,
 // so the 6x6 product P+A is never formed and P_k is accumulated onto P+ (18 + 12 + 12 temporaries instead of 36 + 21).
 template <int NX>
-MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
-                                  double hux1, double* Ps, double* pv) {
+struct RicGain {
+    double G0[NX], G1[NX], i00, i01, i11;       // G = B'(P+ A) (+ Hux at stage 0), Lam^-1
+};
+
+template <int NX, bool STORE_P>
+MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
+                            double* Ps, RicGain<NX>& g) {
     using D = Dim<NX>;
-    constexpr int NS = D::NS;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
-    // h = p+ - P+ c_{k+1}
-    double h[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double t = pv[i];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) t -= sym<NX>(Ps, i, j) * s.cn[j];
-        h[i] = t;
-    }
     // W[i][c] = (P+ dtF)[i][2 + c], c = 0,1,2  (columns delta, v, psi)
     double W[NX][3];
 #pragma unroll
@@ -1411,47 +1410,32 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         W[i][1] = t;
         W[i][2] = pi0 * a04 + pi1 * a14;
     }
-    // G = B'(P+A) (+ Hux at stage 0) = dt * rows (2,3) of (P+ + W);  Lam = Ruu + B'P+B;  l = gu + B'h
-    double G0[NX], G1[NX];
+    // G = B'(P+A) (+ Hux at stage 0) = dt * rows (2,3) of (P+ + W);  Lam = Ruu + B'P+B
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         double g0 = sym<NX>(Ps, 2, j), g1 = sym<NX>(Ps, 3, j);
         if (j >= 2 && j <= 4) { g0 += W[2][j - 2]; g1 += W[3][j - 2]; }
-        G0[j] = dt * g0;
-        G1[j] = dt * g1;
+        g.G0[j] = dt * g0;
+        g.G1[j] = dt * g1;
     }
-    if (k == 0) { G1[2] += hux0; G1[3] += hux1; }
+    if (k == 0) { g.G1[2] += hux0; g.G1[3] += hux1; }
     const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
     const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
     const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
-    const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
     const double det = L00 * L11 - L01 * L01;
     if (!(L00 > 0.0) || !(det > 0.0)) return false;
     const double idet = 1.0 / det;
-    const double i00 = L11 * idet, i01 = -L01 * idet, i11 = L00 * idet;
+    g.i00 = L11 * idet; g.i01 = -L01 * idet; g.i11 = L00 * idet;
     double K0[NX], K1[NX];
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-        K0[j] = -(i00 * G0[j] + i01 * G1[j]);
-        K1[j] = -(i01 * G0[j] + i11 * G1[j]);
+        K0[j] = -(g.i00 * g.G0[j] + g.i01 * g.G1[j]);
+        K1[j] = -(g.i01 * g.G0[j] + g.i11 * g.G1[j]);
     }
-    const double kf0 = -(i00 * l0 + i01 * l1), kf1 = -(i01 * l0 + i11 * l1);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         MPC_UK(P.KK, D::NKK, k, j) = K0[j];
         MPC_UK(P.KK, D::NKK, k, NX + j) = K1[j];
-    }
-    MPC_UK(P.KK, D::NKK, k, 2 * NX) = kf0;
-    MPC_UK(P.KK, D::NKK, k, 2 * NX + 1) = kf1;
-    // p_k = gx + A'h + G'kff
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double t = s.gx[i] + h[i] + G0[i] * kf0 + G1[i] * kf1;
-        if (i == 2) t += a42 * h[4];
-        if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NX == 6) t += dt * h[5]; }
-        if (i == 4) t += a04 * h[0] + a14 * h[1];
-        pv[i] = t;
-        MPC_UK(P.PK, D::NPK, k, NS + i) = t;
     }
     // P_k = H + P+ + W + W' + (dtF)'W + G'K, upper triangle, accumulated onto P+
 #pragma unroll
@@ -1460,7 +1444,7 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
         for (int j = i; j < NX; ++j) {
             double t = Ps[D::sidx(i, j)];
             if (D::hrow(i, j) >= 0) t += s.H[D::sidx(i, j)];
-            t += G0[i] * K0[j] + G1[i] * K1[j];
+            t += g.G0[i] * K0[j] + g.G1[i] * K1[j];
             if (j >= 2 && j <= 4) t += W[i][j - 2];
             if (i >= 2 && i <= 4) t += W[j][i - 2];
             if (i >= 2 && i <= 4 && j >= 2 && j <= 4) {          // ((dtF)'W)[i][j], rows/cols (delta, v, psi)
@@ -1471,9 +1455,56 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
             }
             if (i == j) t += delta;
             Ps[D::sidx(i, j)] = t;
-            MPC_UK(P.PK, D::NPK, k, D::sidx(i, j)) = t;
+            if (STORE_P) MPC_UK(P.PK, D::NPK, k, D::sidx(i, j)) = t;
         }
     }
+    return true;
+}
+
+// Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
+template <int NX>
+MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, const double* Pn, const RicGain<NX>& g, double* pv) {
+    using D = Dim<NX>;
+    constexpr int NS = D::NS;
+    const double dt = P.dt;
+    const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
+    // h = p+ - P+ c_{k+1}
+    double h[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double t = pv[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) t -= sym<NX>(Pn, i, j) * s.cn[j];
+        h[i] = t;
+    }
+    // l = gu + B'h,  kff = -Lam^-1 l
+    const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
+    const double kf0 = -(g.i00 * l0 + g.i01 * l1), kf1 = -(g.i01 * l0 + g.i11 * l1);
+    MPC_UK(P.KK, D::NKK, k, 2 * NX) = kf0;
+    MPC_UK(P.KK, D::NKK, k, 2 * NX + 1) = kf1;
+    // p_k = gx + A'h + G'kff
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double t = s.gx[i] + h[i] + g.G0[i] * kf0 + g.G1[i] * kf1;
+        if (i == 2) t += a42 * h[4];
+        if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NX == 6) t += dt * h[NX - 1]; }
+        if (i == 4) t += a04 * h[0] + a14 * h[1];
+        pv[i] = t;
+        MPC_UK(P.PK, D::NPK, k, NS + i) = t;
+    }
+}
+
+// both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
+template <int NX>
+MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
+                                  double hux1, double* Ps, double* pv) {
+    constexpr int NS = Dim<NX>::NS;
+    double Pn[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) Pn[i] = Ps[i];
+    RicGain<NX> g;
+    if (!ric_matrix_step<NX, true>(P, bb, k, s, delta, hux0, hux1, Ps, g)) return false;
+    ric_vector_step<NX>(P, bb, k, s, Pn, g, pv);
     return true;
 }
 
