@@ -1423,7 +1423,9 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
     const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
     const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
     const double det = L00 * L11 - L01 * L01;
-    if (!(L00 > 0.0) || !(det > 0.0)) return false;
+    // (no early exit when Lam is not positive definite: the lane just carries garbage to the end of the sweep, which is
+    //  repeated with a larger delta_w anyway -- a divergent exit here costs every lane ~70 select instructions per stage)
+    const bool pd = (L00 > 0.0) && (det > 0.0);
     const double idet = 1.0 / det;
     g.i00 = L11 * idet; g.i01 = -L01 * idet; g.i11 = L00 * idet;
     double K0[NX], K1[NX];
@@ -1458,7 +1460,7 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
             if (STORE_P) MPC_UK(P.PK, D::NPK, k, D::sidx(i, j)) = t;
         }
     }
-    return true;
+    return pd;
 }
 
 // Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
