@@ -1073,8 +1073,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int rc = ensure_ws(h, Bp);
     if (rc) return rc;
     const bool small_wg = 8 * (d.N + 1) <= 256 && getenv("MPCGPU_BIG_WG") == nullptr;
-    int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
-    if (getenv("MPCGPU_BX")) bx = atoi(getenv("MPCGPU_BX"));     // experiment: instances per stage workgroup
+    const int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
