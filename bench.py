@@ -207,6 +207,47 @@ def main():
                             single_thread_value=1024 / t_one, cpu_model=model, host_cpus=avail,
                             published_casadi_ipopt="25.1 steps/s (N=10, 1 instance, unknown CPU; BASELINE.md section 1)")
 
+    # ---- the paths around the solve, single-GPU run only, a few hundred milliseconds in total
+    other_paths = None
+    if rank == 0 and world == 1:
+        other_paths = {}
+        try:
+            s5 = mpc_amd.BatchedMPCSolver(N_HORIZON, 5, Q=cfg.Qdiag[:5], R=cfg.R, obstacle_centers=cfg.obstacle_centers, device=local_rank)
+            s5.set_bounds()                                                      # the reference's default limits
+            L, Bc = 60, B
+            k = np.arange(L)
+            path = np.stack([k * 1.5 * np.cos(0.1), k * 1.5 * np.sin(0.1)], axis=1)
+            rng = np.random.default_rng(0)
+            init = np.tile([0.0, 0.0, 0.0, 15.0, 0.1], (Bc, 1))
+            init[:, 1] += rng.uniform(-0.5, 0.5, Bc)
+            init[:, 3] *= rng.uniform(0.9, 1.1, Bc)
+            P_, O_ = np.tile(path, (Bc, 1, 1)), np.full((Bc, L), 0.1)
+            s5.closed_loop(init[:64], P_[:64], O_[:64], np.full(64, 15.0), L)
+            t0 = time.perf_counter()
+            _, _, st_ = s5.closed_loop(init, P_, O_, np.full(Bc, 15.0), L)
+            tcl = time.perf_counter() - t0
+            other_paths["closed_loop"] = dict(ego_steps_per_s=Bc * L / tcl, ms_per_step_of_batch=tcl / L * 1e3, batch=Bc, steps=L, horizon=N_HORIZON,
+                                              converged_frac=float((st_ == 1).mean()),
+                                              note="mpc_closed_loop_batch, nx=5, host buffers in/out once per call (row f1)")
+            sf = mpc_amd.BatchedMPCSolver(10, 5, Q=(2.0, 2.0, 50.0, 0.1, 5.0), R=(2.0, 0.2), P=(4.0, 4.0, 100.0, 0.2, 10.0), device=local_rank)
+            zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 19.0, 0.03495])
+            zb = np.tile(zi, (B, 10, 1))
+            kk = np.arange(1, 11)
+            par = np.tile(np.hstack([np.stack([zi[2] + kk * 2 * np.cos(0.03495), zi[3] + kk * 2 * np.sin(0.03495)], 1), np.full((10, 1), 20.0),
+                                     np.full((10, 1), 0.03495), np.tile([-100.0, 0, -100, 0, -100, 0], (10, 1))]), (B, 1, 1))
+            lbf = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])
+            ubf = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
+            hlf, huf = np.concatenate(([0.0], np.full(9, 1.44))), np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
+            sf.forces_solve(zb[:64], zb[:64, 0, 2:], par[:64], lbf, ubf, hlf, huf)
+            t0 = time.perf_counter()
+            _, fl_, it_, _ = sf.forces_solve(zb, zb[:, 0, 2:], par, lbf, ubf, hlf, huf)
+            tf = time.perf_counter() - t0
+            other_paths["forces_sqp_step"] = dict(solves_per_s=B / tf, ms_per_batch=tf * 1e3, batch=B, horizon=10, solved_frac=float((fl_ == 1).mean()),
+                                                  mean_qp_iterations=float(it_.mean()),
+                                                  note="mpc_forces_solve_batch, host buffers incl. PCIe and per-call allocation (row f3)")
+        except Exception as e:      # never let the side measurements take the bench line down
+            other_paths["error"] = repr(e)
+
     if rank == 0:
         out = dict(metric="MPC steps/sec (N=30, nx=6 nu=2) at batch=4096", value=value, unit="MPC steps/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
@@ -216,7 +257,7 @@ def main():
                                batch_per_gpu=B, horizon=cfg.N, nx=cfg.nx, nu=2, parallelism="independent instances x%d" % world,
                                mode="converged", gpu=torch.cuda.get_device_name(dev)),
                    converged_frac=converged, mean_iters=mean_it, max_iters=max_it, kkt_max=float(kkt.max()),
-                   fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline)
+                   fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, other_paths=other_paths)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
