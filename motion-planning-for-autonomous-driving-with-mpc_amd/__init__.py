@@ -13,6 +13,6 @@ The directory name contains hyphens (it is fixed by the build contract); import 
 at the repository root.
 """
 from ._abi import MpcLibraryError, load_library  # noqa: F401
-from .solver import BatchedMPCSolver, MpcError, SolveResult  # noqa: F401
+from .solver import BatchedMPCSolver, MpcError, SolveResult, rescue_failed  # noqa: F401
 from . import metrics, optimizer, scenario, sharding  # noqa: E402,F401
 from .optimizer import CasadiOptimizer, ForcesproOptimizer  # noqa: E402,F401

@@ -26,7 +26,7 @@ import types
 
 import numpy as np
 
-from .solver import BatchedMPCSolver
+from .solver import BatchedMPCSolver, rescue_failed
 
 # ------------------------------------------------------------------------------------------------------------
 # numeric stand-ins for names the reference's planner pulls in via `from MPC_Planner.optimizer import *`
@@ -113,6 +113,8 @@ class NlpSolverHandle:
     """`ca.nlpsol('solver', 'ipopt', nlp_prob, opts)` look-alike (optimizer.py:558): callable with the same
     keyword arguments as optimizer.py:607.  Accepts a single instance ((n_w,1) / (n_w,)) or a batch [B, n_w]."""
 
+    rescue = True       # failed instances get a second chance by homotopy on the obstacle radius (solver.rescue_failed)
+
     def __init__(self, backend: BatchedMPCSolver):
         self._backend = backend
         self._stats = {}
@@ -128,7 +130,10 @@ class NlpSolverHandle:
         if lbg is not None or lbx is not None or ubg is not None or ubx is not None:
             be.set_bounds(lbx, ubx, lbg, ubg)
         res = be.solve(x0a, pa)
-        self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(),
+        rescued = np.zeros(res.status.shape[0], dtype=bool)
+        if self.rescue and not np.all(res.status == 1) and lbg is not None and lbx is not None and ubg is not None and ubx is not None:
+            res, rescued = rescue_failed(be, x0a, pa, res, (lbx, ubx, lbg, ubg))      # stands in for IPOPT's restoration phase
+        self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(), rescued=rescued,
                            success=bool(np.all(res.status == 1)),
                            return_status="Solve_Succeeded" if np.all(res.status == 1) else "Not_Converged")
         x = res.x if batched else res.x.reshape(-1, 1)

@@ -19,6 +19,9 @@ from . import _abi
 from ._abi import MpcLibraryError, MpcProblemDesc
 
 
+RESCUE_FRACTIONS = (0.0, 0.4, 0.7, 0.9, 1.0)      # of the circle-distance lower bound, see rescue_failed()
+
+
 class MpcError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"mpcgpu error {code}: {msg}")
@@ -87,6 +90,7 @@ class BatchedMPCSolver:
         if lbx is None and ubx is None and lbg is None and ubg is None:
             self._check(self._lib.mpc_set_bounds(self._h, None, None, None, None))
             self._bounds_key = None
+            self._bounds = None
             return
         arrs = [_abi.f64(a).ravel() for a in (lbx, ubx, lbg, ubg)]
         if arrs[0].size != self.n_w or arrs[1].size != self.n_w or arrs[2].size != self.n_g or arrs[3].size != self.n_g:
@@ -96,6 +100,7 @@ class BatchedMPCSolver:
             return
         self._check(self._lib.mpc_set_bounds(self._h, *[_abi.as_dp(a) for a in arrs]))
         self._bounds_key = key
+        self._bounds = tuple(a.copy() for a in arrs)            # (lbx, ubx, lbg, ubg), for rescue_failed()
 
     def solve(self, x0, p, obst=None) -> SolveResult:
         x0 = _abi.f64(x0)
@@ -116,6 +121,18 @@ class BatchedMPCSolver:
         self._check(self._lib.mpc_solve_batch(self._h, B, _abi.as_dp(x0), _abi.as_dp(p), _abi.as_dp(obst), _abi.as_dp(out),
                                               _abi.as_ip(status), _abi.as_ip(iters), _abi.as_dp(kkt)))
         return SolveResult(out, status, iters, kkt)
+
+    def solve_with_rescue(self, x0, p, fractions=RESCUE_FRACTIONS):
+        """solve(); instances that did not converge get a second chance by homotopy on the obstacle radius (rescue_failed).
+        Needs explicit bounds (set_bounds with the four lists).  Returns (SolveResult, rescued mask)."""
+        res = self.solve(x0, p)
+        if np.all(res.status == 1):
+            return res, np.zeros(res.status.shape[0], dtype=bool)
+        if getattr(self, "_bounds", None) is None:
+            raise MpcError(_abi.MPC_ERR_STATE, "solve_with_rescue needs explicit bounds (set_bounds(lbx, ubx, lbg, ubg))")
+        x0 = np.atleast_2d(_abi.f64(x0))
+        p = np.atleast_2d(_abi.f64(p))
+        return rescue_failed(self, x0, p, res, self._bounds, fractions)
 
     def solve_trace(self, x0, p, obst=None):
         x0 = _abi.f64(x0)
@@ -235,4 +252,47 @@ class BatchedMPCSolver:
                     other_ms=out[4], iterations=int(out[5]))
 
 
-__all__ = ["BatchedMPCSolver", "SolveResult", "MpcError", "MpcLibraryError"]
+def rescue_failed(backend, x0, p, result, bounds, fractions=RESCUE_FRACTIONS):
+    """Second chance for the instances of a batch that did not converge (status != 1), by homotopy on the obstacle radius.
+
+    IPOPT hands a start that is locally infeasible -- typically a guess that runs straight through the obstacle, where
+    the linearised circle constraints cannot be met within the fraction-to-the-boundary rule -- to its restoration phase,
+    which is not restated here.  Instead the failed instances are re-solved on the device with the
+    lower bound of the circle-distance rows (`lbg` of the 9 (N+1) obstacle rows, optimizer.py:426-428) raised in steps
+    from 0 to its true value, each solve warm-started from the previous solution; the last solve is the ORIGINAL NLP, so
+    what comes back is a KKT point of the original problem to the original tolerance, or the original failure.
+
+    backend: anything with set_bounds(lbx, ubx, lbg, ubg) and solve(x0, p) -> SolveResult (the BatchedMPCSolver).
+    bounds: the (lbx, ubx, lbg, ubg) of the original problem.  Returns (result, rescued mask)."""
+    status = np.asarray(result.status)
+    bad = np.nonzero(status != 1)[0]
+    rescued = np.zeros(status.shape[0], dtype=bool)
+    if bad.size == 0:
+        return result, rescued
+    lbx, ubx, lbg, ubg = [np.asarray(a, dtype=np.float64).ravel().copy() for a in bounds]
+    n_obst = 9 * (int(backend.N) + 1) if hasattr(backend, "N") else 9 * ((lbg.size - 1) // 14)
+    xs = np.asarray(x0, dtype=np.float64)[bad].copy()
+    ps = np.asarray(p, dtype=np.float64)[bad]
+    iters = np.zeros(bad.size, dtype=np.int64)
+    last = None
+    try:
+        for frac in fractions:
+            lbg_f = lbg.copy()
+            lbg_f[-n_obst:] = frac * lbg[-n_obst:]
+            backend.set_bounds(lbx, ubx, lbg_f, ubg)
+            last = backend.solve(xs, ps)
+            ok = np.asarray(last.status) == 1
+            xs[ok] = np.asarray(last.x)[ok]                       # warm start of the next, tighter problem
+            iters += np.asarray(last.iters)
+    finally:
+        backend.set_bounds(lbx, ubx, lbg, ubg)
+    ok = np.asarray(last.status) == 1
+    x, st, it, kkt = [np.array(a, copy=True) for a in (result.x, result.status, result.iters, result.kkt)]
+    sel = bad[ok]
+    x[sel], st[sel], kkt[sel] = np.asarray(last.x)[ok], 1, np.asarray(last.kkt)[ok]
+    it[sel] = it[sel] + iters[ok]
+    rescued[sel] = True
+    return SolveResult(x, st, it, kkt), rescued
+
+
+__all__ = ["BatchedMPCSolver", "SolveResult", "MpcError", "MpcLibraryError", "rescue_failed", "RESCUE_FRACTIONS"]
