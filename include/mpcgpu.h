@@ -21,6 +21,12 @@
  *                                     (no PCIe traffic; this is what bench.py times).
  *   mpc_plant_step .................. `shift_movement` plant update `x0 + delta_t * f(x0, u[:,0])`
  *                                     (optimizer.py:645-650) / `model.eq` RK4 step (optimizer.py:98,356).
+ *   mpc_closed_loop_batch[_dev] ..... the loop body of `CasadiOptimizer.optimize` between two solves (optimizer.py:596-631,
+ *                                     645-702): first control, plant step, shifted warm start, next reference window.
+ *   mpc_forces_stage_eval ........... `FORCESNLPsolver_casadi2forces` (test/FORCESNLPsolver/FORCESNLPsolver_interface.c:41-198):
+ *                                     FORCES-mode stage cost / RK4 dynamics / inequalities with their derivatives.
+ *   mpc_forces_solve_batch .......... `output, exitflag, info = solver.solve(problem)` of ForcesproOptimizer (optimizer.py:326).
+ *   mpc_metrics_batch ............... deviation.txt / RMSD.txt of MPCPlanner (mpc_planner.py:184-199, 279-292), circle clearance.
  *
  * Conventions (modelled on FORCESNLPsolver.h:117-203): caller-owned plain buffers, int return codes, no
  * exceptions, no callbacks, no globals; the library never keeps a host pointer past the call.
