@@ -160,6 +160,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.fl = hp.fl; P.fu = hp.fu; P.ol = hp.ol; P.ou = hp.ou;
     P.inv_S = (uint32_t)((0x100000000ull + (uint64_t)d.N) / (uint64_t)(d.N + 1));
     P.run_counter = nullptr;
+    P.dec_s = 0;                      // set after the masks below
     P.tile_mask = nullptr;
     P.lo_mask = P.hi_mask = 0;
     for (size_t q = 0; q < hp.LB.size(); ++q) {
@@ -167,6 +168,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
         if (hp.LB[q] > -1e300) P.lo_mask |= 1u << i;
         if (hp.UB[q] < 1e300) P.hi_mask |= 1u << i;
     }
+    P.dec_s = (d.nx == 6 && d.Q[5] == 0.0 && !((P.lo_mask | P.hi_mask) & (1u << 7))) ? 1 : 0;
     P.x0 = nullptr; P.p = nullptr; P.LB = dLB; P.UB = dUB;
     // every array pointer addresses its first row inside tile 0
     P.Z = base + w.Z * 64; P.ZL = base + w.ZL * 64; P.ZU = base + w.ZU * 64;

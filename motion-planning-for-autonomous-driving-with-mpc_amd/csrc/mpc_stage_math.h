@@ -65,8 +65,10 @@ constexpr double EPS10 = 10.0 * 2.220446049250313e-16;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) const double* mpc_lds_cptr;
+typedef __attribute__((address_space(3))) double* mpc_lds_ptr;
 #else
 typedef const double* mpc_lds_cptr;
+typedef double* mpc_lds_ptr;
 #endif
 
 // ---- per-instance scalar rows ----------------------------------------------------------------------------
@@ -87,6 +89,7 @@ struct Params {
     double dt, wheelbase, friction_div, ego_offset, tol;
     double Q[6], R[2], obst[6];
     double fl, fu, ol, ou;       // relaxed slack bounds of the friction / obstacle rows
+    int32_t dec_s;               // nx = 6 with a costless, unbounded progress state: the Riccati sweep may skip it (see ric_matrix_step)
     unsigned long long* tile_mask;   // [tiles] bit l: instance l of the tile was iterating when the last Riccati launch started (stage workgroups with no such instance leave before touching HBM)
     int32_t* run_counter;        // device counter of this launch: += instances still iterating after it (nullptr: none)
     uint32_t inv_S;              // ceil(2^32 / (N+1)): segment -> (row, stage) split of the LDS prefetch
@@ -1388,31 +1391,41 @@ MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>
 // With A = I + dtF (F has 7 nonzeros) the products are organised around W = P+ (dtF), which has only three nonzero
 // columns (delta, v, psi):   A'P+A = P+ + W + W' + (dtF)'W,   P+A = P+ + W,
 // so the 6x6 product P+A is never formed and P_k is accumulated onto P+ (18 + 12 + 12 temporaries instead of 36 + 21).
+// Where a step puts its results.  SINK = false: straight to the workspace in HBM (MPC_UK).  SINK = true: into an LDS
+// staging block `sink` ([row][64 lanes]: gain rows first, then cost-to-go rows; `sink` already points at the lane's
+// column) from which another wavefront writes them out -- a global store costs the issuing wave ~25 cycles during which
+// it issues nothing else (tools/ubench/store_cost.hip), an LDS write ~3.
+#define RIC_PUT_KK(row, v) do { if (SINK) sink[(row) * 64] = (v); else MPC_UK(P.KK, D::NKK, k, (row)) = (v); } while (0)
+#define RIC_PUT_PK(row, v) do { if (SINK) sink[(D::NKK + (row)) * 64] = (v); else MPC_UK(P.PK, D::NPK, k, (row)) = (v); } while (0)
+
 template <int NX>
 struct RicGain {
     double G0[NX], G1[NX], i00, i01, i11;       // G = B'(P+ A) (+ Hux at stage 0), Lam^-1
 };
 
-template <int NX, bool STORE_P>
+// NE < NX (NE = 5 with NX = 6): the progress state s (index 5: s' = v, zero weight, unbounded) is decoupled -- its row and
+// column of the cost-to-go are identically zero as long as no inertia correction is added -- so the recursion runs on NE
+// states and writes explicit zeros where the six-state layout has entries of s.
+template <int NX, bool STORE_P, int NE = NX, bool SINK = false>
 MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
-                            double* Ps, RicGain<NX>& g) {
+                            double* Ps, RicGain<NX>& g, mpc_lds_ptr sink = nullptr) {
     using D = Dim<NX>;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
     // W[i][c] = (P+ dtF)[i][2 + c], c = 0,1,2  (columns delta, v, psi)
     double W[NX][3];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const double pi0 = sym<NX>(Ps, i, 0), pi1 = sym<NX>(Ps, i, 1), pi4 = sym<NX>(Ps, i, 4);
         W[i][0] = pi4 * a42;
         double t = pi0 * a03 + pi1 * a13 + pi4 * a43;
-        if (NX == 6) t += sym<NX>(Ps, i, 5) * dt;
+        if (NE == 6) t += sym<NX>(Ps, i, 5) * dt;
         W[i][1] = t;
         W[i][2] = pi0 * a04 + pi1 * a14;
     }
     // G = B'(P+A) (+ Hux at stage 0) = dt * rows (2,3) of (P+ + W);  Lam = Ruu + B'P+B
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
+    for (int j = 0; j < NE; ++j) {
         double g0 = sym<NX>(Ps, 2, j), g1 = sym<NX>(Ps, 3, j);
         if (j >= 2 && j <= 4) { g0 += W[2][j - 2]; g1 += W[3][j - 2]; }
         g.G0[j] = dt * g0;
@@ -1430,20 +1443,26 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
     g.i00 = L11 * idet; g.i01 = -L01 * idet; g.i11 = L00 * idet;
     double K0[NX], K1[NX];
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
+    for (int j = 0; j < NE; ++j) {
         K0[j] = -(g.i00 * g.G0[j] + g.i01 * g.G1[j]);
         K1[j] = -(g.i01 * g.G0[j] + g.i11 * g.G1[j]);
     }
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-        MPC_UK(P.KK, D::NKK, k, j) = K0[j];
-        MPC_UK(P.KK, D::NKK, k, NX + j) = K1[j];
+        if (j >= NE) { K0[j] = 0.0; K1[j] = 0.0; g.G0[j] = 0.0; g.G1[j] = 0.0; }
+        RIC_PUT_KK(j, K0[j]);
+        RIC_PUT_KK(NX + j, K1[j]);
     }
     // P_k = H + P+ + W + W' + (dtF)'W + G'K, upper triangle, accumulated onto P+
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
         for (int j = i; j < NX; ++j) {
+            if (j >= NE) {                                    // entries of the decoupled state: zero
+                Ps[D::sidx(i, j)] = 0.0;
+                if (STORE_P) RIC_PUT_PK(D::sidx(i, j), 0.0);
+                continue;
+            }
             double t = Ps[D::sidx(i, j)];
             if (D::hrow(i, j) >= 0) t += s.H[D::sidx(i, j)];
             t += g.G0[i] * K0[j] + g.G1[i] * K1[j];
@@ -1452,20 +1471,21 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
             if (i >= 2 && i <= 4 && j >= 2 && j <= 4) {          // ((dtF)'W)[i][j], rows/cols (delta, v, psi)
                 const int cj = j - 2;
                 if (i == 2) t += a42 * W[4][cj];
-                if (i == 3) { t += a03 * W[0][cj] + a13 * W[1][cj] + a43 * W[4][cj]; if (NX == 6) t += dt * W[5][cj]; }
+                if (i == 3) { t += a03 * W[0][cj] + a13 * W[1][cj] + a43 * W[4][cj]; if (NE == 6) t += dt * W[5][cj]; }
                 if (i == 4) t += a04 * W[0][cj] + a14 * W[1][cj];
             }
             if (i == j) t += delta;
             Ps[D::sidx(i, j)] = t;
-            if (STORE_P) MPC_UK(P.PK, D::NPK, k, D::sidx(i, j)) = t;
+            if (STORE_P) RIC_PUT_PK(D::sidx(i, j), t);
         }
     }
     return pd;
 }
 
 // Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
-template <int NX>
-MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, const double* Pn, const RicGain<NX>& g, double* pv) {
+template <int NX, int NE = NX, bool SINK = false>
+MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, const double* Pn, const RicGain<NX>& g, double* pv,
+                            mpc_lds_ptr sink = nullptr) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const double dt = P.dt;
@@ -1473,41 +1493,51 @@ MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<
     // h = p+ - P+ c_{k+1}
     double h[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
+    for (int i = 0; i < NE; ++i) {
         double t = pv[i];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) t -= sym<NX>(Pn, i, j) * s.cn[j];
+        for (int j = 0; j < NE; ++j) t -= sym<NX>(Pn, i, j) * s.cn[j];
         h[i] = t;
     }
     // l = gu + B'h,  kff = -Lam^-1 l
     const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
     const double kf0 = -(g.i00 * l0 + g.i01 * l1), kf1 = -(g.i01 * l0 + g.i11 * l1);
-    MPC_UK(P.KK, D::NKK, k, 2 * NX) = kf0;
-    MPC_UK(P.KK, D::NKK, k, 2 * NX + 1) = kf1;
+    RIC_PUT_KK(2 * NX, kf0);
+    RIC_PUT_KK(2 * NX + 1, kf1);
     // p_k = gx + A'h + G'kff
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
+        if (i >= NE) { pv[i] = 0.0; RIC_PUT_PK(NS + i, 0.0); continue; }
         double t = s.gx[i] + h[i] + g.G0[i] * kf0 + g.G1[i] * kf1;
         if (i == 2) t += a42 * h[4];
-        if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NX == 6) t += dt * h[NX - 1]; }
+        if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NE == 6) t += dt * h[NX - 1]; }
         if (i == 4) t += a04 * h[0] + a14 * h[1];
         pv[i] = t;
-        MPC_UK(P.PK, D::NPK, k, NS + i) = t;
+        RIC_PUT_PK(NS + i, t);
     }
 }
 
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
-template <int NX>
+template <int NX, int NE = NX, bool SINK = false>
 MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
-                                  double hux1, double* Ps, double* pv) {
+                                  double hux1, double* Ps, double* pv, mpc_lds_ptr sink = nullptr) {
     constexpr int NS = Dim<NX>::NS;
     double Pn[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Pn[i] = Ps[i];
     RicGain<NX> g;
-    if (!ric_matrix_step<NX, true>(P, bb, k, s, delta, hux0, hux1, Ps, g)) return false;
-    ric_vector_step<NX>(P, bb, k, s, Pn, g, pv);
+    if (!ric_matrix_step<NX, true, NE, SINK>(P, bb, k, s, delta, hux0, hux1, Ps, g, sink)) return false;
+    ric_vector_step<NX, NE, SINK>(P, bb, k, s, Pn, g, pv, sink);
     return true;
+}
+
+// the step with the decoupled-state shortcut where it applies: six states, flagged by the host, and no inertia correction in
+// this sweep (delta_w would put a nonzero entry on the diagonal of the decoupled state)
+template <int NX>
+MPC_HD bool ric_bwd_any(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
+                        double* Ps, double* pv) {
+    if (NX == 6 && P.dec_s && delta == 0.0) return riccati_backward_step<NX, (NX == 6 ? 5 : NX)>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+    return riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
 }
 
 // stage data of the forward sweep
@@ -1532,17 +1562,24 @@ MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
 }
 
 // one step of the forward sweep: du_k = K dx_k + kff, dx_{k+1} = A dx_k + B du_k - c_{k+1}; stores (du_k, dx_k)
-template <int NX>
-MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
+template <int NX, bool SINK = false>
+MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx, mpc_lds_ptr sink = nullptr) {
     using D = Dim<NX>;
     const double dt = P.dt;
     double du0 = f.kf0, du1 = f.kf1;
 #pragma unroll
     for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
-    MPC_UK(P.DZ, D::NZ, k, 0) = du0;
-    MPC_UK(P.DZ, D::NZ, k, 1) = du1;
+    if (SINK) {
+        sink[0] = du0;
+        sink[64] = du1;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) MPC_UK(P.DZ, D::NZ, k, 2 + i) = dx[i];
+        for (int i = 0; i < NX; ++i) sink[(2 + i) * 64] = dx[i];
+    } else {
+        MPC_UK(P.DZ, D::NZ, k, 0) = du0;
+        MPC_UK(P.DZ, D::NZ, k, 1) = du1;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) MPC_UK(P.DZ, D::NZ, k, 2 + i) = dx[i];
+    }
     double dn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) dn[i] = dx[i] - f.cn[i];
@@ -1591,12 +1628,12 @@ MPC_HD void riccati_instance(const Params& P, int b) {
         int k = N - 1;
         for (; k >= 1; k -= 2) {
             ric_load<NX>(P, b, k - 1, nxt);
-            if (!riccati_backward_step<NX>(P, bb, k, cur, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+            if (!ric_bwd_any<NX>(P, bb, k, cur, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
             if (k >= 2) ric_load<NX>(P, b, k - 2, cur);
-            if (!riccati_backward_step<NX>(P, bb, k - 1, nxt, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+            if (!ric_bwd_any<NX>(P, bb, k - 1, nxt, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
         }
         if (ok && k == 0) {
-            if (!riccati_backward_step<NX>(P, bb, 0, cur, delta, hux0, hux1, Ps, pv)) ok = false;
+            if (!ric_bwd_any<NX>(P, bb, 0, cur, delta, hux0, hux1, Ps, pv)) ok = false;
         }
         if (ok) break;
         if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);

@@ -385,6 +385,8 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
             // ---------------- compute
             bool ok = need;
             double Ps[NS], pv[NX];
+            // decoupled progress state (nx = 6): five-state recursion while no lane of the tile carries an inertia correction
+            const bool dec = NX == 6 && P.dec_s && !__any((need && delta != 0.0) ? 1 : 0);
             for (int t = 0; t <= N; ++t) {
                 const int k = N - t;
                 if (t == 15) RIC_STAMP(3);
@@ -405,7 +407,8 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
                         for (int i = 0; i < NX; ++i) MPC_U(P.PK, pk + NS + i) = pv[i];
                     }
                 } else if (ok) {
-                    ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+                    ok = dec ? riccati_backward_step<NX, (NX == 6 ? 5 : NX)>(P, bb, k, s, delta, hux0, hux1, Ps, pv)
+                             : riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
                 }
                 if (t == 15) RIC_STAMP(5);
             }
@@ -1196,6 +1199,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         h->tile_mask_cap = (size_t)ntiles;
     }
     P.tile_mask = h->d_tile_mask;
+    if (getenv("MPCGPU_NO_DEC")) P.dec_s = 0;
+    if (stage_timing) fprintf(stderr, "[mpcgpu] dec_s=%d lo_mask=%x hi_mask=%x\n", P.dec_s, P.lo_mask, P.hi_mask);
     const bool polled = d.fixed_iters <= 0 && !trace;
     if (polled) {
         if (cap > mpc_handle::MAX_POLL_IT) { h->err = "max_iter exceeds the poll table (1024)"; return MPC_ERR_INVALID; }
