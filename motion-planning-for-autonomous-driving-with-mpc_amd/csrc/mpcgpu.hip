@@ -1199,8 +1199,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         h->tile_mask_cap = (size_t)ntiles;
     }
     P.tile_mask = h->d_tile_mask;
-    if (getenv("MPCGPU_NO_DEC")) P.dec_s = 0;
-    if (stage_timing) fprintf(stderr, "[mpcgpu] dec_s=%d lo_mask=%x hi_mask=%x\n", P.dec_s, P.lo_mask, P.hi_mask);
     const bool polled = d.fixed_iters <= 0 && !trace;
     if (polled) {
         if (cap > mpc_handle::MAX_POLL_IT) { h->err = "max_iter exceeds the poll table (1024)"; return MPC_ERR_INVALID; }
