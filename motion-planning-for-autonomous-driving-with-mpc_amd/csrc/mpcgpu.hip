@@ -385,8 +385,6 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
             // ---------------- compute
             bool ok = need;
             double Ps[NS], pv[NX];
-            // decoupled progress state (nx = 6): five-state recursion while no lane of the tile carries an inertia correction
-            const bool dec = NX == 6 && P.dec_s && !__any((need && delta != 0.0) ? 1 : 0);
             for (int t = 0; t <= N; ++t) {
                 const int k = N - t;
                 if (t == 15) RIC_STAMP(3);
@@ -407,8 +405,7 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
                         for (int i = 0; i < NX; ++i) MPC_U(P.PK, pk + NS + i) = pv[i];
                     }
                 } else if (ok) {
-                    ok = dec ? riccati_backward_step<NX, (NX == 6 ? 5 : NX)>(P, bb, k, s, delta, hux0, hux1, Ps, pv)
-                             : riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+                    ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
                 }
                 if (t == 15) RIC_STAMP(5);
             }
