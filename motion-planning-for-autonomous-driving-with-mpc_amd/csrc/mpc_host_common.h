@@ -142,7 +142,7 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
 
 inline int pick_bx(int N, int max_threads) {
     int bx = 64;
-    while (bx > 8 && bx * (N + 1) > max_threads) bx >>= 1;
+    while (bx > 4 && bx * (N + 1) > max_threads) bx >>= 1;      // N <= 127 (validate_desc): 4 * 128 = 512 threads at most
     return bx;
 }
 

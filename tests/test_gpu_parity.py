@@ -245,3 +245,46 @@ def test_rescue_makes_every_collision_avoidance_cold_start_converge():
         assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6)
     again = s.solve(x0[:64], p[:64])                     # the handle's bounds are the original ones again
     assert np.array_equal(again.x, plain.x[:64])
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 63, 127])
+def test_extreme_horizons_match_oracle(N):
+    """shortest horizons and the largest one the C-ABI accepts (N <= 127: 512-thread stage workgroups, bx = 4...): same
+    iterates as the oracle"""
+    cfg = NLPConfig(N=N, nx=5)
+    B = 40 if N < 100 else 24
+    x0, p = synthetic_batch(cfg, B)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    r = s.solve(x0, p)
+    ro = OracleSolver(cfg).solve_batch(x0, p, nthreads=8)
+    assert np.array_equal(r.status, ro["status"]) and np.array_equal(r.iters, ro["iters"])
+    ok = r.status == 1
+    assert ok.mean() > 0.8 and np.abs(r.x[ok] - ro["x"][ok]).max() < TOL_ORACLE          # (at N = 127 a few of the 12.7 s synthetic problems stall, in the oracle too)
+
+
+def test_bad_inputs_are_contained_and_reported():
+    """NaN / Inf in one instance's inputs: that instance reports -6 (BADFUNCEVAL, FORCESNLPsolver.h:68-106 convention) and its
+    neighbours in the same workgroup and tile are bit-identical to a clean run; argument errors come back as error codes."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 130, **kw)
+    s = make_solver(cfg)
+    clean = s.solve(x0, p)
+    bad_x0, bad_p = x0.copy(), p.copy()
+    bad_x0[9, 2 * cfg.N + 3] = np.nan            # a NaN in the STATE guess is survivable: the start-point safeguard rolls the controls out
+    bad_p[5, 2 * cfg.N + cfg.nx + 1] = np.nan    # reference entries are not
+    bad_p[70, 2 * cfg.N + 2 * cfg.nx] = np.inf
+    r = s.solve(bad_x0, bad_p)
+    assert r.status[5] == -6 and r.status[70] == -6 and r.status[9] == 1
+    assert np.abs(r.x[9] - clean.x[9]).max() < 1e-6
+    keep = np.ones(130, bool)
+    keep[[5, 9, 70]] = False
+    assert np.array_equal(r.x[keep], clean.x[keep]) and np.array_equal(r.status[keep], clean.status[keep])
+    with pytest.raises(pkg.MpcError) as e:
+        s.solve(x0[:, :-1], p[:, :-1])
+    assert e.value.code == abi.MPC_ERR_INVALID
+    L = abi.load_library()
+    h = s._h
+    assert L.mpc_solve_batch(h, 0, abi.as_dp(x0), abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
+    assert L.mpc_solve_batch(h, 4, None, abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
+    assert b"required" in L.mpc_last_error(h)
