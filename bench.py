@@ -135,7 +135,8 @@ def main():
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch
     ab = algorithmic_bytes(cfg.N, cfg.nx)
     solver.set_profiling(True)
-    ric_ms = ric_n = stg_ms = stg_n = 0.0
+    ric_ms = ric_n = stg_ms = stg_n = pipe_ms = pipe_n = 0.0
+    pipe_stats = None
     torch.cuda.synchronize(dev)
     tp0 = time.perf_counter()
     for _ in range(args.steps):
@@ -143,12 +144,19 @@ def main():
         pr = solver.get_profile()
         ric_ms += pr["riccati_ms"]; ric_n += pr["riccati_launches"]
         stg_ms += pr["stage_ms"]; stg_n += pr["stage_launches"]
+        pp = solver.get_pipeline_profile()
+        if pp["ran"]:                                    # all iterations in ONE persistent launch (k_pipeline)
+            pipe_ms += pp["ms"]; pipe_n += 1
+            pipe_stats = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in pp.items()}
     torch.cuda.synchronize(dev)
     prof_ms_per_step = (time.perf_counter() - tp0) / args.steps * 1e3
     solver.set_profiling(False)
     inst_iters = float(it.sum())                         # instance-iterations actually performed per step
     kern = {}
-    for name, ms, n, bpi in (("k_riccati", ric_ms, ric_n, ab["b_riccati"]), ("k_stage", stg_ms, stg_n, ab["b_stage"])):
+    for name, ms, n, bpi in (("k_riccati", ric_ms, ric_n, ab["b_riccati"]), ("k_stage", stg_ms, stg_n, ab["b_stage"]),
+                             ("k_pipeline", pipe_ms, pipe_n, ab["b_riccati"] + ab["b_stage"])):
+        if n == 0:
+            continue
         n_per_step = n / args.steps
         avg_us = ms / max(n, 1) * 1e3
         bytes_per_launch = bpi * inst_iters / max(n_per_step, 1)      # active instances per launch x bytes per instance
@@ -163,7 +171,7 @@ def main():
                     whole_step=dict(bytes_per_mpc_step=ab["b_io"] + mean_it * ab["b_iter"],
                                     gbs=value / world * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9,
                                     frac=value / world * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS),
-                    profiled_ms_per_step=prof_ms_per_step)
+                    profiled_ms_per_step=prof_ms_per_step, pipeline=pipe_stats)
 
     # ---- deterministic-work variant (exactly 20 iterations per instance, no early exit)
     fsolver = make(20)

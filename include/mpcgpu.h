@@ -170,6 +170,13 @@ int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, c
  * out[4] = ms in init + output kernels, out[5] = IPM iterations launched.                                 */
 int mpc_set_profiling(mpc_handle* h, int32_t enable);
 int mpc_get_profile(const mpc_handle* h, double out[6]);
+/* When the last call ran all its iterations in ONE persistent launch (k_pipeline: batches of 1024..8192 instances;
+ * MPCGPU_PIPELINE=0 turns it off) the per-kernel figures above are zero and this reports instead:
+ * out[0] = ms of that launch (profiling enabled only), out[1] = 1 if the pipeline ran (0: one launch per kernel),
+ * out[2] = iterations of the slowest tile, out[3] / out[4] = ms the Riccati / stage workers spent waiting for work,
+ * summed over workers, out[5] = ms the stage workers spent on work items, out[6] = work items processed,
+ * out[7] = stage workers + Riccati workers / 1000.                                                          */
+int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]);
 
 /* debugging: per-iteration per-instance scalars of a host solve.  trace: [max_iter+1, 8, B] doubles
  * rows {mu, theta, phi, alpha, alpha_dual, delta_w, E0, n_trials}; returns iterations launched in *n_it. */

@@ -172,20 +172,18 @@ __device__ __forceinline__ void stage_prefetch(const Params& P, uint32_t b0, cha
 #endif
 }
 
+// One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
+// of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
+// leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
 template <int NX, bool INIT, int MAXT, bool PF>
-__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ int or_slots[2][8];
+__device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
+                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8]) {
     int or_parity = 0;
     constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
-    // workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD gets a contiguous run of instance
-    // columns -- the 64/bx workgroups that share every 128-byte line of a tile then share one L2
-    uint32_t blk = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
-    c.b = (int)((blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + (t & (bx - 1));
+    c.b = (int)b0 + (t & (bx - 1));
     c.valid = (c.k <= P.N) && (c.b < P.B);
     c.active = false;
     c.status = 0;
@@ -193,11 +191,8 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 #define MPC_STAMP(i) do { if (P.DBG && t == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
     if (!INIT) {
-        if (P.tile_mask != nullptr) {                  // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
-            const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
-            const unsigned long long m = P.tile_mask[b0 >> 6] >> (b0 & 63u);
-            if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
-        }
+        const unsigned long long m = tile_bits >> (b0 & 63u);
+        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
     }
     // LDS: [reduction scratch | bounds table | exchange / stash rows | prefetch images]
     double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
@@ -230,7 +225,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
         if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
         // the rows of the update phase stream into LDS while phase 1 and the line search compute (issued only now: the
         // memory system serves requests in no particular order, an earlier issue just competes with the loads above)
-        if (PF) stage_prefetch<NX>(P, (blk + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx, pfb);
+        if (PF) stage_prefetch<NX>(P, b0, pfb);
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX>(P, c, r1);
@@ -281,6 +276,20 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 #undef MPC_STAMP
 }
 
+template <int NX, bool INIT, int MAXT, bool PF>
+__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int or_slots[2][8];
+    // workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD gets a contiguous run of instance
+    // columns -- the 64/bx workgroups that share every 128-byte line of a tile then share one L2
+    uint32_t blk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
+    // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
+    const unsigned long long bits = (!INIT && P.tile_mask != nullptr) ? P.tile_mask[b0 >> 6] : ~0ull;
+    stage_block<NX, INIT, MAXT, PF>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_riccati: block-tridiagonal (Riccati) factor + solve.  One workgroup = one tile of 64 instances = two wavefronts:
 //   wave 1 (loader)  streams the condensed stage blocks HBM -> LDS with asynchronous buffer->LDS DMA (1 KiB per wave
@@ -307,8 +316,10 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
+// instance of the tile is iterating, nothing was touched)
 template <int NX>
-__global__ void __launch_bounds__(192) k_riccati(const Params P) {
+__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
@@ -319,19 +330,16 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
     constexpr int FWD_CHUNKS = KK_CHUNKS + 6;                      // gains + A rows + defect rows
     constexpr uint32_t FSLOT = FWD_CHUNKS * 1024u;
     static_assert(2 * BLK_CHUNKS <= 63 && RIC_DEPTH == 4 && 4 * FWD_CHUNKS <= 63 && RIC_DEPTH_F == 10, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t RING_BYTES = (RIC_DEPTH * SLOT > RIC_DEPTH_F * FSLOT) ? RIC_DEPTH * SLOT : RIC_DEPTH_F * FSLOT;
     int* flag = reinterpret_cast<int*>(smem + RING_BYTES);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x + (uint32_t)P.tile0;
     const int b = (int)(tile * 64u) + lane;
     const uint32_t bb = (uint32_t)b;
     const int N = P.N;
     const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
     const unsigned long long act_mask = __ballot(active ? 1 : 0);
-    if (P.tile_mask != nullptr && threadIdx.x == 0) P.tile_mask[tile] = act_mask;
-    if (!__any(active ? 1 : 0)) return;                             // all waves see the same 64 instances
+    if (act_mask == 0ull) return 0ull;                              // all waves see the same 64 instances
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
@@ -486,6 +494,186 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
     }
     RIC_STAMP(2);
 #undef RIC_STAMP
+    return act_mask;
+#else
+    return 0ull;
+#endif
+}
+
+template <int NX>
+__global__ void __launch_bounds__(192) k_riccati(const Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tile = blockIdx.x + (uint32_t)P.tile0;
+    const unsigned long long act_mask = riccati_tile<NX>(P, tile, smem);
+    // (every lane holds the same mask; the stage kernel that follows reads it with a scalar load)
+    if (P.tile_mask != nullptr && threadIdx.x == 0) P.tile_mask[tile] = act_mask;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_pipeline: ALL iterations of a solve in one launch.  k_riccati is the latency of one 31-stage chain on 64 of the 256
+// CUs, k_stage needs two rounds of whole-CU workgroups; launched back to back, each waits for the other.  Here the two
+// run side by side as roles of one persistent grid (one workgroup per CU) and every tile of 64 instances cycles on its
+// own:   Riccati worker(tile) --ready queue--> 64/bx stage work items --per-tile arrival counter--> Riccati worker ...
+// so the stage workers always have the items of SOME tile to chew on while the others sit in their Riccati chain, and a
+// tile whose instances have all converged simply stops producing items (no batch-wide convergence poll).
+//
+// Hand-off protocol.  A tile's data never leaves one XCD: a workgroup reads the XCD it actually runs on
+// (HW_REG_XCC_ID, not a guess from blockIdx) and serves only the tiles with tile % 8 == that XCD, in the role its
+// arrival order on that XCD gives it.  Producer and consumer of every row therefore share one L2:
+//   producer: plain stores -> s_waitcnt vmcnt(0) (acknowledged by the L2) -> barrier -> agent-scope atomic on the flag
+//   consumer: relaxed agent-scope poll by one lane -> agent-scope acquire (drops this CU's vector L1) -> barrier -> loads
+// The flags themselves (queue slots, counters, abort word) are agent-scope atomics, valid across XCDs.
+// Every spin is bounded: a wait longer than PIPE_SPIN_LIMIT sets the abort word, every worker leaves, and the host
+// re-runs the solve with one launch per kernel (also if the dispatcher leaves an XCD without stage workers).
+// ---------------------------------------------------------------------------------------------------------------
+struct PipeArgs {
+    uint32_t* ctl;          // control block, zeroed before every launch (layout below)
+    uint32_t ntiles;
+    uint32_t n_ric;         // Riccati workers per XCD (the first arrivals)
+    uint32_t cap;           // ready-queue slots per XCD, a power of two >= 2 * items of one XCD
+    uint32_t items;         // stage work items per tile = 64 / bx
+    uint32_t flags;         // bit 0: producers also issue an agent-scope release (MPCGPU_PIPE_RELEASE: the protocol that does not
+                            // rely on a tile staying inside one L2; same results, 10-17 % slower); bit 1: raise the abort word at
+                            // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path)
+};
+constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48
+constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
+constexpr uint32_t PIPE_STATS = PIPE_ABORT + 2;         // [wait ticks riccati, wait ticks stage, busy ticks stage, items, workers stage, workers riccati]
+constexpr uint32_t PIPE_HDR = PIPE_ABORT + 16;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
+constexpr uint32_t PIPE_EXIT = 0xFFFFFFFFu;
+constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-clock ticks = 50 ms
+__host__ __device__ inline uint32_t pipe_slots_off(uint32_t ntiles) { return (PIPE_HDR + ntiles + 1u) & ~1u; }
+__host__ __device__ inline size_t pipe_ctl_words(uint32_t ntiles, uint32_t cap) { return (size_t)pipe_slots_off(ntiles) + (size_t)16 * cap; }
+
+__device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pipe_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t pipe_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NX>
+__global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int or_slots[2][8];
+    __shared__ uint32_t sh_word[4];
+    const int t = threadIdx.x;
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
+    uint32_t* X = A.ctl + xcd * PIPE_X_STRIDE;
+    uint32_t* abort_w = A.ctl + PIPE_ABORT;
+    uint32_t* stage_done = A.ctl + PIPE_HDR;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(A.ctl + pipe_slots_off(A.ntiles)) + (size_t)xcd * A.cap;
+    const uint32_t n_tiles_x = A.ntiles > xcd ? (A.ntiles - xcd + 7u) >> 3 : 0u;            // tiles xcd, xcd + 8, ...
+    if (n_tiles_x == 0u) return;
+    if ((A.flags & 2u) && t == 0) pipe_st(abort_w, 1u);
+    if (t == 0) sh_word[0] = pipe_add(X + 0, 1u);
+    lds_barrier();
+    const uint32_t slot = sh_word[0];
+    const uint32_t n_ric = A.n_ric < n_tiles_x ? A.n_ric : n_tiles_x;
+    lds_barrier();
+    unsigned long long waited = 0;
+    if (slot < n_ric) {
+        // ============================================================ Riccati worker: local tiles slot, slot + n_ric, ...
+        if (t >= 192) return;
+        const uint32_t n_own = (n_tiles_x - slot + n_ric - 1u) / n_ric;
+        uint32_t fin = 0u, round = 0u;
+        for (;; ++round) {
+            bool all_done = true;
+            for (uint32_t j = 0; j < n_own; ++j) {
+                if ((fin >> j) & 1u) continue;
+                all_done = false;
+                const uint32_t tile = (slot + j * n_ric) * 8u + xcd;
+                if (t == 0) {
+                    uint32_t ok = 1u;
+                    const uint32_t need = A.items * round;
+                    const unsigned long long t0 = wall_clock64();
+                    while (pipe_ld(stage_done + tile) < need) {
+                        if (pipe_ld(abort_w)) { ok = 0u; break; }
+                        if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); ok = 0u; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    waited += wall_clock64() - t0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the invalidate has completed before the barrier lets the other waves load
+                    sh_word[1] = ok;
+                }
+                lds_barrier();
+                if (sh_word[1] == 0u) return;
+                const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds));
+                if (mask == 0ull) {
+                    fin |= 1u << j;
+                    if (t == 0) {
+                        atomicMax(A.ctl + PIPE_ABORT + 1, round);
+                        pipe_add(X + 48, 1u);
+                    }
+                } else if (t < 64) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // gains, cost-to-go and the step are in the L2
+                    if (t == 0) {
+                        if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const uint32_t tk = pipe_add(X + 32, A.items);
+                        for (uint32_t q = 0; q < A.items; ++q)
+                            __hip_atomic_store(slots + ((tk + q) & (A.cap - 1u)), ((unsigned long long)(tk + q + 1u) << 32) | (unsigned long long)((tile << 8) | q),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                lds_barrier();                     // the rings are free again
+            }
+            if (all_done) break;
+        }
+        if (t == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS) + 0, waited); pipe_add(A.ctl + PIPE_STATS + 11, 1u); }
+        return;
+    }
+    // ================================================================ stage worker: pulls (tile, sub-block) items of its XCD
+    unsigned long long busy = 0;
+    uint32_t n_items = 0;
+    for (;;) {
+        if (t == 0) {
+            const uint32_t tk = pipe_add(X + 16, 1u);
+            const unsigned long long* sl = slots + (tk & (A.cap - 1u));
+            uint32_t item = PIPE_EXIT;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) == tk + 1u) { item = (uint32_t)v; break; }
+                if (pipe_ld(X + 48) >= n_tiles_x || pipe_ld(abort_w)) break;             // every tile of this XCD is finished: nothing can arrive
+                if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const unsigned long long t1 = wall_clock64();
+            waited += t1 - t0;
+            busy -= t1;
+            unsigned long long bits = 0ull;
+            if (item != PIPE_EXIT) {
+                bits = __hip_atomic_load(P.tile_mask + (item >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            sh_word[1] = item;
+            sh_word[2] = (uint32_t)bits;
+            sh_word[3] = (uint32_t)(bits >> 32);
+        }
+        lds_barrier();
+        const uint32_t item = sh_word[1];
+        const unsigned long long bits = ((unsigned long long)sh_word[3] << 32) | sh_word[2];
+        if (item == PIPE_EXIT) break;
+        const uint32_t tile = item >> 8;
+        stage_block<NX, false, 256, false>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
+        lds_barrier();
+        if (t == 0) {
+            if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            pipe_add(stage_done + tile, 1u);
+            busy += wall_clock64();
+            ++n_items;
+        }
+    }
+    if (t == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS);
+        atomicAdd(st + 1, waited);
+        atomicAdd(st + 2, busy + wall_clock64());
+        atomicAdd(st + 3, (unsigned long long)n_items);
+        pipe_add(A.ctl + PIPE_STATS + 10, 1u);
+    }
 #endif
 }
 
@@ -876,6 +1064,11 @@ struct mpc_handle {
     double* d_state = nullptr;         // [B,5] plant state of the closed-loop driver
     size_t cap_state = 0;
     size_t tile_mask_cap = 0;
+    uint32_t* d_pipe = nullptr;        // control block of the single-launch pipeline (k_pipeline)
+    size_t pipe_words = 0;
+    uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (16 words)
+    bool pipe_disabled = false;        // set when a pipeline launch had to be abandoned (see k_pipeline)
+    int last_mode = 0;                 // 0: one launch per kernel and iteration, 1: single-launch pipeline
     int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
     int32_t* h_counter = nullptr;      // pinned, [MAX_GROUPS][2] (double-buffered per poll)
     hipEvent_t ev_poll[4][2] = {};
@@ -892,6 +1085,8 @@ struct mpc_handle {
     // profiling
     bool profiling = false;
     double prof[6] = {0, 0, 0, 0, 0, 0};
+    double pipe_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // k_pipeline: ms (profiling only), launches, rounds, Riccati-wait / stage-wait / stage-busy ms summed over workers, items, stage workers + riccati workers / 1000
+    int n_cu = 256;
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -953,6 +1148,10 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
         delete h;
         return MPC_ERR_HIP;
     }
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->n_cu = ncu;
+    }
     bool ok_streams = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g)
         for (int q = 0; q < 2; ++q) ok_streams = ok_streams && hipEventCreateWithFlags(&h->ev_poll[g][q], hipEventDisableTiming) == hipSuccess;
@@ -974,6 +1173,8 @@ int mpc_destroy(mpc_handle* h) {
     if (h->d_LB) (void)hipFree(h->d_LB);
     if (h->d_UB) (void)hipFree(h->d_UB);
     if (h->d_counter) (void)hipFree(h->d_counter);
+    if (h->d_pipe) (void)hipFree(h->d_pipe);
+    if (h->h_pipe) (void)hipHostFree(h->h_pipe);
     if (h->d_tile_mask) (void)hipFree(h->d_tile_mask);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
@@ -1005,6 +1206,12 @@ int mpc_set_bounds(mpc_handle* h, const double* lbx, const double* ubx, const do
 int mpc_set_profiling(mpc_handle* h, int32_t enable) {
     if (!h) return MPC_ERR_INVALID;
     h->profiling = enable != 0;
+    return MPC_OK;
+}
+
+int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]) {
+    if (!h || !out) return MPC_ERR_INVALID;
+    for (int i = 0; i < 8; ++i) out[i] = h->pipe_prof[i];
     return MPC_OK;
 }
 
@@ -1056,6 +1263,7 @@ struct Prof {
             (void)hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
             if (kinds[i] == 0) { h->prof[0] += ms; h->prof[1] += 1; }
             else if (kinds[i] == 1) { h->prof[2] += ms; h->prof[3] += 1; }
+            else if (kinds[i] == 3) h->pipe_prof[0] += ms;
             else h->prof[4] += ms;
         }
     }
@@ -1111,6 +1319,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             attr_set[NX - 5] = true;
         }
     }
@@ -1206,7 +1415,61 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         }
     }
     int it = 0, chunk_id = 0;
-    while (it < cap) {
+    // ---- single-launch pipeline (k_pipeline): all iterations in one persistent grid, tiles cycling independently.
+    // Pays while the Riccati chain is latency bound (few tiles per CU); larger batches keep one launch per kernel.
+    h->last_mode = 0;
+    for (int i = 0; i < 8; ++i) h->pipe_prof[i] = 0;
+    bool piped = false;
+    {
+        const char* env = getenv("MPCGPU_PIPELINE");
+        const int tiles_x = (ntiles + 7) / 8;
+        int n_ric = std::min(8, tiles_x);
+        if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(16, tiles_x)));
+        const bool eligible = G == 1 && !trace && !stage_timing && small_wg && !use_pf && threads >= 192 && threads <= 256 &&
+                              ntiles >= 16 && ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
+                              std::max(lds_bytes, ric_lds) <= lds_max;
+        // (measured at B = 8192: the early finishers of converged mode still gain 15 %, a fixed iteration count loses 8 % --
+        //  with two tiles per Riccati worker both roles are throughput bound and the split of the CUs only costs)
+        if (eligible && !h->pipe_disabled && !(env && env[0] == '0')) {
+            PipeArgs A;
+            A.ntiles = (uint32_t)ntiles;
+            A.n_ric = (uint32_t)n_ric;
+            A.items = 64u / (uint32_t)bx;
+            A.cap = 1;
+            while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
+            A.flags = (getenv("MPCGPU_PIPE_RELEASE") != nullptr ? 1u : 0u) | (getenv("MPCGPU_PIPE_TEST_ABORT") != nullptr ? 2u : 0u);
+            const size_t words = pipe_ctl_words(A.ntiles, A.cap);
+            if (h->pipe_words < words) {
+                if (h->d_pipe) (void)hipFree(h->d_pipe);
+                h->d_pipe = nullptr; h->pipe_words = 0;
+                HIP_TRY(h, hipMalloc(&h->d_pipe, words * sizeof(uint32_t)));
+                h->pipe_words = words;
+            }
+            if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 16 * sizeof(uint32_t)));
+            A.ctl = h->d_pipe;
+            HIP_TRY(h, hipMemsetAsync(h->d_pipe, 0, words * sizeof(uint32_t), stream));
+            prof.begin(3, stream);
+            hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            prof.end(stream);
+            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(h, hipStreamSynchronize(stream));
+            if (h->h_pipe[0] != 0u) {
+                // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
+                // through an iteration, so start over with one launch per kernel -- and stay there for this handle
+                h->pipe_disabled = true;
+                fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired); re-running with one launch per kernel\n");
+                return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
+            }
+            piped = true;
+            h->last_mode = 1;
+            it = (int)h->h_pipe[1];
+            const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(h->h_pipe + 2);
+            h->pipe_prof[1] = 1; h->pipe_prof[2] = it;
+            h->pipe_prof[3] = (double)st64[0] * 1e-5; h->pipe_prof[4] = (double)st64[1] * 1e-5; h->pipe_prof[5] = (double)st64[2] * 1e-5;   // 100 MHz ticks -> ms
+            h->pipe_prof[6] = (double)st64[3]; h->pipe_prof[7] = (double)h->h_pipe[12] + 1e-3 * (double)h->h_pipe[13];
+        }
+    }
+    while (!piped && it < cap) {
         const int n = std::min(trace ? 1 : chunk, cap - it);
         bool any = false;
         for (int j = 0; j < n; ++j) {

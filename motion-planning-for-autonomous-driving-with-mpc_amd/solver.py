@@ -251,6 +251,14 @@ class BatchedMPCSolver:
         return dict(riccati_ms=out[0], riccati_launches=int(out[1]), stage_ms=out[2], stage_launches=int(out[3]),
                     other_ms=out[4], iterations=int(out[5]))
 
+    def get_pipeline_profile(self):
+        """Figures of the single-launch pipeline (k_pipeline) for the last solve; `ran` is False when the solve used one
+        launch per kernel instead (small or very large batches, MPCGPU_PIPELINE=0)."""
+        out = np.zeros(8)
+        self._check(self._lib.mpc_get_pipeline_profile(self._h, _abi.as_dp(out)))
+        return dict(ms=out[0], ran=bool(out[1]), rounds=int(out[2]), riccati_wait_ms=out[3], stage_wait_ms=out[4],
+                    stage_busy_ms=out[5], items=int(out[6]), stage_workers=int(out[7]), riccati_workers=int(round((out[7] % 1) * 1000)))
+
 
 def rescue_failed(backend, x0, p, result, bounds, fractions=RESCUE_FRACTIONS):
     """Second chance for the instances of a batch that did not converge (status != 1), by homotopy on the obstacle radius.

@@ -72,6 +72,63 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
     assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+def _same(a, b):
+    return np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters) and np.array_equal(a.status, b.status) and np.array_equal(a.kkt, b.kkt)
+
+
+@pytest.mark.parametrize("B,fixed", [(4096, 0), (4096, 20), (1000, 0), (2048 + 17, 0), (8192, 0)])
+def test_single_launch_pipeline_is_bit_identical(B, fixed, monkeypatch):
+    """k_pipeline (all iterations in one persistent launch, tiles cycling independently between Riccati and stage workers)
+    runs the same per-instance arithmetic as one launch per kernel and iteration: bit-identical results, and it is the
+    path that actually ran."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    ref = s.solve(x0, p)
+    assert not s.get_pipeline_profile()["ran"]
+    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    for _ in range(3):                       # repeated: the hand-offs must not depend on what the caches hold from the last solve
+        alt = s.solve(x0, p)
+        pp = s.get_pipeline_profile()
+        assert pp["ran"] and pp["rounds"] == int(ref.iters.max()) and pp["stage_workers"] > 0 and pp["riccati_workers"] > 0
+        assert _same(alt, ref)
+
+
+def test_single_launch_pipeline_on_collision_avoidance(monkeypatch):
+    """long nonconvex solves (up to max_iter, inertia corrections, failures): the tiles of a batch finish tens of
+    iterations apart, which is what the pipeline is for; results stay bit-identical"""
+    B = 1024
+    x0, p = ca_batch(CA_CFG, B)
+    s = make_solver(CA_CFG)
+    set_cfg_bounds(s, CA_CFG)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    ref = s.solve(x0, p)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    alt = s.solve(x0, p)
+    assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
+
+
+def test_pipeline_release_protocol_and_restart(monkeypatch):
+    """(1) MPCGPU_PIPE_RELEASE adds agent-scope releases on the producers (the hand-off that does not rely on a tile
+    staying inside one XCD's L2): same bits.  (2) MPCGPU_PIPE_TEST_ABORT raises the pipeline's abort word: the host
+    must notice, start over with one launch per kernel from the untouched inputs, and stay on that path."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 2048, **kw)
+    s = make_solver(cfg)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    ref = s.solve(x0, p)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    monkeypatch.setenv("MPCGPU_PIPE_RELEASE", "1")
+    assert _same(s.solve(x0, p), ref) and s.get_pipeline_profile()["ran"]
+    monkeypatch.delenv("MPCGPU_PIPE_RELEASE")
+    monkeypatch.setenv("MPCGPU_PIPE_TEST_ABORT", "1")
+    assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]
+    monkeypatch.delenv("MPCGPU_PIPE_TEST_ABORT")
+    assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]      # this handle stays on the per-kernel path
+    assert _same(make_solver(cfg).solve(x0, p), ref)
+
+
 def test_full_size_batch_properties():
     """BASELINE metric size: N = 30, nx = 6, B = 4096.  Size-independent properties: every instance converged;
     permuting instances permutes results bit-exactly; splitting the batch changes nothing; the returned points

@@ -21,7 +21,7 @@ def main(d, json_out=None):
                 short = name.replace("void (anonymous namespace)::", "").split("(")[0]
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k in sorted(acc, key=lambda k: -len(acc[k])):
-        if not ("k_stage" in k or "k_riccati" in k):
+        if not ("k_stage" in k or "k_riccati" in k or "k_pipeline" in k):
             continue
         print(f"== {k}")
         for c, v in sorted(acc[k].items()):
@@ -37,7 +37,8 @@ def main(d, json_out=None):
         for k, cs in acc.items():
             if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
                 continue
-            name = "k_stage" if "k_stage" in k and "true" not in k.split(",")[1] else ("k_riccati" if "k_riccati" in k else None)
+            name = ("k_stage" if "k_stage" in k and "true" not in k.split(",")[1] else
+                    "k_riccati" if "k_riccati" in k else "k_pipeline" if "k_pipeline" in k else None)
             if name is None:
                 continue
 
