@@ -177,7 +177,7 @@ __device__ __forceinline__ void stage_prefetch(const Params& P, uint32_t b0, cha
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
 template <int NX, bool INIT, int MAXT, bool PF>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
-                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8]) {
+                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true) {
     int or_parity = 0;
     constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     c.active = false;
     c.status = 0;
     c.iters = 0;
-#define MPC_STAMP(i) do { if (P.DBG && t == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
     if (!INIT) {
         const unsigned long long m = tile_bits >> (b0 & 63u);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
 // instance of the tile is iterating, nothing was touched)
 template <int NX>
-__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem) {
+__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem, const bool stamp = true) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
@@ -340,7 +340,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
     const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
     const unsigned long long act_mask = __ballot(active ? 1 : 0);
     if (act_mask == 0ull) return 0ull;                              // all waves see the same 64 instances
-#define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
     const uint32_t tile_off = tile * P.tile_elems * 8u;
@@ -570,6 +570,9 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
     const uint32_t n_ric = A.n_ric < n_tiles_x ? A.n_ric : n_tiles_x;
     lds_barrier();
     unsigned long long waited = 0;
+    // (profiling aid: stamps of the worker's 6th pass / item only -- later ones would overwrite them)
+    uint32_t n_pass = 0;
+#define PIPE_STAMP(i) do { if (P.DBG && t == 0 && n_pass == 5u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (slot < n_ric) {
         // ============================================================ Riccati worker: local tiles slot, slot + n_ric, ...
         if (t >= 192) return;
@@ -581,6 +584,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                 if ((fin >> j) & 1u) continue;
                 all_done = false;
                 const uint32_t tile = (slot + j * n_ric) * 8u + xcd;
+                PIPE_STAMP(11);
                 if (t == 0) {
                     uint32_t ok = 1u;
                     const uint32_t need = A.items * round;
@@ -597,7 +601,8 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                 }
                 lds_barrier();
                 if (sh_word[1] == 0u) return;
-                const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds));
+                PIPE_STAMP(12);
+                const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds), n_pass == 5u);
                 if (mask == 0ull) {
                     fin |= 1u << j;
                     if (t == 0) {
@@ -616,6 +621,8 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                PIPE_STAMP(13);
+                ++n_pass;
                 lds_barrier();                     // the rings are free again
             }
             if (all_done) break;
@@ -627,6 +634,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
     unsigned long long busy = 0;
     uint32_t n_items = 0;
     for (;;) {
+        PIPE_STAMP(11);
         if (t == 0) {
             const uint32_t tk = pipe_add(X + 16, 1u);
             const unsigned long long* sl = slots + (tk & (A.cap - 1u));
@@ -640,6 +648,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                 __builtin_amdgcn_s_sleep(8);
             }
             const unsigned long long t1 = wall_clock64();
+            PIPE_STAMP(12);
             waited += t1 - t0;
             busy -= t1;
             unsigned long long bits = 0ull;
@@ -656,17 +665,22 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
         const uint32_t item = sh_word[1];
         const unsigned long long bits = ((unsigned long long)sh_word[3] << 32) | sh_word[2];
         if (item == PIPE_EXIT) break;
+        PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-        stage_block<NX, false, 256, false>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots);
+        stage_block<NX, false, 256, false>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
         lds_barrier();
+        PIPE_STAMP(14);
         if (t == 0) {
             if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             pipe_add(stage_done + tile, 1u);
             busy += wall_clock64();
             ++n_items;
         }
+        PIPE_STAMP(15);
+        ++n_pass;
     }
+#undef PIPE_STAMP
     if (t == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS);
         atomicAdd(st + 1, waited);
@@ -1426,10 +1440,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         int n_ric = std::min(8, tiles_x);
         if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(16, tiles_x)));
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && !use_pf && threads >= 192 && threads <= 256 &&
-                              ntiles >= 16 && ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
+                              ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
-        // (measured at B = 8192: the early finishers of converged mode still gain 15 %, a fixed iteration count loses 8 % --
-        //  with two tiles per Riccati worker both roles are throughput bound and the split of the CUs only costs)
+        // (measured: 7-11 % faster than one launch per kernel at B = 64 ... 1024, 31 % at B = 4096; at B = 8192 the early
+        //  finishers of converged mode still gain 15 %, a fixed iteration count loses 8 % -- with two tiles per Riccati
+        //  worker both roles are throughput bound and the split of the CUs only costs)
         if (eligible && !h->pipe_disabled && !(env && env[0] == '0')) {
             PipeArgs A;
             A.ntiles = (uint32_t)ntiles;
@@ -1448,6 +1463,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 16 * sizeof(uint32_t)));
             A.ctl = h->d_pipe;
             HIP_TRY(h, hipMemsetAsync(h->d_pipe, 0, words * sizeof(uint32_t), stream));
+            unsigned long long* d_pdbg = nullptr;
+            if (getenv("MPCGPU_PIPE_TIMING")) {
+                HIP_TRY(h, hipMalloc(&d_pdbg, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
+                HIP_TRY(h, hipMemsetAsync(d_pdbg, 0, sizeof(unsigned long long) * 16 * (size_t)h->n_cu, stream));
+                P.DBG = d_pdbg;
+            }
             prof.begin(3, stream);
             hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
@@ -1459,6 +1480,32 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 h->pipe_disabled = true;
                 fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired); re-running with one launch per kernel\n");
                 return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
+            }
+            P.DBG = nullptr;
+            if (d_pdbg) {       // shader-clock stamps of every worker's LAST work item / tile pass
+                std::vector<unsigned long long> hd((size_t)16 * h->n_cu);
+                HIP_TRY(h, hipMemcpy(hd.data(), d_pdbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                (void)hipFree(d_pdbg);
+                double sa[16] = {0}, ra[4] = {0};
+                int ns = 0, nr = 0;
+                for (int bq = 0; bq < h->n_cu; ++bq) {
+                    const unsigned long long* r = hd.data() + (size_t)bq * 16;
+                    if (r[15] && r[10]) {
+                        const int order[16] = {11, 12, 13, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15};
+                        for (int q = 0; q + 1 < 16; ++q) sa[q] += (double)(long long)(r[order[q + 1]] - r[order[q]]);
+                        ++ns;
+                    } else if (r[13] && r[2]) {
+                        ra[0] += (double)(long long)(r[12] - r[11]); ra[1] += (double)(long long)(r[1] - r[12]);
+                        ra[2] += (double)(long long)(r[2] - r[1]); ra[3] += (double)(long long)(r[13] - r[2]);
+                        ++nr;
+                    }
+                }
+                static const char* sn[15] = {"dequeue", "acquire+bcast", "enter", "issue-loads", "wait+barrier", "P1", "reduce1", "linesearch", "P3-update",
+                                             "exchange", "P4-eval", "reduce3", "P5", "drain", "signal"};
+                fprintf(stderr, "[mpcgpu pipeline timing, shader-clock ticks, last item of %d stage workers]", ns);
+                for (int q = 0; q < 15; ++q) fprintf(stderr, " %s=%.0f", sn[q], ns ? sa[q] / ns : 0.0);
+                fprintf(stderr, "\n[last pass of %d Riccati workers] wait=%.0f backward=%.0f forward=%.0f publish=%.0f\n", nr, nr ? ra[0] / nr : 0.0,
+                        nr ? ra[1] / nr : 0.0, nr ? ra[2] / nr : 0.0, nr ? ra[3] / nr : 0.0);
             }
             piped = true;
             h->last_mode = 1;
