@@ -109,29 +109,31 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
 }
 
 // ---- workspace: one allocation of doubles + one of int32, tile-major [tile of 64 instances][row][64 lanes] --------
-// WsLayout members are ROW offsets inside a tile; element(row, b) = (b >> 6) * tile_elems + row * 64 + (b & 63).
+// WsLayout members are ROW offsets inside a tile (all even: rows are stored in pairs, see mpc_prow in mpc_stage_math.h);
+// element(row, b) = (b >> 6) * tile_elems + mpc_prow(row) + 2 * (b & 63).
 struct WsLayout {
     size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, EV, ROLL, SC, FILT, OBST;
     size_t rows, irows;          // rows per tile (double / int32 workspace)
     size_t tile_elems, itile_elems, ntiles;
     size_t total, itotal;        // elements to allocate
-    size_t elem(size_t row0, size_t row, size_t b) const { return (b >> 6) * tile_elems + (row0 + row) * 64 + (b & 63); }
-    size_t ielem(size_t row, size_t b) const { return (b >> 6) * itile_elems + row * 64 + (b & 63); }
+    size_t elem(size_t row0, size_t row, size_t b) const { return (b >> 6) * tile_elems + mpc_prow((uint32_t)(row0 + row)) + (b & 63) * 2; }
+    size_t ielem(size_t row, size_t b) const { return (b >> 6) * itile_elems + mpc_prow((uint32_t)row) + (b & 63) * 2; }
 };
 
 inline WsLayout ws_layout(int N, int nx, size_t Bp) {
-    const size_t NZ = nx + 2, NS = (size_t)nx * (nx + 1) / 2, S = N + 1;
-    const size_t NBLK = (nx + 5) + 10 + 2 * nx, NPK = NS + nx, NKK = 2 * nx + 2;      // Dim<NX>::NBLK: sparse H (NX + 5 entries)
+    const size_t NS = (size_t)nx * (nx + 1) / 2, S = N + 1;
+    auto ev = [](size_t r) { return (r + 1) & ~(size_t)1; };                          // MPC_EV: whole row pairs per stage
+    const size_t NZ = ev(nx + 2), XS = ev(nx), NBLK = ev((nx + 5) + 10 + 2 * nx), NPK = ev(NS + nx), NKK = 2 * nx + 2;   // Dim<NX>::NBLK: sparse H (NX + 5 entries)
     WsLayout w{};
     size_t off = 0;
-    auto take = [&](size_t rows) { const size_t o = off; off += rows; return o; };
+    auto take = [&](size_t rows) { const size_t o = off; off += ev(rows); return o; };
     w.Z = take(S * NZ); w.ZL = take(S * NZ); w.ZU = take(S * NZ);
-    w.SO = take(S * 3); w.NUO = take(S * 3); w.ZLO = take(S * 3); w.ZUO = take(S * 3);
-    w.LAM = take(S * nx); w.REF = take(S * nx); w.DZ = take(S * NZ);
-    w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.EV = take(S * 12); w.ROLL = take(S * nx);
+    w.SO = take(S * 4); w.NUO = take(S * 4); w.ZLO = take(S * 4); w.ZUO = take(S * 4);
+    w.LAM = take(S * XS); w.REF = take(S * XS); w.DZ = take(S * NZ);
+    w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.EV = take(0); w.ROLL = take(S * XS);
     w.SC = take(SC_COUNT); w.FILT = take(2 * FILTER_MAX); w.OBST = take(6);
     w.rows = off;
-    w.irows = IS_COUNT;
+    w.irows = ev(IS_COUNT);
     w.tile_elems = w.rows * 64;
     w.itile_elems = w.irows * 64;
     w.ntiles = Bp / 64;

@@ -124,9 +124,18 @@ struct Params {
     double* kkt_out;
 };
 
+// Layout of a tile of 64 instances: rows come in PAIRS, interleaved per instance -- rows 2j and 2j+1 of an array are
+// the two halves of one 16-byte element per lane, [row pair][instance][2].  A thread that touches rows e and e+1
+// (e even) of its instance does so with ONE 16-byte access (the compiler merges the two 8-byte buffer operations, their
+// immediates differ by 8), the bx = 8 instance columns of a stage workgroup are a full 128-byte line per (row pair,
+// stage), and the Riccati wave writes 1 KiB per store instruction.  Every array starts on a pair boundary and every
+// per-stage row count is padded to an even number (MPC_EV), so that the parity of a row is the parity of its
+// within-stage index, a compile-time literal at every hot call site.
+#define MPC_EV(R) ((((uint32_t)(R)) + 1u) & ~1u)
+MPC_HD constexpr uint32_t mpc_prow(uint32_t r) { return (r & ~1u) * 64u + (r & 1u); }      // element offset of row r (instance 0) inside its array
 // element index of (row, instance b) relative to the first row of an array, tile-major layout
-MPC_HD uint32_t ws_index(const Params& P, const double*, uint32_t row, uint32_t b) { return (b >> 6) * P.tile_elems + row * 64u + (b & 63u); }
-MPC_HD uint32_t ws_index(const Params& P, const int32_t*, uint32_t row, uint32_t b) { return (b >> 6) * P.itile_elems + row * 64u + (b & 63u); }
+MPC_HD uint32_t ws_index(const Params& P, const double*, uint32_t row, uint32_t b) { return (b >> 6) * P.tile_elems + mpc_prow(row) + (b & 63u) * 2u; }
+MPC_HD uint32_t ws_index(const Params& P, const int32_t*, uint32_t row, uint32_t b) { return (b >> 6) * P.itile_elems + mpc_prow(row) + (b & 63u) * 2u; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int mpc_v2u __attribute__((ext_vector_type(2)));
@@ -169,34 +178,82 @@ struct WsRefI {          // element of the int32 workspace
         return x;
     }
 };
+// rows e (even) and e + 1 of one instance in ONE 16-byte access; `r` refers to row e
+typedef unsigned int mpc_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ws_load2(const WsRefD& r, double& lo, double& hi) {
+    const __amdgpu_buffer_rsrc_t d = mpc_rsrc(r.P.WS, r.P.ws_bytes);
+    const mpc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(d, (int)r.voff, mpc_uni(r.aoff + r.uoff), 0);
+    lo = __builtin_bit_cast(double, mpc_v2u{v.x, v.y});
+    hi = __builtin_bit_cast(double, mpc_v2u{v.z, v.w});
+}
+// NOTE the scalar offset goes into the VECTOR offset here and soffset stays the constant 0.  A buffer store of more than
+// 64 bits still reads its data registers for a few cycles after issue; a VALU instruction that overwrites one of them
+// right behind it corrupts the last lanes read (observed on gfx950: lanes 12-15 of every 16, timing dependent).  The
+// compiler inserts the wait states for this hazard only when soffset is NOT a register (GCNHazardRecognizer follows the
+// older ISA manuals, which exempt the SGPR-soffset form) -- with an SGPR soffset it scheduled `v_add_u32 v18, ...`
+// directly behind `buffer_store_dwordx4 v[18:21], ...`.
+__device__ __forceinline__ void ws_store2(const WsRefD& r, double lo, double hi) {
+    const __amdgpu_buffer_rsrc_t d = mpc_rsrc(r.P.WS, r.P.ws_bytes);
+    const mpc_v2u a = __builtin_bit_cast(mpc_v2u, lo), b = __builtin_bit_cast(mpc_v2u, hi);
+    __builtin_amdgcn_raw_buffer_store_b128(mpc_v4u{a.x, a.y, b.x, b.y}, d, (int)(r.voff + (uint32_t)mpc_uni(r.aoff + r.uoff)), 0, 0);
+}
+#define MPC_LD2(ref, lo, hi) ws_load2((ref), (lo), (hi))
+#define MPC_ST2(ref, lo, hi) ws_store2((ref), (lo), (hi))
 // uni: uniform element offset (-> scalar/immediate offset), b: instance, extra: further per-lane elements
 __device__ __forceinline__ WsRefD ws_ref3(const Params& P, const double* arr, uint32_t uni, uint32_t b, uint32_t extra) {
-    return WsRefD{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.WS, uni * 8u, ((b >> 6) * P.tile_elems + (b & 63u) + extra) * 8u};
+    return WsRefD{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.WS, uni * 8u, ((b >> 6) * P.tile_elems + (b & 63u) * 2u + extra) * 8u};
 }
 __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, uint32_t uni, uint32_t b, uint32_t extra) {
-    return WsRefI{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.IWS + uni * 4u, ((b >> 6) * P.itile_elems + (b & 63u) + extra) * 4u};
+    return WsRefI{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.IWS + uni * 4u, ((b >> 6) * P.itile_elems + (b & 63u) * 2u + extra) * 4u};
 }
 // accessors: (array, uniform element offset -> SGPR soffset / immediate, per-lane element offset -> VGPR voffset)
 //   MPC_K(arr, R, dk, e)  stage kernel: row (k + dk) * R + e of thread c (k per lane, e and dk uniform)
 //   MPC_S(arr, row)       per-instance scalar row (row uniform) of thread c
 //   MPC_SD(arr, row)      same, row may differ between lanes
 //   MPC_U(arr, row)       instance-per-thread kernels (a wavefront = one tile): uniform row, instance `bb` in scope
-#define MPC_K(ptr, R, dk, e) ws_ref3(P, (ptr), ((uint32_t)(dk) * (uint32_t)(R) + (uint32_t)(e)) * 64u, (uint32_t)c.b, (uint32_t)c.k * ((uint32_t)(R) * 64u))
-#define MPC_S(ptr, row) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)c.b, 0u)
-#define MPC_SD(ptr, row) ws_ref3(P, (ptr), 0u, (uint32_t)c.b, (uint32_t)(row) * 64u)
-#define MPC_U(ptr, row) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)bb, 0u)
-#define MPC_UB(ptr, row, b_) ws_ref3(P, (ptr), (uint32_t)(row) * 64u, (uint32_t)(b_), 0u)
-//   MPC_UK(arr, R, k, e)  same kernels, row k * R + e with a loop-variant stage k and a literal e: ONE scalar offset per
-//                         (array, stage), the literal goes into the instruction's immediate / a hoisted lane offset
-#define MPC_UK(ptr, R, k_, e) ws_ref3(P, (ptr), (uint32_t)(k_) * ((uint32_t)(R) * 64u), (uint32_t)bb, (uint32_t)(e) * 64u)
+#define MPC_K(ptr, R, dk, e) ws_ref3(P, (ptr), (uint32_t)(dk) * (MPC_EV(R) * 64u) + mpc_prow((uint32_t)(e)), (uint32_t)c.b, (uint32_t)c.k * (MPC_EV(R) * 64u))
+#define MPC_S(ptr, row) ws_ref3(P, (ptr), mpc_prow((uint32_t)(row)), (uint32_t)c.b, 0u)
+#define MPC_SD(ptr, row) ws_ref3(P, (ptr), 0u, (uint32_t)c.b, mpc_prow((uint32_t)(row)))
+#define MPC_U(ptr, row) ws_ref3(P, (ptr), mpc_prow((uint32_t)(row)), (uint32_t)bb, 0u)
+#define MPC_UB(ptr, row, b_) ws_ref3(P, (ptr), mpc_prow((uint32_t)(row)), (uint32_t)(b_), 0u)
+//   MPC_UK(arr, R, k, e)  same kernels, row e of stage k (R rows per stage) with a loop-variant k and a literal e: ONE scalar
+//                         offset per (array, stage), the literal goes into the instruction's immediate / a hoisted lane offset
+#define MPC_UK(ptr, R, k_, e) ws_ref3(P, (ptr), (uint32_t)(k_) * (MPC_EV(R) * 64u), (uint32_t)bb, mpc_prow((uint32_t)(e)))
 #else
-#define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k * (uint32_t)(R) + (uint32_t)(dk) * (uint32_t)(R) + (uint32_t)(e)), (uint32_t)c.b)])
+#define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
 #define MPC_SD(ptr, row) MPC_S(ptr, row)
 #define MPC_U(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)bb)])
 #define MPC_UB(ptr, row, b_) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)(b_))])
-#define MPC_UK(ptr, R, k_, e) ((ptr)[ws_index(P, (ptr), (uint32_t)(k_) * (uint32_t)(R) + (uint32_t)(e), (uint32_t)bb)])
+#define MPC_UK(ptr, R, k_, e) ((ptr)[ws_index(P, (ptr), (uint32_t)(k_) * MPC_EV(R) + (uint32_t)(e), (uint32_t)bb)])
+// (the two rows of a pair are adjacent doubles)
+#define MPC_LD2(ref, lo, hi) do { const double* p2_ = &(ref); (lo) = p2_[0]; (hi) = p2_[1]; } while (0)
+#define MPC_ST2(ref, lo, hi) do { double* p2_ = &(ref); p2_[0] = (lo); p2_[1] = (hi); } while (0)
 #endif
+// CNT consecutive rows starting at an EVEN row: pairs with 16-byte accesses, an odd last row on its own.  `ref(e)` names
+// row e of the run (use MPC_ROWS around one of the accessors above, written in terms of `e`).
+#define MPC_ROWS(expr) [&](int e) -> decltype(auto) { return (expr); }
+template <int CNT, class RefFn>
+MPC_HD void ws_load_rows(RefFn ref, double* dst) {
+#pragma unroll
+    for (int i = 0; i + 1 < CNT; i += 2) MPC_LD2(ref(i), dst[i], dst[i + 1]);
+    if (CNT & 1) dst[CNT - 1] = ref(CNT - 1);
+}
+// the same for a run that starts at any row START (ref takes the row itself): an odd first row goes on its own
+template <int START, int CNT, class RefFn>
+MPC_HD void ws_store_run(RefFn ref, const double* src) {
+    constexpr int HEAD = START & 1;
+    if (HEAD) ref(START) = src[0];
+#pragma unroll
+    for (int i = HEAD; i + 1 < CNT; i += 2) MPC_ST2(ref(START + i), src[i], src[i + 1]);
+    if ((CNT - HEAD) & 1) ref(START + CNT - 1) = src[CNT - 1];
+}
+template <int CNT, class RefFn>
+MPC_HD void ws_store_rows(RefFn ref, const double* src) {
+#pragma unroll
+    for (int i = 0; i + 1 < CNT; i += 2) MPC_ST2(ref(i), src[i], src[i + 1]);
+    if (CNT & 1) ref(CNT - 1) = src[CNT - 1];
+}
 
 template <int NX>
 struct Dim {
@@ -212,7 +269,8 @@ struct Dim {
              : (i == 2 && j == 3) ? NX + 3 : (i == 3 && j == 4) ? NX + 4 : -1;
     }
     // BLK rows per stage
-    static constexpr int B_H = 0, B_RUU = NH, B_A = NH + 2, B_GX = NH + 8, B_GU = NH + 8 + NX, B_CN = NH + 10 + NX;
+    // (A and the defect rows are copied on their own by the forward sweep: both start on a row-pair boundary)
+    static constexpr int B_A = 0, B_RUU = 6, B_GU = 8, B_CN = 10, B_GX = 10 + NX, B_H = 10 + 2 * NX;
     static constexpr int NBLK = NH + 10 + 2 * NX;
     static constexpr int NPK = NS + NX;
     static constexpr int NKK = 2 * NX + 2;
@@ -308,7 +366,7 @@ MPC_HD double zreset(double z, double gap, double mu) {
 
 // per-thread context kept in registers across the phases of the stage kernel
 template <int NX>
-struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath (non-PF)
+struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath
 
 template <int NX>
 struct Ctx {
@@ -341,12 +399,8 @@ struct Ctx {
     bool fric_row;   // stage-0 friction row kept as a row (false: presolved into the bounds a0lb/a0ub of a_0)
     double a0lb, a0ub;
     bool conv;       // fixed-iteration (benchmark) mode: tolerance already reached, steps are accepted as they come
-    // --- LDS image of the rows that only the update phase needs (PF kernels: fetched by global->LDS DMA while phase 1
-    //     and the line search run).  Element e of array A at stage k, column bl:  pf[A_base + e * pf_row + pf_col]
-    mpc_lds_cptr pf;
     mpc_lds_cptr bnd;                        // LDS copy of the bounds table [LB (N+1)*NZ | UB (N+1)*NZ] (device)
     int bnd_ub;
-    int pf_row, pf_col, pf_lam, pf_nuo;      // doubles: (N+1)*bx, k*bx + bl, first element of the LAM / NUO images
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
@@ -456,17 +510,17 @@ MPC_HD void ingest_instance(const Params& P, int b) {
     const double* x0b = P.x0 + (size_t)b * nw;
     const double* pb = P.p + (size_t)b * nw;
     for (int k = 0; k <= N; ++k) {
-        for (int i = 0; i < 2; ++i) MPC_U(P.Z, (uint32_t)k * NZ + i) = (k < N) ? x0b[2 * k + i] : 0.0;
+        for (int i = 0; i < 2; ++i) MPC_UK(P.Z, NZ, k, i) = (k < N) ? x0b[2 * k + i] : 0.0;
         for (int i = 0; i < NX; ++i) {
-            MPC_U(P.Z, (uint32_t)k * NZ + 2 + i) = x0b[2 * N + NX * k + i];
-            MPC_U(P.REF, (uint32_t)k * NX + i) = pb[2 * N + NX * k + i];
+            MPC_UK(P.Z, NZ, k, 2 + i) = x0b[2 * N + NX * k + i];
+            MPC_UK(P.REF, NX, k, i) = pb[2 * N + NX * k + i];
         }
     }
 }
 
-#define X0U(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + (uint32_t)(i_)))
-#define X0X(k_, i_) ((double)MPC_U(P.Z, (uint32_t)(k_) * NZ + 2u + (uint32_t)(i_)))
-#define PRX(k_, i_) ((double)MPC_U(P.REF, (uint32_t)(k_) * NX + (uint32_t)(i_)))
+#define X0U(k_, i_) ((double)MPC_UK(P.Z, NZ, (k_), (i_)))
+#define X0X(k_, i_) ((double)MPC_UK(P.Z, NZ, (k_), 2u + (uint32_t)(i_)))
+#define PRX(k_, i_) ((double)MPC_UK(P.REF, NX, (k_), (i_)))
 // presolve of the stage-0 friction row |a_0^2 + c| <= fu, c = v_0^2 tan(delta_0) / kappa: x_0 is pinned to r_0
 // by the equality rows, so c is a constant and the row is the simple bound a_0^2 <= fu - c (valid when the
 // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
@@ -544,7 +598,7 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub, m
                 const double rn = push_in(raw, lb, ub);
                 th += fabs(rn - raw);
                 x[i] = rn;
-                MPC_U(P.ROLL, ((uint32_t)(k + 1) * NX + i)) = rn;
+                MPC_UK(P.ROLL, NX, k + 1, i) = rn;
             } else {
                 const double gn = push_in(graw[i], lb, ub);
                 th += fabs(gn - raw);
@@ -729,41 +783,48 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 
 // all array loads of the stage kernel in ONE batch (no dependence on the per-instance scalars), plus the arithmetic
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
-template <int NX, bool PF = false>
+template <int NX>
 MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
     load_obst(P, c);
+    // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
+    ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+    ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        c.z[i] = MPC_K(P.Z, NZ, 0, i);
-        c.dz[i] = MPC_K(P.DZ, NZ, 0, i);
-        // multipliers of bounds that exist nowhere are never read (a_0 has per-instance bounds: stage 0 always loads)
-        const bool a0 = (i == 1) && (k == 0);
-        c.zl[i] = (((P.lo_mask >> i) & 1u) || a0) ? (double)MPC_K(P.ZL, NZ, 0, i) : 0.0;
-        c.zu[i] = (((P.hi_mask >> i) & 1u) || a0) ? (double)MPC_K(P.ZU, NZ, 0, i) : 0.0;
+    for (int i = 0; i < NZ; i += 2) {
+        // multipliers of bounds that exist nowhere are never read (a_0 has per-instance bounds: stage 0 always loads its pair);
+        // a row of the pair whose bound is absent holds the zero the start iterate wrote
+        const bool a0 = (i == 0) && (k == 0);
+        const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
+        c.zl[i] = 0.0;
+        c.zu[i] = 0.0;
+        if (i + 1 < NZ) { c.zl[i + 1] = 0.0; c.zu[i + 1] = 0.0; }
+        if (((P.lo_mask >> i) & both) || a0) {
+            if (i + 1 < NZ) MPC_LD2(MPC_K(P.ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_K(P.ZL, NZ, 0, i);
+        }
+        if (((P.hi_mask >> i) & both) || a0) {
+            if (i + 1 < NZ) MPC_LD2(MPC_K(P.ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
+        }
     }
+    if (k < N) {
+        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 1, e)), c.rn);
+        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.Z, NZ, 1, 2 + e)), c.xn);
+        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
-        c.xn[i] = (k < N) ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : 0.0;
-        c.dxn[i] = (k < N) ? (double)MPC_K(P.DZ, NZ, 1, 2 + i) : 0.0;
-        if (!PF) tmp.lam[i] = MPC_K(P.LAM, NX, 0, i);
-        c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+        for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
     }
-    if (!PF) {
+    ws_load_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
-        for (int i = 0; i < D::NPK; ++i) tmp.pk[i] = MPC_K(P.PK, D::NPK, 0, i);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        c.so[j] = MPC_K(P.SO, 3, 0, j);
-        c.nuo[j] = PF ? 0.0 : (double)MPC_K(P.NUO, 3, 0, j);
-        c.zlo[j] = P.has_ol ? (double)MPC_K(P.ZLO, 3, 0, j) : 0.0;
-        c.zuo[j] = P.has_ou ? (double)MPC_K(P.ZUO, 3, 0, j) : 0.0;
-    }
+    for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+    ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
+    ws_load_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
+    ws_load_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
+    if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo); else { c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0; }
+    if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo); else { c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0; }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
     if (k == 0) {                                          // (fric_row is not known yet; the values are only used if it is set)
@@ -779,7 +840,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
 }
 
 // arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam
-template <int NX, bool PF = false>
+template <int NX>
 MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     if (!c.valid) return;
@@ -802,15 +863,13 @@ MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
             c.dso[j] = ds;
         }
     }
-    if (!PF) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double s = tmp.pk[D::NS + i];
+    for (int i = 0; i < NX; ++i) {
+        double s = tmp.pk[D::NS + i];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) s += tmp.pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
-            c.lam[i] = tmp.lam[i];
-            c.dlam[i] = -s - tmp.lam[i];
-        }
+        for (int j = 0; j < NX; ++j) s += tmp.pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
+        c.lam[i] = tmp.lam[i];
+        c.dlam[i] = -s - tmp.lam[i];
     }
     c.dsf = c.dfric0 - c.sf + c.gfr0[0] * c.dz[1] + c.gfr0[1] * c.dz[2 + 2] + c.gfr0[2] * c.dz[2 + 3];
 }
@@ -992,25 +1051,12 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX, bool PF = false>
+template <int NX>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.active) return;
     const int N = P.N, k = c.k;
-    if (PF) {                               // rows parked in LDS by the prefetch: cost-to-go (P_k, p_k), lambda_k, nu_k
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double s = c.pf[(D::NS + i) * c.pf_row + c.pf_col];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) s += c.pf[((i <= j) ? D::sidx(i, j) : D::sidx(j, i)) * c.pf_row + c.pf_col] * c.dz[2 + j];
-            const double l = c.pf[c.pf_lam + i * c.pf_row + c.pf_col];
-            c.lam[i] = l;
-            c.dlam[i] = -s - l;
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) c.nuo[j] = c.pf[c.pf_nuo + j * c.pf_row + c.pf_col];
-    }
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
         if (k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
@@ -1022,17 +1068,27 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         if (i < 2 && k == N) continue;
         MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
-        MPC_K(P.Z, NZ, 0, i) = zn;
-        if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; MPC_K(P.ZL, NZ, 0, i) = c.zl[i]; }
-        if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
+        if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
+        if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
         c.z[i] = zn;
+    }
+    // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
+    ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+#pragma unroll
+    for (int i = 0; i < NZ; i += 2) {
+        const bool a0 = (i == 0) && (k == 0);
+        const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
+        if (((P.lo_mask >> i) & both) || a0) {
+            if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_K(P.ZL, NZ, 0, i) = c.zl[i];
+        }
+        if (((P.hi_mask >> i) & both) || a0) {
+            if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_K(P.ZU, NZ, 0, i) = c.zu[i];
+        }
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        c.lam[i] += al * c.dlam[i];
-        MPC_K(P.LAM, NX, 0, i) = c.lam[i];
-    }
+    for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
+    ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), c.lam);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
@@ -1042,20 +1098,20 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
             sg += c.zlo[j] * ig; gb -= mu * ig;
             c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
             c.iglo[j] = ign;
-            MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
         }
         if (P.has_ou) {
             const double ig = c.iguo[j], ign = 1.0 / (P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
             c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
             c.iguo[j] = ign;
-            MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
         }
         c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
-        MPC_K(P.NUO, 3, 0, j) = c.nuo[j];
-        MPC_K(P.SO, 3, 0, j) = sn;
         c.so[j] = sn;
     }
+    if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo);
+    if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
     if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
@@ -1270,23 +1326,20 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     }
     if (k < N) dual = fmax(dual, fmax(fabs(ru[0]), fabs(ru[1])));
     // stage blocks that do not depend on the barrier parameter
-    const int base = k * D::NBLK;
+    {
+        static_assert(D::B_A == 0 && D::B_RUU == 6 && D::B_CN % 2 == 0 && D::B_H % 2 == 0, "stage-block runs start on row-pair boundaries");
+        const double head[8] = {a03, a04, a13, a14, a42, a43, ruu[0], ruu[1]};
+        ws_store_rows<8>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_A + e)), head);
+        ws_store_rows<NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_CN + e)), cn);
+        double hh[D::NH];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
+        for (int i = 0; i < NX; ++i) {
 #pragma unroll
-        for (int j = i; j < NX; ++j)
-            if (D::hrow(i, j) >= 0) MPC_K(P.BLK, D::NBLK, 0, D::B_H + D::hrow(i, j)) = H[D::sidx(i, j)];
+            for (int j = i; j < NX; ++j)
+                if (D::hrow(i, j) >= 0) hh[D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0] = H[D::sidx(i, j)];
+        }
+        ws_store_rows<D::NH>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_H + e)), hh);
     }
-    MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 0) = ruu[0];
-    MPC_K(P.BLK, D::NBLK, 0, D::B_RUU + 1) = ruu[1];
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 0) = a03;
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 1) = a04;
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 2) = a13;
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 3) = a14;
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 4) = a42;
-    MPC_K(P.BLK, D::NBLK, 0, D::B_A + 5) = a43;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_CN + i) = cn[i];
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
     ls = log(gp);
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
@@ -1325,11 +1378,11 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
             tau = fmax(TAU_MIN, 1.0 - mu);
             mu_changed = true;
         }
-        const int base_row = k * D::NBLK;
+        double gx[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) MPC_K(P.BLK, D::NBLK, 0, D::B_GX + i) = c.gxa[i] + mu * c.gxb[i];
-        MPC_K(P.BLK, D::NBLK, 0, D::B_GU + 0) = c.gua[0] + mu * c.gub[0];
-        MPC_K(P.BLK, D::NBLK, 0, D::B_GU + 1) = c.gua[1] + mu * c.gub[1];
+        for (int i = 0; i < NX; ++i) gx[i] = c.gxa[i] + mu * c.gxb[i];
+        ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), gx);
+        MPC_ST2(MPC_K(P.BLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
     }
     c.status = status;
     if (k == 0) {
@@ -1363,8 +1416,8 @@ struct RicStage {
 template <int NX>
 MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
     using D = Dim<NX>;
-    const uint32_t base = (uint32_t)k * D::NBLK;
-#define RL(row) MPC_UB(P.BLK, base + (row), b)
+    const uint32_t bb = (uint32_t)b;
+#define RL(row) MPC_UK(P.BLK, D::NBLK, k, (row))
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
@@ -1391,24 +1444,20 @@ MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>
 // With A = I + dtF (F has 7 nonzeros) the products are organised around W = P+ (dtF), which has only three nonzero
 // columns (delta, v, psi):   A'P+A = P+ + W + W' + (dtF)'W,   P+A = P+ + W,
 // so the 6x6 product P+A is never formed and P_k is accumulated onto P+ (18 + 12 + 12 temporaries instead of 36 + 21).
-// Where a step puts its results.  SINK = false: straight to the workspace in HBM (MPC_UK).  SINK = true: into an LDS
-// staging block `sink` ([row][64 lanes]: gain rows first, then cost-to-go rows; `sink` already points at the lane's
-// column) from which another wavefront writes them out -- a global store costs the issuing wave ~25 cycles during which
-// it issues nothing else (tools/ubench/store_cost.hip), an LDS write ~3.
-#define RIC_PUT_KK(row, v) do { if (SINK) sink[(row) * 64] = (v); else MPC_UK(P.KK, D::NKK, k, (row)) = (v); } while (0)
-#define RIC_PUT_PK(row, v) do { if (SINK) sink[(D::NKK + (row)) * 64] = (v); else MPC_UK(P.PK, D::NPK, k, (row)) = (v); } while (0)
-
+// Neither half stores anything: the gains and the cost-to-go stay in registers (RicGain, Ps, pv) and ric_store_stage
+// writes them as 16-byte row pairs once both halves are done -- a global store holds the issuing wave for ~25-30 cycles
+// whatever its width (tools/ubench/store_cost.hip), so 21 wide stores cost half of 41 narrow ones.
 template <int NX>
 struct RicGain {
     double G0[NX], G1[NX], i00, i01, i11;       // G = B'(P+ A) (+ Hux at stage 0), Lam^-1
+    double K0[NX], K1[NX], kf0, kf1;            // feedback gains K = -Lam^-1 G and feed-forward kff (rows of KK)
 };
 
 // NE < NX (NE = 5 with NX = 6): the progress state s (index 5: s' = v, zero weight, unbounded) is decoupled -- its row and
 // column of the cost-to-go are identically zero as long as no inertia correction is added -- so the recursion runs on NE
 // states and writes explicit zeros where the six-state layout has entries of s.
-template <int NX, bool STORE_P, int NE = NX, bool SINK = false>
-MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
-                            double* Ps, RicGain<NX>& g, mpc_lds_ptr sink = nullptr) {
+template <int NX, int NE = NX>
+MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g) {
     using D = Dim<NX>;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
@@ -1441,18 +1490,15 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
     const bool pd = (L00 > 0.0) && (det > 0.0);
     const double idet = 1.0 / det;
     g.i00 = L11 * idet; g.i01 = -L01 * idet; g.i11 = L00 * idet;
-    double K0[NX], K1[NX];
+    double* K0 = g.K0;
+    double* K1 = g.K1;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         K0[j] = -(g.i00 * g.G0[j] + g.i01 * g.G1[j]);
         K1[j] = -(g.i01 * g.G0[j] + g.i11 * g.G1[j]);
     }
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-        if (j >= NE) { K0[j] = 0.0; K1[j] = 0.0; g.G0[j] = 0.0; g.G1[j] = 0.0; }
-        RIC_PUT_KK(j, K0[j]);
-        RIC_PUT_KK(NX + j, K1[j]);
-    }
+    for (int j = NE; j < NX; ++j) { K0[j] = 0.0; K1[j] = 0.0; g.G0[j] = 0.0; g.G1[j] = 0.0; }
     // P_k = H + P+ + W + W' + (dtF)'W + G'K, upper triangle, accumulated onto P+
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1460,7 +1506,6 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
         for (int j = i; j < NX; ++j) {
             if (j >= NE) {                                    // entries of the decoupled state: zero
                 Ps[D::sidx(i, j)] = 0.0;
-                if (STORE_P) RIC_PUT_PK(D::sidx(i, j), 0.0);
                 continue;
             }
             double t = Ps[D::sidx(i, j)];
@@ -1476,16 +1521,14 @@ MPC_HD bool ric_matrix_step(const Params& P, uint32_t bb, int k, const RicStage<
             }
             if (i == j) t += delta;
             Ps[D::sidx(i, j)] = t;
-            if (STORE_P) RIC_PUT_PK(D::sidx(i, j), t);
         }
     }
     return pd;
 }
 
 // Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
-template <int NX, int NE = NX, bool SINK = false>
-MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, const double* Pn, const RicGain<NX>& g, double* pv,
-                            mpc_lds_ptr sink = nullptr) {
+template <int NX, int NE = NX>
+MPC_HD void ric_vector_step(const Params& P, const RicStage<NX>& s, const double* Pn, RicGain<NX>& g, double* pv) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const double dt = P.dt;
@@ -1502,32 +1545,49 @@ MPC_HD void ric_vector_step(const Params& P, uint32_t bb, int k, const RicStage<
     // l = gu + B'h,  kff = -Lam^-1 l
     const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
     const double kf0 = -(g.i00 * l0 + g.i01 * l1), kf1 = -(g.i01 * l0 + g.i11 * l1);
-    RIC_PUT_KK(2 * NX, kf0);
-    RIC_PUT_KK(2 * NX + 1, kf1);
+    g.kf0 = kf0;
+    g.kf1 = kf1;
     // p_k = gx + A'h + G'kff
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        if (i >= NE) { pv[i] = 0.0; RIC_PUT_PK(NS + i, 0.0); continue; }
+        if (i >= NE) { pv[i] = 0.0; continue; }
         double t = s.gx[i] + h[i] + g.G0[i] * kf0 + g.G1[i] * kf1;
         if (i == 2) t += a42 * h[4];
         if (i == 3) { t += a03 * h[0] + a13 * h[1] + a43 * h[4]; if (NE == 6) t += dt * h[NX - 1]; }
         if (i == 4) t += a04 * h[0] + a14 * h[1];
         pv[i] = t;
-        RIC_PUT_PK(NS + i, t);
     }
 }
 
+// rows of stage k: gains [K0 | K1 | kff] -> KK, cost-to-go [P_k upper triangle | p_k] -> PK
+template <int NX>
+MPC_HD void ric_store_stage(const Params& P, uint32_t bb, int k, const double* Ps, const double* pv, const RicGain<NX>& g) {
+    using D = Dim<NX>;
+    double kk[D::NKK], pk[D::NPK];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { kk[j] = g.K0[j]; kk[NX + j] = g.K1[j]; }
+    kk[2 * NX] = g.kf0;
+    kk[2 * NX + 1] = g.kf1;
+#pragma unroll
+    for (int i = 0; i < D::NS; ++i) pk[i] = Ps[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pk[D::NS + i] = pv[i];
+    ws_store_rows<D::NKK>(MPC_ROWS(MPC_UK(P.KK, D::NKK, k, e)), kk);
+    ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, k, e)), pk);
+}
+
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
-template <int NX, int NE = NX, bool SINK = false>
+template <int NX, int NE = NX>
 MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
-                                  double hux1, double* Ps, double* pv, mpc_lds_ptr sink = nullptr) {
+                                  double hux1, double* Ps, double* pv) {
     constexpr int NS = Dim<NX>::NS;
     double Pn[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Pn[i] = Ps[i];
     RicGain<NX> g;
-    if (!ric_matrix_step<NX, true, NE, SINK>(P, bb, k, s, delta, hux0, hux1, Ps, g, sink)) return false;
-    ric_vector_step<NX, NE, SINK>(P, bb, k, s, Pn, g, pv, sink);
+    if (!ric_matrix_step<NX, NE>(P, k, s, delta, hux0, hux1, Ps, g)) return false;
+    ric_vector_step<NX, NE>(P, s, Pn, g, pv);
+    ric_store_stage<NX>(P, bb, k, Ps, pv, g);
     return true;
 }
 
@@ -1551,37 +1611,33 @@ struct FwdStage {
 template <int NX>
 MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
     using D = Dim<NX>;
-    const size_t Bp = (size_t)P.Bp, kk = (size_t)k * D::NKK, br = (size_t)k * D::NBLK;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-        f.K0[j] = MPC_U(P.KK, (kk + j));
-        f.K1[j] = MPC_U(P.KK, (kk + NX + j));
-        f.cn[j] = MPC_U(P.BLK, (br + D::B_CN + j));
+        f.K0[j] = MPC_UK(P.KK, D::NKK, k, j);
+        f.K1[j] = MPC_UK(P.KK, D::NKK, k, NX + j);
+        f.cn[j] = MPC_UK(P.BLK, D::NBLK, k, D::B_CN + j);
     }
-    f.kf0 = MPC_U(P.KK, (kk + 2 * NX));
-    f.kf1 = MPC_U(P.KK, (kk + 2 * NX + 1));
+    f.kf0 = MPC_UK(P.KK, D::NKK, k, 2 * NX);
+    f.kf1 = MPC_UK(P.KK, D::NKK, k, 2 * NX + 1);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) f.a[i] = MPC_U(P.BLK, (br + D::B_A + i));
+    for (int i = 0; i < 6; ++i) f.a[i] = MPC_UK(P.BLK, D::NBLK, k, D::B_A + i);
 }
 
 // one step of the forward sweep: du_k = K dx_k + kff, dx_{k+1} = A dx_k + B du_k - c_{k+1}; stores (du_k, dx_k)
-template <int NX, bool SINK = false>
-MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx, mpc_lds_ptr sink = nullptr) {
+template <int NX>
+MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
     using D = Dim<NX>;
     const double dt = P.dt;
     double du0 = f.kf0, du1 = f.kf1;
 #pragma unroll
     for (int j = 0; j < NX; ++j) { du0 += f.K0[j] * dx[j]; du1 += f.K1[j] * dx[j]; }
-    if (SINK) {
-        sink[0] = du0;
-        sink[64] = du1;
+    {
+        double dz[D::NZ];
+        dz[0] = du0;
+        dz[1] = du1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) sink[(2 + i) * 64] = dx[i];
-    } else {
-        MPC_UK(P.DZ, D::NZ, k, 0) = du0;
-        MPC_UK(P.DZ, D::NZ, k, 1) = du1;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) MPC_UK(P.DZ, D::NZ, k, 2 + i) = dx[i];
+        for (int i = 0; i < NX; ++i) dz[2 + i] = dx[i];
+        ws_store_rows<D::NZ>(MPC_ROWS(MPC_UK(P.DZ, D::NZ, k, e)), dz);
     }
     double dn[NX];
 #pragma unroll
@@ -1620,11 +1676,10 @@ MPC_HD void riccati_instance(const Params& P, int b) {
             for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
-            const uint32_t pk = (uint32_t)N * D::NPK;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) MPC_U(P.PK, (pk + i)) = Ps[i];
+            for (int i = 0; i < NS; ++i) MPC_UK(P.PK, D::NPK, N, i) = Ps[i];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) MPC_U(P.PK, (pk + NS + i)) = pv[i];
+            for (int i = 0; i < NX; ++i) MPC_UK(P.PK, D::NPK, N, NS + i) = pv[i];
         }
         // software pipeline: the block of stage k-1 is requested before stage k is processed, so its HBM latency
         // overlaps the ~330 fp64 operations of the step (two stages per trip: cur/nxt ping-pong without copies)
@@ -1662,11 +1717,10 @@ MPC_HD void riccati_instance(const Params& P, int b) {
     }
     if (k < N) fwd_step(k, fa);
     {
-        const uint32_t zr = (uint32_t)N * D::NZ;
-        MPC_U(P.DZ, (zr + 0)) = 0.0;
-        MPC_U(P.DZ, (zr + 1)) = 0.0;
+        MPC_UK(P.DZ, D::NZ, N, 0) = 0.0;
+        MPC_UK(P.DZ, D::NZ, N, 1) = 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) MPC_U(P.DZ, (zr + 2 + i)) = dx[i];
+        for (int i = 0; i < NX; ++i) MPC_UK(P.DZ, D::NZ, N, 2 + i) = dx[i];
     }
 }
 
@@ -1682,10 +1736,10 @@ MPC_HD void output_instance(const Params& P, int b) {
     MPC_GLOBAL_AS double* xo = (MPC_GLOBAL_AS double*)P.x_out + (size_t)bb * nw;
     for (int k = 0; k <= N; ++k) {
         if (k < N) {
-            xo[2 * k] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 0));
-            xo[2 * k + 1] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 1));
+            xo[2 * k] = MPC_UK(P.Z, D::NZ, k, 0);
+            xo[2 * k + 1] = MPC_UK(P.Z, D::NZ, k, 1);
         }
-        for (int i = 0; i < NX; ++i) xo[2 * N + NX * k + i] = MPC_U(P.Z, ((uint32_t)k * D::NZ + 2 + i));
+        for (int i = 0; i < NX; ++i) xo[2 * N + NX * k + i] = MPC_UK(P.Z, D::NZ, k, 2 + i);
     }
     int st = MPC_U(P.ISC, (uint32_t)IS_STATUS);
     if (st == ST_RUNNING) st = 0;     // iteration budget of the launch loop exhausted

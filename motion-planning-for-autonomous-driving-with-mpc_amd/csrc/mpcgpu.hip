@@ -111,10 +111,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef MPC_STAGE_STASH
 #define MPC_STAGE_STASH 1
 #endif
-template <int NX, bool PF> struct Stash {
-    __host__ __device__ static constexpr int rows(bool has_ou) { return 4 * (NX + 2) + 2 * 3 + (has_ou ? 2 * 3 : 0) + (PF ? 0 : 3 + 2 * NX); }
+template <int NX> struct Stash {
+    __host__ __device__ static constexpr int rows(bool has_ou) { return 4 * (NX + 2) + 2 * 3 + (has_ou ? 2 * 3 : 0) + 3 + 2 * NX; }
 };
-template <int NX, bool PF, bool OUT>
+template <int NX, bool OUT>
 __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t, bool has_ou) {
     int r = 0;
 #define MPC_ST(v) do { if (OUT) st[r * T + t] = (v); else (v) = st[r * T + t]; ++r; } while (0)
@@ -126,56 +126,17 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 #pragma unroll
         for (int j = 0; j < 3; ++j) { MPC_ST(c.zuo[j]); MPC_ST(c.iguo[j]); }
     }
-    if (!PF) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) MPC_ST(c.nuo[j]);
+    for (int j = 0; j < 3; ++j) MPC_ST(c.nuo[j]);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
-    }
+    for (int i = 0; i < NX; ++i) { MPC_ST(c.lam[i]); MPC_ST(c.dlam[i]); }
 #undef MPC_ST
-}
-
-// LDS prefetch of the rows that only the update phase reads (cost-to-go P_k/p_k, lambda_k, nu_k): global->LDS DMA,
-// 16 bytes per lane.  A (row, stage) segment of the workgroup's bx instance columns is bx*8 contiguous bytes in HBM;
-// one wave instruction moves 128/bx segments and lands them back to back, so the LDS image of an array is
-// [row][stage][column] -- the element of thread (k, bl) in row e sits at (e*(N+1) + k)*bx + bl.
-template <int NX>
-struct PfLayout {
-    uint32_t nins[3], base[3], total;        // DMA instructions per array, first instruction (= KiB) of each image
-    __host__ __device__ PfLayout(int N, int bx) {
-        const uint32_t spi = 128u / (uint32_t)bx, S = (uint32_t)N + 1u;
-        const uint32_t rows[3] = {(uint32_t)Dim<NX>::NPK, (uint32_t)NX, 3u};
-        total = 0;
-        for (int a = 0; a < 3; ++a) { nins[a] = (rows[a] * S + spi - 1) / spi; base[a] = total; total += nins[a]; }
-    }
-};
-template <int NX>
-__device__ __forceinline__ void stage_prefetch(const Params& P, uint32_t b0, char* lds_pf) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const PfLayout<NX> L(P.N, P.bx);
-    const uint32_t S = (uint32_t)P.N + 1u, lps = (uint32_t)P.bx >> 1, spi = 128u / (uint32_t)P.bx;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6, lane = threadIdx.x & 63u;
-    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
-    const uint32_t col_off = ((b0 >> 6) * P.tile_elems + (b0 & 63u)) * 8u + (lane % lps) * 16u;
-    const double* arrs[3] = {P.PK, P.LAM, P.NUO};
-    const uint32_t rows[3] = {(uint32_t)Dim<NX>::NPK, (uint32_t)NX, 3u};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const uint32_t aoff = (uint32_t)(uintptr_t)arrs[a] - (uint32_t)(uintptr_t)P.WS + col_off, R = rows[a], nseg = R * S;
-        for (uint32_t i = wave; i < L.nins[a]; i += nw) {
-            const uint32_t sg = i * spi + lane / lps;
-            const uint32_t e = __umulhi(sg, P.inv_S), k = sg - e * S;
-            const uint32_t goff = sg < nseg ? aoff + (k * R + e) * 512u : 0xFFFFFFF0u;      // out of range: dropped by the bounds check
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_pf + (L.base[a] + i) * 1024u), 16, (int)goff, 0, 0, 0);
-        }
-    }
-#endif
 }
 
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
-template <int NX, bool INIT, int MAXT, bool PF>
+template <int NX, bool INIT, int MAXT>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true) {
     int or_parity = 0;
@@ -210,22 +171,10 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        phase_preload<NX, PF>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
-        char* pfb = reinterpret_cast<char*>(lds_x + stash_rows * (int)blockDim.x);
-        if (PF) {
-            const PfLayout<NX> L(P.N, bx);
-            c.pf = (mpc_lds_cptr)(lds_ptr_t)pfb;
-            c.pf_row = (P.N + 1) * bx;
-            c.pf_col = c.k * bx + (t & (bx - 1));
-            c.pf_lam = (int)L.base[1] * 128;
-            c.pf_nuo = (int)L.base[2] * 128;
-        }
-        phase_premath<NX, PF>(P, c, tmp);
+        phase_preload<NX>(P, c, tmp);                  // every array load of the kernel is in flight before the first wait
+        phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
-        // the rows of the update phase stream into LDS while phase 1 and the line search compute (issued only now: the
-        // memory system serves requests in no particular order, an earlier issue just competes with the loads above)
-        if (PF) stage_prefetch<NX>(P, b0, pfb);
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX>(P, c, r1);
@@ -234,17 +183,16 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
         double* stash = lds_x;                                 // shares the exchange region (each thread touches its own column only)
-        if (STASH) stash_xfer<NX, PF, true>(c, stash, blockDim.x, t, P.has_ou != 0);
-        if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the prefetch has landed; the barrier below publishes it
+        if (STASH) stash_xfer<NX, true>(c, stash, blockDim.x, t, P.has_ou != 0);
         while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
-        if (STASH) stash_xfer<NX, PF, false>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (STASH) stash_xfer<NX, false>(c, stash, blockDim.x, t, P.has_ou != 0);
         MPC_STAMP(5);
-        phase_apply_update<NX, PF>(P, c);
+        phase_apply_update<NX>(P, c);
         MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
@@ -276,7 +224,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
 #undef MPC_STAMP
 }
 
-template <int NX, bool INIT, int MAXT, bool PF>
+template <int NX, bool INIT, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -287,7 +235,7 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
     // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
     const unsigned long long bits = (!INIT && P.tile_mask != nullptr) ? P.tile_mask[b0 >> 6] : ~0ull;
-    stage_block<NX, INIT, MAXT, PF>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
+    stage_block<NX, INIT, MAXT>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -323,7 +271,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
-    constexpr uint32_t BLK_BYTES = D::NBLK * 512u;
+    constexpr uint32_t BLK_BYTES = MPC_EV(D::NBLK) * 512u;              // a stage block: whole row pairs, 1 KiB each ([pair][lane][2])
     constexpr int BLK_CHUNKS = (BLK_BYTES + 1023u) / 1024u;
     constexpr uint32_t SLOT = BLK_CHUNKS * 1024u;
     constexpr int KK_CHUNKS = (D::NKK * 512u + 1023u) / 1024u;
@@ -352,22 +300,23 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
         for (int c = 0; c < nchunks; ++c)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + dst + (uint32_t)c * 1024u), 16, lane * 16, (int)(src + (uint32_t)c * 1024u), 0, 0);
     };
-    auto lds_d = [&](uint32_t off) { return *reinterpret_cast<const double*>(smem + off + (uint32_t)lane * 8u); };
+    // row r of an LDS image that starts at `off` (the DMA copies the row pairs verbatim)
+    auto lds_r = [&](uint32_t off, uint32_t r) { return *reinterpret_cast<const double*>(smem + off + mpc_prow(r) * 8u + (uint32_t)lane * 16u); };
     auto read_stage = [&](uint32_t slot, RicStage<NX>& s) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
 #pragma unroll
             for (int j = i; j < NX; ++j)
-                s.H[D::sidx(i, j)] = (D::hrow(i, j) >= 0) ? lds_d(slot + (D::B_H + (D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0)) * 512u) : 0.0;
+                s.H[D::sidx(i, j)] = (D::hrow(i, j) >= 0) ? lds_r(slot, D::B_H + (D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0)) : 0.0;
         }
-        s.ruu[0] = lds_d(slot + (D::B_RUU) * 512u);
-        s.ruu[1] = lds_d(slot + (D::B_RUU + 1) * 512u);
+        s.ruu[0] = lds_r(slot, D::B_RUU);
+        s.ruu[1] = lds_r(slot, D::B_RUU + 1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s.a[i] = lds_d(slot + (D::B_A + i) * 512u);
+        for (int i = 0; i < 6; ++i) s.a[i] = lds_r(slot, D::B_A + i);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { s.gx[i] = lds_d(slot + (D::B_GX + i) * 512u); s.cn[i] = lds_d(slot + (D::B_CN + i) * 512u); }
-        s.gu[0] = lds_d(slot + (D::B_GU) * 512u);
-        s.gu[1] = lds_d(slot + (D::B_GU + 1) * 512u);
+        for (int i = 0; i < NX; ++i) { s.gx[i] = lds_r(slot, D::B_GX + i); s.cn[i] = lds_r(slot, D::B_CN + i); }
+        s.gu[0] = lds_r(slot, D::B_GU);
+        s.gu[1] = lds_r(slot, D::B_GU + 1);
     };
     // ================================================================ backward sweep(s)
     double delta = 0.0, delta_last = 0.0, hux0 = 0.0, hux1 = 0.0;
@@ -406,11 +355,12 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
                     if (ok) {
-                        const uint32_t pk = (uint32_t)N * D::NPK;
+                        double pk[D::NPK];
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) MPC_U(P.PK, pk + i) = Ps[i];
+                        for (int i = 0; i < NS; ++i) pk[i] = Ps[i];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) MPC_U(P.PK, pk + NS + i) = pv[i];
+                        for (int i = 0; i < NX; ++i) pk[NS + i] = pv[i];
+                        ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, N, e)), pk);
                     }
                 } else if (ok) {
                     ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
@@ -441,6 +391,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
         const int par = wave - 1;
         auto dma_fwd = [&](int k, uint32_t dst) {
             dma(kk_base + (uint32_t)k * (D::NKK * 512u), dst, KK_CHUNKS);
+            static_assert(D::B_A % 2 == 0 && D::B_CN % 2 == 0 && D::NKK % 2 == 0, "sub-blocks copied on their own start on a row-pair boundary");
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_A * 512u, dst + KK_CHUNKS * 1024u, 3);
             dma(blk_base + (uint32_t)k * BLK_BYTES + D::B_CN * 512u, dst + (KK_CHUNKS + 3) * 1024u, 3);
         };
@@ -471,25 +422,26 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
             FwdStage<NX> f;
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
-                f.K0[j] = lds_d(slot + (uint32_t)j * 512u);
-                f.K1[j] = lds_d(slot + (uint32_t)(NX + j) * 512u);
-                f.cn[j] = lds_d(slot + (KK_CHUNKS + 3) * 1024u + (uint32_t)j * 512u);
+                f.K0[j] = lds_r(slot, (uint32_t)j);
+                f.K1[j] = lds_r(slot, (uint32_t)(NX + j));
+                f.cn[j] = lds_r(slot + (KK_CHUNKS + 3) * 1024u, (uint32_t)j);
             }
-            f.kf0 = lds_d(slot + (uint32_t)(2 * NX) * 512u);
-            f.kf1 = lds_d(slot + (uint32_t)(2 * NX + 1) * 512u);
+            f.kf0 = lds_r(slot, (uint32_t)(2 * NX));
+            f.kf1 = lds_r(slot, (uint32_t)(2 * NX + 1));
 #pragma unroll
-            for (int i = 0; i < 6; ++i) f.a[i] = lds_d(slot + KK_CHUNKS * 1024u + (uint32_t)i * 512u);
+            for (int i = 0; i < 6; ++i) f.a[i] = lds_r(slot + KK_CHUNKS * 1024u, (uint32_t)i);
             // executed by every lane (finished / padding instances just write an unused step): keeping the stores out of
             // a divergent branch spares a waterfall loop around each of them
             riccati_forward_step<NX>(P, bb, k, f, dx);
             if (k == 15) RIC_STAMP(8);
         }
         if (go) {
-            const uint32_t zr = (uint32_t)N * D::NZ;
-            MPC_U(P.DZ, zr + 0) = 0.0;
-            MPC_U(P.DZ, zr + 1) = 0.0;
+            double dz[D::NZ];
+            dz[0] = 0.0;
+            dz[1] = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) MPC_U(P.DZ, zr + 2 + i) = dx[i];
+            for (int i = 0; i < NX; ++i) dz[2 + i] = dx[i];
+            ws_store_rows<D::NZ>(MPC_ROWS(MPC_UK(P.DZ, D::NZ, N, e)), dz);
         }
     }
     RIC_STAMP(2);
@@ -667,7 +619,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-        stage_block<NX, false, 256, false>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u);
+        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
         lds_barrier();
         PIPE_STAMP(14);
@@ -723,9 +675,9 @@ __global__ void __launch_bounds__(128) k_prestart(const Params P) {
 template <int NX>
 __device__ __forceinline__ uint32_t zrow_of_col(int col, int N) {          // decision-vector column -> row of Z
     constexpr int NZ = NX + 2;
-    if (col < 2 * N) return (uint32_t)(col >> 1) * NZ + (uint32_t)(col & 1);
+    if (col < 2 * N) return (uint32_t)(col >> 1) * MPC_EV(NZ) + (uint32_t)(col & 1);
     const int cx = col - 2 * N;
-    return (uint32_t)(cx / NX) * NZ + 2u + (uint32_t)(cx % NX);
+    return (uint32_t)(cx / NX) * MPC_EV(NZ) + 2u + (uint32_t)(cx % NX);
 }
 
 // grid = (tiles, 64-column chunks): every workgroup moves one 64 x 64 block, so a batch of 64 tiles is ~450 workgroups
@@ -750,13 +702,13 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
     for (int cc = w; cc < 64; cc += 4) {
         const int col = c0 + cc;
         if (col < nw) {
-            if (pass == 0) Zt[zrow_of_col<NX>(col, N) * 64u + lane] = tile[lane][cc];
-            else Rt[(uint32_t)(col - 2 * N) * 64u + lane] = tile[lane][cc];
+            if (pass == 0) Zt[mpc_prow(zrow_of_col<NX>(col, N)) + 2u * lane] = tile[lane][cc];
+            else Rt[mpc_prow((uint32_t)((col - 2 * N) / NX) * MPC_EV(NX) + (uint32_t)((col - 2 * N) % NX)) + 2u * lane] = tile[lane][cc];
         }
     }
     // u rows of the terminal stage do not exist in x0
     constexpr int NZ = NX + 2;
-    if (blockIdx.y == 0 && threadIdx.x < 128) Zt[((uint32_t)N * NZ + (threadIdx.x >> 6)) * 64u + lane] = 0.0;
+    if (blockIdx.y == 0 && threadIdx.x < 128) Zt[mpc_prow((uint32_t)N * MPC_EV(NZ) + (threadIdx.x >> 6)) + 2u * lane] = 0.0;
 }
 
 template <int NX>
@@ -769,7 +721,7 @@ __global__ void __launch_bounds__(256) k_egest(const Params P) {
     const int c0 = (int)blockIdx.y * 64;
     for (int cc = w; cc < 64; cc += 4) {
         const int col = c0 + cc;
-        tile[lane][cc] = (col < nw) ? Zt[zrow_of_col<NX>(col, N) * 64u + lane] : 0.0;
+        tile[lane][cc] = (col < nw) ? Zt[mpc_prow(zrow_of_col<NX>(col, N)) + 2u * lane] : 0.0;
     }
     __syncthreads();
     for (int r = w; r < 64; r += 4) {
@@ -781,18 +733,18 @@ __global__ void __launch_bounds__(256) k_egest(const Params P) {
     if (threadIdx.x < 64) {
         const uint32_t b = t0 + (uint32_t)lane;
         if (b < (uint32_t)P.B) {
-            int st = P.ISC[tl * P.itile_elems + (uint32_t)IS_STATUS * 64u + lane];
+            int st = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_STATUS) + 2u * lane];
             if (st == ST_RUNNING) st = 0;          // iteration budget of the launch loop exhausted
             if (P.status_out) P.status_out[b] = st;
-            if (P.iters_out) P.iters_out[b] = P.ISC[tl * P.itile_elems + (uint32_t)IS_ITERS * 64u + lane];
-            if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)tl * P.tile_elems + (uint32_t)SC_E0 * 64u + lane];
+            if (P.iters_out) P.iters_out[b] = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_ITERS) + 2u * lane];
+            if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)tl * P.tile_elems + mpc_prow((uint32_t)SC_E0) + 2u * lane];
         }
     }
 }
 
 __global__ void k_count_running(const int32_t* iws, uint32_t itile_elems, int b0, int B, int32_t* counter) {
     const int b = b0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int run = (b < B && iws[((uint32_t)b >> 6) * itile_elems + (uint32_t)IS_STATUS * 64u + ((uint32_t)b & 63u)] == ST_RUNNING) ? 1 : 0;
+    const int run = (b < B && iws[((uint32_t)b >> 6) * itile_elems + mpc_prow((uint32_t)IS_STATUS) + 2u * ((uint32_t)b & 63u)] == ST_RUNNING) ? 1 : 0;
     const unsigned long long m = __ballot(run);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
 }
@@ -801,7 +753,7 @@ __global__ void k_transpose_obst(const double* obst /*[B][6]*/, double* OBST /*r
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) OBST[((uint32_t)b >> 6) * tile_elems + (uint32_t)i * 64u + ((uint32_t)b & 63u)] = obst[(size_t)b * 6 + i];
+    for (int i = 0; i < 6; ++i) OBST[((uint32_t)b >> 6) * tile_elems + mpc_prow((uint32_t)i) + 2u * ((uint32_t)b & 63u)] = obst[(size_t)b * 6 + i];
 }
 
 // debug/trace helper: gather 8 per-instance scalar rows into a contiguous [8][B] buffer
@@ -810,7 +762,7 @@ __global__ void k_gather_trace(const double* SC /*rows of tile 0*/, uint32_t til
     if (b >= B) return;
     const int rows[8] = {SC_MU, SC_THETA, SC_PHI, SC_ALPHA, SC_ADU, SC_DELTA, SC_E0, SC_NTRIAL};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) out[(size_t)q * B + b] = SC[((uint32_t)b >> 6) * tile_elems + (uint32_t)rows[q] * 64u + ((uint32_t)b & 63u)];
+    for (int q = 0; q < 8; ++q) out[(size_t)q * B + b] = SC[((uint32_t)b >> 6) * tile_elems + mpc_prow((uint32_t)rows[q]) + 2u * ((uint32_t)b & 63u)];
 }
 
 // correctly rounded square root: the library sqrt is within 1 ulp; one residual correction r += (x - r*r) / (2r) with a
@@ -1313,26 +1265,19 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // LDS: reductions | the larger of (stage exchange, multiplier stash of the 256-thread variant) | prefetch images
     const bool has_ou = h->hp.has_ou != 0;
     const size_t lds_max = 160 * 1024 - 1024;          // the kernels also hold a few hundred bytes of static LDS
-    const PfLayout<NX> pfl(d.N, bx);
-    // opt-in (MPCGPU_PREFETCH=1): measured neutral on MI355X at B = 4096 (59.5 us without, 60.2 us with) -- the kernel is
-    // bound by the per-workgroup latency chain, not by the load burst the prefetch spreads out
-    bool use_pf = small_wg && getenv("MPCGPU_PREFETCH") != nullptr;
-    int stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, true>::rows(has_ou), 2 * NX) : 2 * NX;
-    if (use_pf && ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double) + (size_t)pfl.total * 1024 > lds_max) use_pf = false;
-    if (!use_pf) stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX, false>::rows(has_ou), 2 * NX) : 2 * NX;
-    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double) + (use_pf ? (size_t)pfl.total * 1024 : 0);
+    const int stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX>::rows(has_ou), 2 * NX) : 2 * NX;
+    const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double);
     const int rblk = (int)(Bp / 64);
-    const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((Dim<NX>::NBLK * 512 + 1023) / 1024) * 1024,
+    const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((MPC_EV(Dim<NX>::NBLK) * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
     {
         static bool attr_set[2] = {false, false};
         if (!attr_set[NX - 5]) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             attr_set[NX - 5] = true;
         }
@@ -1371,12 +1316,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Pg.tile0 = q.tile0;
         if (!init && stage_timing && P.DBG) Pg.DBG = P.DBG;
         if (small_wg) {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else if (use_pf) hipLaunchKernelGGL((k_stage<NX, false, 256, true>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else hipLaunchKernelGGL((k_stage<NX, false, 256, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else hipLaunchKernelGGL((k_stage<NX, false, 512, false>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
     for (int g = 0; g < G; ++g) {
@@ -1439,7 +1383,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const int tiles_x = (ntiles + 7) / 8;
         int n_ric = std::min(8, tiles_x);
         if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(16, tiles_x)));
-        const bool eligible = G == 1 && !trace && !stage_timing && small_wg && !use_pf && threads >= 192 && threads <= 256 &&
+        const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
         // (measured: 7-11 % faster than one launch per kernel at B = 64 ... 1024, 31 % at B = 4096; at B = 8192 the early

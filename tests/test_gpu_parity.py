@@ -59,17 +59,19 @@ def test_ragged_batch_sizes(B):
     assert np.array_equal(part.x, full.x[:B]) and np.array_equal(part.iters, full.iters[:B])
 
 
-@pytest.mark.parametrize("env", ["MPCGPU_PREFETCH", "MPCGPU_BIG_WG", "MPCGPU_GROUPS"])
+@pytest.mark.parametrize("env", ["MPCGPU_BIG_WG", "MPCGPU_GROUPS"])
 def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
-    """The opt-in variants (LDS prefetch of the update-phase rows, 512-thread stage workgroups, sub-batch streams) run
-    the same arithmetic: results must equal the default path bit for bit."""
+    """The opt-in variants (512-thread stage workgroups -- the kernel long horizons use --, sub-batch streams) run the
+    same arithmetic: results must equal the default path bit for bit, run after run (the 512-thread kernel is the one
+    in which a 16-byte store was once followed directly by a VALU write of its data register, see ws_store2)."""
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 600, **kw)
     s = make_solver(cfg)
     ref = s.solve(x0, p)
     monkeypatch.setenv(env, "2" if env == "MPCGPU_GROUPS" else "1")
-    alt = s.solve(x0, p)
-    assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
+    for _ in range(4):
+        alt = s.solve(x0, p)
+        assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
 def _same(a, b):

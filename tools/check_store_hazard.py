@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Scan the gfx950 ISA of mpcgpu.hip for a store-data hazard the compiler does not guard.
+
+A buffer store of more than 64 bits keeps reading its data VGPRs for a few cycles after it issues.  LLVM's hazard
+recognizer inserts the wait states only when the store has no SGPR soffset; on MI355X the hazard was observed with an
+SGPR soffset as well (`buffer_store_dwordx4 v[18:21], ...` directly followed by `v_add_u32 v18, ...`: lanes 12-15 of
+every 16 stored the new value, timing dependent).  The code avoids the form (ws_store2 in mpc_stage_math.h); this
+script proves it for the whole translation unit: no 128-bit buffer store may be followed, within two instructions and
+without an s_nop, by a VALU write of one of its data registers -- and none may use an SGPR soffset at all.
+
+usage: python tools/check_store_hazard.py [file.s]     (without an argument: compiles csrc/mpcgpu.hip with -S)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def isa_text():
+    src = os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpcgpu.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "mpcgpu.s")
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                               "--cuda-device-only", src, "-o", out])
+        return open(out).read()
+
+
+def scan(text):
+    lines = text.split("\n")
+    stores, sgpr_soffset, overwritten = 0, [], []
+    for n, l in enumerate(lines):
+        m = re.search(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\], (\S+), s\[\d+:\d+\], (\S+)", l)
+        if not m:
+            continue
+        stores += 1
+        lo, hi, soff = int(m.group(1)), int(m.group(2)), m.group(4)
+        if re.match(r"s\d+|s\[", soff):
+            sgpr_soffset.append((n + 1, l.strip()))
+        seen = 0
+        for q in range(n + 1, min(n + 12, len(lines))):
+            t = lines[q].strip()
+            if not t or t[0] in ";." or t.endswith(":"):
+                continue
+            seen += 1
+            if seen > 2 or t.startswith("s_nop"):
+                break
+            mm = re.match(r"v_\S+\s+v\[?(\d+)(?::(\d+))?\]?", t)
+            if mm and not (int(mm.group(2) or mm.group(1)) < lo or int(mm.group(1)) > hi):
+                overwritten.append((n + 1, l.strip(), t))
+                break
+    return stores, sgpr_soffset, overwritten
+
+
+if __name__ == "__main__":
+    text = open(sys.argv[1]).read() if len(sys.argv) > 1 else isa_text()
+    stores, sgpr, over = scan(text)
+    print(f"{stores} buffer stores of more than 64 bits; {len(sgpr)} with an SGPR soffset; {len(over)} followed by a write of their data")
+    for item in sgpr[:10] + over[:10]:
+        print("  ", item)
+    sys.exit(1 if (sgpr or over) else 0)
