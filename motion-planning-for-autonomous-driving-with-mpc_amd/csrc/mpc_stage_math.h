@@ -15,9 +15,9 @@
 //   circle geometry ...................... configuration.py:69-93
 //   the call being replaced .............. optimizer.py:607   sol(x0=,p=,lbg=,lbx=,ubg=,ubx=)
 //
-// Data layout in HBM: structure-of-arrays, `row * Bp + b` with the instance index b fastest, so that a
-// wavefront working on 64 (or 32/16) consecutive instances of one horizon stage reads 512 (256/128)
-// contiguous bytes per field.  Rows are (stage k, component i) pairs; see the *_ROW helpers.
+// Data layout in HBM: tile-major structure-of-arrays with interleaved row pairs, [tile of 64 instances][row pair]
+// [instance][2] (mpc_prow below): a wavefront working on consecutive instances of one horizon stage reads contiguous
+// 16-byte elements.  Rows are (stage k, component i) pairs.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -30,8 +30,8 @@
 
 // Device code addresses the SoA workspace through ONE buffer resource descriptor (SRSRC, 4 SGPRs) with
 //   soffset (SGPR)  = byte offset of the array inside the workspace (uniform),
-//   voffset (VGPR)  = 8 * (row * Bp + b), a 32-bit per-lane byte offset,
-// i.e. buffer_load_dwordx2 / buffer_store_dwordx2 instead of flat accesses with 64-bit VGPR addresses: kernel-argument
+//   voffset (VGPR)  = the instance's 32-bit byte offset inside its tile (+ the tile's base),
+// i.e. buffer_load / buffer_store (dwordx2, or dwordx4 for a row pair) instead of flat accesses with 64-bit VGPR addresses: kernel-argument
 // pointers that arrive inside a by-value struct are otherwise treated as generic pointers (2-3 VALU of 64-bit
 // address arithmetic per access, no scalar-base addressing).  The workspace is < 4 GiB (checked on the host);
 // out-of-range accesses are dropped by the hardware bounds check.  On the host (emulation harness) the same macros
@@ -1439,8 +1439,8 @@ MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>
 // One backward step of the recursion, in two halves that only meet through (P+, G, Lam^-1):
 //   ric_matrix_step  P+ -> P_k, gains K            (the critical chain: the next stage needs P_k)
 //   ric_vector_step  p+ -> p_k, feed-forward kff   (needs P+, G, Lam^-1 of the same stage; nothing waits for it)
-// The GPU kernel runs them on two wavefronts, the vector half one stage behind the matrix half; riccati_backward_step below
-// chains them for the one-thread-per-instance paths.
+// riccati_backward_step below chains them (running them on two wavefronts, the vector half one stage behind, was measured
+// and rejected: DESIGN.md section 4).
 // With A = I + dtF (F has 7 nonzeros) the products are organised around W = P+ (dtF), which has only three nonzero
 // columns (delta, v, psi):   A'P+A = P+ + W + W' + (dtF)'W,   P+A = P+ + W,
 // so the 6x6 product P+A is never formed and P_k is accumulated onto P+ (18 + 12 + 12 temporaries instead of 36 + 21).

@@ -4,18 +4,22 @@
 //     res = sol(x0=init_control, p=c_p, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)     MPC_Planner/optimizer.py:607
 // i.e. CasADi's nlpsol('ipopt') on the multiple-shooting NLP of optimizer.py:373-558.
 //
-// Kernels (one IPM iteration = k_riccati + k_stage):
-//   k_stage<NX, INIT>  one thread per (instance, horizon stage); a workgroup holds all N+1 stages of `bx`
+// Device code (one IPM iteration of an instance = a Riccati sweep of its tile + the stage work of its 8-instance block):
+//   stage_block<NX, INIT>  one thread per (instance, horizon stage); a workgroup holds all N+1 stages of `bx`
 //                      instances so that per-instance reductions (step lengths, filter line search, KKT error)
 //                      stay inside the workgroup: wave-level xor-shuffles across the stages that share a
 //                      wavefront, then a small LDS exchange across wavefronts.  Evaluates the bicycle dynamics,
 //                      cost, circle-distance rows and their derivatives, condenses slacks/bounds into the stage
 //                      Hessian and writes the banded KKT blocks.
-//   k_riccati<NX>      one thread per instance, sequential over the stages: block-tridiagonal (Riccati)
-//                      factor + solve of the condensed KKT system, with the sparsity of A_k, B_k hard-wired.
+//   riccati_tile<NX>   one instance per lane of a compute wave, sequential over the stages: block-tridiagonal
+//                      (Riccati) factor + solve of the condensed KKT system, with the sparsity of A_k, B_k hard-wired;
+//                      loader waves stream the stage blocks HBM -> LDS by DMA.
+//   k_pipeline         ALL iterations of a solve in one persistent launch: tiles cycle between Riccati workers and
+//                      stage workers of their XCD (ready queue, arrival counters, bounded waits).
+//   k_stage, k_riccati the same two functions as kernels of their own (one launch per kernel and iteration): large
+//                      batches, long horizons, trace mode, and the path the pipeline falls back to.
 //   k_ingest / k_egest LDS-tiled transposes between the caller's row-major buffers and the tile-major workspace.
-// HBM layout: structure-of-arrays [row][instance]; a 64-lane wavefront touches 64 (k_riccati) or bx (k_stage)
-// consecutive doubles per row => fully coalesced 512 B / 128-256 B segments.
+// HBM layout: tile-major structure-of-arrays with interleaved row pairs (mpc_prow in mpc_stage_math.h).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -38,7 +38,7 @@ def main(d, json_out=None):
             if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
                 continue
             name = ("k_stage" if "k_stage" in k and "true" not in k.split(",")[1] else
-                    "k_riccati" if "k_riccati" in k else "k_pipeline" if "k_pipeline" in k else None)
+                    "k_riccati" if "k_riccati" in k else "k_pipeline" if "k_pipeline<6" in k else None)     # <6>: the metric configuration
             if name is None:
                 continue
 
@@ -46,6 +46,20 @@ def main(d, json_out=None):
                 mx = max(v)
                 return [x for x in v if x > 0.1 * mx] or v
             fe, wr = live(cs["FETCH_SIZE"]), live(cs["WRITE_SIZE"])
+            if name == "k_pipeline":
+                # one launch per solve: the bench command runs converged-mode solves (mean 8 iterations) and fixed-20
+                # solves; `mean` is the converged-mode cluster (what the bench line's roofline object is quoted on)
+                def low(v):
+                    mid = 0.5 * (min(v) + max(v))
+                    return [x for x in v if x <= mid] or v
+                fe_lo, wr_lo = low(fe), low(wr)
+                out[name] = dict(fetch_size_kib_mean=sum(fe_lo) / len(fe_lo), write_size_kib_mean=sum(wr_lo) / len(wr_lo),
+                                 fetch_size_kib_max=max(fe), write_size_kib_max=max(wr),
+                                 hbm_bytes_per_launch_mean=(2 * sum(fe_lo) / len(fe_lo) + sum(wr_lo) / len(wr_lo)) * 1024,
+                                 hbm_bytes_per_launch_full=(2 * max(fe) + max(wr)) * 1024,
+                                 note="2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes over `python bench.py --steps 2 --warmup 1`; one launch "
+                                      "per solve: mean = converged-mode solves (mean 8 iterations per instance), full = 20 fixed iterations")
+                continue
             out[name] = dict(fetch_size_kib_mean=sum(fe) / len(fe), write_size_kib_mean=sum(wr) / len(wr),
                              fetch_size_kib_max=max(fe), write_size_kib_max=max(wr),
                              hbm_bytes_per_launch_mean=(2 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024,
