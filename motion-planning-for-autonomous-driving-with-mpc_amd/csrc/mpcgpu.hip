@@ -716,8 +716,9 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
 }
 
 template <int NX>
-__global__ void __launch_bounds__(256) k_egest(const Params P) {
+__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if) {
     __shared__ double tile[64][65];
+    if (skip_if != nullptr && *skip_if != 0u) return;        // abandoned pipeline launch: the host starts over, the caller's buffers stay untouched
     const int N = P.N, nw = 2 * N + NX * (N + 1);
     const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1422,6 +1423,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.begin(3, stream);
             hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
+            // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
+            // synchronisation of the call is the last thing that happens
+            prof.begin(2, stream);
+            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT));
+            prof.end(stream);
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, hipStreamSynchronize(stream));
             if (h->h_pipe[0] != 0u) {
@@ -1558,11 +1564,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (n_it_out) *n_it_out = it;
     for (int g = 0; g < G; ++g) {
         const Group& q = grp[g];
-        if (q.b1 <= q.b0) continue;
+        if (q.b1 <= q.b0 || piped) continue;          // (pipeline: already enqueued behind the launch)
         Params Pg = P;
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg, (const uint32_t*)nullptr);
         prof.end(q.st);
         if (G > 1) {
             HIP_TRY(h, hipEventRecord(h->ev_join[g], q.st));
