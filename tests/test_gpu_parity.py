@@ -306,10 +306,11 @@ def test_rescue_makes_every_collision_avoidance_cold_start_converge():
     assert np.array_equal(again.x, plain.x[:64])
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 63, 127])
+@pytest.mark.parametrize("N", [1, 2, 3, 20, 23, 31, 32, 63, 64, 127])
 def test_extreme_horizons_match_oracle(N):
-    """shortest horizons and the largest one the C-ABI accepts (N <= 127: 512-thread stage workgroups, bx = 4...): same
-    iterates as the oracle"""
+    """shortest horizons, the largest one the C-ABI accepts (N <= 127: 512-thread stage workgroups, bx = 4) and the
+    boundaries of the workgroup shapes in between (N = 23: 192-thread pipeline workgroups; 31 | 32: 8 | 4 instances per
+    256-thread workgroup; 63 | 64: 256 | 512 threads): same iterates as the oracle"""
     cfg = NLPConfig(N=N, nx=5)
     B = 40 if N < 100 else 24
     x0, p = synthetic_batch(cfg, B)
