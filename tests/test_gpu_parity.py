@@ -131,6 +131,30 @@ def test_pipeline_release_protocol_and_restart(monkeypatch):
     assert _same(make_solver(cfg).solve(x0, p), ref)
 
 
+def test_two_handles_solve_concurrently():
+    """Two handles driven from two host threads: their persistent launches compete for the same CUs (each wants one
+    workgroup per CU).  Whatever the dispatcher does -- interleave them, starve one for a while, or make a bounded wait
+    run out so that a solve restarts on the per-kernel path -- both must return the bits of a solve that ran alone."""
+    import threading
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    xa, pa = synthetic_batch(cfg, 2048, **kw)
+    xb, pb = synthetic_batch(cfg, 3000, start=5000, **kw)
+    sa, sb = make_solver(cfg), make_solver(cfg)
+    ra, rb = sa.solve(xa, pa), sb.solve(xb, pb)
+    out = {}
+
+    def work(name, s, x, p):
+        out[name] = [s.solve(x, p) for _ in range(6)]
+
+    ts = [threading.Thread(target=work, args=("a", sa, xa, pa)), threading.Thread(target=work, args=("b", sb, xb, pb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts)
+    assert all(_same(r, ra) for r in out["a"]) and all(_same(r, rb) for r in out["b"])
+
+
 def test_full_size_batch_properties():
     """BASELINE metric size: N = 30, nx = 6, B = 4096.  Size-independent properties: every instance converged;
     permuting instances permutes results bit-exactly; splitting the batch changes nothing; the returned points
