@@ -243,18 +243,19 @@ __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_riccati: block-tridiagonal (Riccati) factor + solve.  One workgroup = one tile of 64 instances = two wavefronts:
+// Riccati sweep (riccati_tile; k_riccati is the same as a kernel of its own): block-tridiagonal factor + solve.  One tile of
+// 64 instances = three wavefronts (the second loader, wave 2, only works in the forward sweep):
 //   wave 1 (loader)  streams the condensed stage blocks HBM -> LDS with asynchronous buffer->LDS DMA (1 KiB per wave
 //                    instruction, no VGPR round trip) RIC_DEPTH-1 stages ahead into a ring of RIC_DEPTH slots; its
 //                    vmcnt counter tracks nothing but those DMAs, so "stage k has landed" is an exact s_waitcnt.
-//   wave 0 (compute) one instance per lane: s_barrier -> ds_read of the stage block -> ~220 fp64 FMAs -> fire-and-forget
-//                    stores of gains / cost-to-go; it never waits on HBM.
-// The stage block of stage k is ONE contiguous 512*NBLK-byte chunk of the tile-major workspace, so the LDS image is
-// [row][lane] and every ds_read_b64 is conflict free.  Arithmetic: riccati_backward_step / riccati_forward_step of
+//   wave 0 (compute) one instance per lane: s_barrier -> ds_read of the stage block -> ~270 fp64 operations -> 16-byte
+//                    fire-and-forget stores of gains / cost-to-go; it never waits on HBM.
+// The stage block of stage k is ONE contiguous chunk of the tile-major workspace (whole row pairs, 1 KiB each), so the LDS
+// image is [row pair][lane][2] and a lane reads both rows of a pair with one conflict-free ds_read_b128.  Arithmetic: riccati_backward_step / riccati_forward_step of
 // mpc_stage_math.h (shared with the CPU emulation harness).  Inertia correction: if some lane finds an indefinite
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 22 KiB each)
+constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 17 KiB each at nx = 6)
 constexpr int RIC_DEPTH_F = 10;     // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead --
                                     // fed by TWO loader waves (even / odd stages), each limited to 4 stages in flight by the 6-bit vmcnt
 
