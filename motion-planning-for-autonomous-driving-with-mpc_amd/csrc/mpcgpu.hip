@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
 struct PipeArgs {
     uint32_t* ctl;          // control block, zeroed before every launch (layout below)
     uint32_t ntiles;
+    uint32_t xcd_mask;      // bit x: the device has an XCD with HW_REG_XCC_ID x (tile t belongs to the (t mod n)-th of them)
     uint32_t n_ric;         // Riccati workers per XCD (the first arrivals)
     uint32_t cap;           // ready-queue slots per XCD, a power of two >= 2 * items of one XCD
     uint32_t items;         // stage work items per tile = 64 / bx
@@ -506,6 +507,13 @@ __device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_at
 __device__ __forceinline__ void pipe_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pipe_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// which XCDs does this device have?  (one bit per HW_REG_XCC_ID that some workgroup of a grid of 4 x CUs ran on)
+__global__ void k_xcd_census(uint32_t* mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0) atomicOr(mask, 1u << ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u));
+#endif
+}
+
 template <int NX>
 __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -513,12 +521,16 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
     __shared__ int or_slots[2][8];
     __shared__ uint32_t sh_word[4];
     const int t = threadIdx.x;
-    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;        // HW_REG_XCC_ID[3:0]
+    // the XCD this workgroup runs on, as an index among the XCDs the device was seen to have (k_xcd_census at handle
+    // creation: 8 on a whole MI355X, fewer in a partitioned mode); a workgroup on an XCD outside that set has no tiles
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID[3:0]
+    if (!((A.xcd_mask >> xcc) & 1u)) return;
+    const uint32_t n_xcd = (uint32_t)__popc(A.xcd_mask), xcd = (uint32_t)__popc(A.xcd_mask & ((1u << xcc) - 1u));
     uint32_t* X = A.ctl + xcd * PIPE_X_STRIDE;
     uint32_t* abort_w = A.ctl + PIPE_ABORT;
     uint32_t* stage_done = A.ctl + PIPE_HDR;
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(A.ctl + pipe_slots_off(A.ntiles)) + (size_t)xcd * A.cap;
-    const uint32_t n_tiles_x = A.ntiles > xcd ? (A.ntiles - xcd + 7u) >> 3 : 0u;            // tiles xcd, xcd + 8, ...
+    const uint32_t n_tiles_x = A.ntiles > xcd ? (A.ntiles - xcd + n_xcd - 1u) / n_xcd : 0u;   // tiles xcd, xcd + n_xcd, ...
     if (n_tiles_x == 0u) return;
     if ((A.flags & 2u) && t == 0) pipe_st(abort_w, 1u);
     if (t == 0) sh_word[0] = pipe_add(X + 0, 1u);
@@ -540,7 +552,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
             for (uint32_t j = 0; j < n_own; ++j) {
                 if ((fin >> j) & 1u) continue;
                 all_done = false;
-                const uint32_t tile = (slot + j * n_ric) * 8u + xcd;
+                const uint32_t tile = (slot + j * n_ric) * n_xcd + xcd;
                 PIPE_STAMP(11);
                 if (t == 0) {
                     uint32_t ok = 1u;
@@ -1059,6 +1071,7 @@ struct mpc_handle {
     double prof[6] = {0, 0, 0, 0, 0, 0};
     double pipe_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // k_pipeline: ms (profiling only), launches, rounds, Riccati-wait / stage-wait / stage-busy ms summed over workers, items, stage workers + riccati workers / 1000
     int n_cu = 256;
+    uint32_t xcd_mask = 0xFFu;          // XCDs seen by k_xcd_census
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -1123,6 +1136,16 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0) h->n_cu = ncu;
+    }
+    {
+        // the pipeline routes a tile's work by the XCD a workgroup really runs on: learn the set once (d_counter[0] as scratch)
+        uint32_t m = 0;
+        if (hipMemset(h->d_counter, 0, sizeof(uint32_t)) == hipSuccess) {
+            hipLaunchKernelGGL(k_xcd_census, dim3(4 * h->n_cu), dim3(64), 0, h->own_stream, reinterpret_cast<uint32_t*>(h->d_counter));
+            if (hipStreamSynchronize(h->own_stream) == hipSuccess &&
+                hipMemcpy(&m, h->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess && m != 0u && __builtin_popcount(m) <= 8) h->xcd_mask = m;
+            else h->pipe_disabled = true;
+        }
     }
     bool ok_streams = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g)
@@ -1388,9 +1411,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     bool piped = false;
     {
         const char* env = getenv("MPCGPU_PIPELINE");
-        const int tiles_x = (ntiles + 7) / 8;
-        int n_ric = std::min(8, tiles_x);
-        if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(16, tiles_x)));
+        uint32_t xcd_mask = h->xcd_mask;
+        if (getenv("MPCGPU_PIPE_XCD_MASK")) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
+            const uint32_t m = (uint32_t)strtoul(getenv("MPCGPU_PIPE_XCD_MASK"), nullptr, 0) & h->xcd_mask;
+            if (m) xcd_mask = m;
+        }
+        const int n_xcd = __builtin_popcount(xcd_mask);
+        const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
+        const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
+        int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
+        if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(cu_x / 2, tiles_x)));
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
@@ -1401,6 +1431,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             PipeArgs A;
             A.ntiles = (uint32_t)ntiles;
             A.n_ric = (uint32_t)n_ric;
+            A.xcd_mask = xcd_mask;
             A.items = 64u / (uint32_t)bx;
             A.cap = 1;
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;

@@ -111,6 +111,22 @@ def test_single_launch_pipeline_on_collision_avoidance(monkeypatch):
     assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
 
 
+@pytest.mark.parametrize("mask", ["0x0F", "0x81", "0x10"])
+def test_pipeline_on_a_subset_of_the_xcds(mask, monkeypatch):
+    """The pipeline routes a tile's work by the XCD a workgroup really runs on and learns the set of XCDs from the device
+    (8 on a whole MI355X, fewer in a partitioned mode).  MPCGPU_PIPE_XCD_MASK pretends XCDs away: workgroups that land
+    there leave, the tiles are dealt to the remaining ones -- four, two or a single XCD -- and the bits stay the same."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 1500, **kw)
+    s = make_solver(cfg)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    ref = s.solve(x0, p)
+    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    monkeypatch.setenv("MPCGPU_PIPE_XCD_MASK", mask)
+    alt = s.solve(x0, p)
+    assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
+
+
 def test_pipeline_release_protocol_and_restart(monkeypatch):
     """(1) MPCGPU_PIPE_RELEASE adds agent-scope releases on the producers (the hand-off that does not rely on a tile
     staying inside one XCD's L2): same bits.  (2) MPCGPU_PIPE_TEST_ABORT raises the pipeline's abort word: the host
