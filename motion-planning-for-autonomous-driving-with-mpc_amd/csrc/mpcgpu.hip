@@ -995,9 +995,52 @@ __global__ void k_loop_setup(const LoopArgs A) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < A.B) loop_setup_instance(A, b);
 }
-__global__ void k_loop_advance(const Params P, const LoopArgs A, const int i) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < A.B) loop_advance_instance(P, A, b, i);
+// after solve i: what loop_advance_instance (mpc_closed_loop.h, the form the CPU harness steps through) does for one
+// instance, laid out for coalesced rows -- one workgroup per instance, the threads run over the n_w columns of the three
+// row-major rows (solution in, warm start and parameter vector out); thread 0 records the step and integrates the plant.
+// Same values bit for bit (the columns are copies, the plant step is the same code).
+__global__ void __launch_bounds__(128) k_loop_advance(const Params P, const LoopArgs A, const int i) {
+    __shared__ double cur_s[5];
+    const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+    const int N = A.N, nw = 2 * N + 5 * (N + 1);
+    const double* xo = A.x_out + (size_t)b * nw;
+    if (t == 0) {
+        double cur[5], u[2], f[5], s, c, td;
+        for (int q = 0; q < 5; ++q) cur[q] = A.state[(size_t)b * 5 + q];
+        u[0] = xo[0];
+        u[1] = xo[1];
+        for (int q = 0; q < 5; ++q) A.traj[((size_t)b * A.L + i) * 5 + q] = cur[q];
+        A.ctrl[((size_t)b * A.L + i) * 2 + 0] = u[0];
+        A.ctrl[((size_t)b * A.L + i) * 2 + 1] = u[1];
+        if (A.step_status) A.step_status[(size_t)b * A.L + i] = A.status ? A.status[b] : 0;
+        ode_eval<5>(P, cur, u, f, s, c, td);
+        for (int q = 0; q < 5; ++q) { cur[q] = cur[q] + P.dt * f[q]; A.state[(size_t)b * 5 + q] = cur[q]; cur_s[q] = cur[q]; }
+    }
+    __syncthreads();
+    double* x0 = A.x0 + (size_t)b * nw;
+    double* p = A.p + (size_t)b * nw;
+    const double vd = A.vdes[b];
+    const int shift = (i >= A.L - N) ? (i - (A.L - N) + 1) : 0;                 // frozen tail of the reference window (loop_write_reference)
+    for (int q = t; q < nw; q += (int)blockDim.x) {
+        double v0, vp = 0.0;
+        if (q < N) {
+            v0 = xo[2 * ((q + 1 < N) ? q + 1 : N - 1)];                          // all steering rates ...
+        } else if (q < 2 * N) {
+            const int k = q - N;
+            v0 = xo[2 * ((k + 1 < N) ? k + 1 : N - 1) + 1];                      // ... then all accelerations
+        } else {
+            const int r = q - 2 * N, k = r / 5, c = r - 5 * k;
+            v0 = xo[2 * N + 5 * ((k + 1 <= N) ? k + 1 : N) + c];
+            if (k == 0) vp = cur_s[c];
+            else {
+                const int idx = i + k - shift;                                    // = i_done + (k - 1) + 1 - shift
+                vp = (c == 0) ? A.path[((size_t)b * A.Lp + idx) * 2] : (c == 1) ? A.path[((size_t)b * A.Lp + idx) * 2 + 1]
+                   : (c == 2) ? 0.0 : (c == 3) ? vd : A.orient[(size_t)b * A.Lp + idx];
+            }
+        }
+        x0[q] = v0;
+        p[q] = vp;
+    }
 }
 
 template <int NX>
@@ -1737,7 +1780,7 @@ int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, c
     for (int i = 0; i < L; ++i) {
         rc = solve_dev(h, B, h->d_x0, h->d_p, nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, stream, nullptr, 0, nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_loop_advance, grid, block, 0, stream, P, A, i);
+        hipLaunchKernelGGL(k_loop_advance, dim3(B), dim3(128), 0, stream, P, A, i);
     }
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
