@@ -112,7 +112,7 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
 // WsLayout members are ROW offsets inside a tile (all even: rows are stored in pairs, see mpc_prow in mpc_stage_math.h);
 // element(row, b) = (b >> 6) * tile_elems + mpc_prow(row) + 2 * (b & 63).
 struct WsLayout {
-    size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, EV, ROLL, SC, FILT, OBST;
+    size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, ROLL, SC, FILT, OBST;
     size_t rows, irows;          // rows per tile (double / int32 workspace)
     size_t tile_elems, itile_elems, ntiles;
     size_t total, itotal;        // elements to allocate
@@ -130,7 +130,7 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     w.Z = take(S * NZ); w.ZL = take(S * NZ); w.ZU = take(S * NZ);
     w.SO = take(S * 4); w.NUO = take(S * 4); w.ZLO = take(S * 4); w.ZUO = take(S * 4);
     w.LAM = take(S * XS); w.REF = take(S * XS); w.DZ = take(S * NZ);
-    w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.EV = take(0); w.ROLL = take(S * XS);
+    w.PK = take(S * NPK); w.KK = take((size_t)N * NKK); w.BLK = take(S * NBLK); w.ROLL = take(S * XS);
     w.SC = take(SC_COUNT); w.FILT = take(2 * FILTER_MAX); w.OBST = take(6);
     w.rows = off;
     w.irows = ev(IS_COUNT);
@@ -176,7 +176,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.Z = base + w.Z * 64; P.ZL = base + w.ZL * 64; P.ZU = base + w.ZU * 64;
     P.SO = base + w.SO * 64; P.NUO = base + w.NUO * 64; P.ZLO = base + w.ZLO * 64; P.ZUO = base + w.ZUO * 64;
     P.LAM = base + w.LAM * 64; P.REF = base + w.REF * 64; P.DZ = base + w.DZ * 64; P.PK = base + w.PK * 64; P.KK = base + w.KK * 64;
-    P.BLK = base + w.BLK * 64; P.EV = base + w.EV * 64; P.ROLL = base + w.ROLL * 64; P.SC = base + w.SC * 64;
+    P.BLK = base + w.BLK * 64; P.ROLL = base + w.ROLL * 64; P.SC = base + w.SC * 64;
     P.FILT = base + w.FILT * 64; P.OBST = base + w.OBST * 64;
     P.tile_elems = (uint32_t)w.tile_elems; P.itile_elems = (uint32_t)w.itile_elems;
     P.ISC = ibase;

@@ -106,7 +106,6 @@ struct Params {
     double *PK;                  // [(N+1)*(NS+NX)][Bp]  cost-to-go P_k (upper triangle) and p_k
     double *KK;                  // [N*(2*NX+2)][Bp]     feedback gains K_k, k_k
     double *BLK;                 // [(N+1)*NBLK][Bp]     condensed stage blocks consumed by the Riccati sweep
-    double *EV;                  // (unused: circle distances / Jacobians are recomputed from the iterate instead of passing through HBM)
     double *ROLL;                // [(N+1)*NX][Bp]       dynamics rollout of the warm-start controls (start-point safeguard)
     double *SC;                  // [SC_COUNT][Bp]
     double *FILT;                // [2*FILTER_MAX][Bp]
@@ -274,7 +273,6 @@ struct Dim {
     static constexpr int NBLK = NH + 10 + 2 * NX;
     static constexpr int NPK = NS + NX;
     static constexpr int NKK = 2 * NX + 2;
-    static constexpr int NEV = 12;
     MPC_HD static constexpr int sidx(int i, int j) { return i * NX - i * (i - 1) / 2 + (j - i); }   // i <= j
 };
 
