@@ -114,6 +114,8 @@ int mpc_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const doub
 /* Batched plant step on the device path: x_next = x + dt f(x,u) (integrator 0 = forward Euler,
  * optimizer.py:649-650) or one RK4 step (integrator 1, optimizer.py:97-98).  x: [B, nx], u: [B, 2] host. */
 int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x, const double* u, double* x_next);
+/* same with device pointers; the kernel is enqueued on `stream`, nothing is synchronised or allocated */
+int mpc_plant_step_dev(mpc_handle* h, int32_t B, int32_t integrator, const double* d_x, const double* d_u, double* d_x_next, void* stream);
 
 /* Closed-loop driver (scope row f1): the loop body of CasadiOptimizer.optimize (optimizer.py:596-631) run for B egos
  * without host round trips between the solves -- per step: mpc_solve_batch_dev, first control, forward-Euler plant
@@ -162,6 +164,21 @@ int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const dou
 int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
                               const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl,
                               int32_t* d_step_status, void* stream);
+/* device-pointer forms of the two entry points above: work enqueued on `stream`, no allocation per call (scratch lives in
+ * the handle), no synchronisation.  lb / ub / hl / hu of the FORCES solve are small HOST arrays (they go by value).      */
+int mpc_metrics_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* d_traj, const double* d_ref_path,
+                          const double* d_origin_path, double r_sum, int32_t all_pairs, double* d_deviation, double* d_rmsd,
+                          double* d_clearance, void* stream);
+int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_xinit, const double* d_all_parameters,
+                               const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
+                               double* d_x_out, int32_t* d_exitflag, int32_t* d_it, double* d_res, void* stream);
+
+/* Run-time switches of a handle.  They are read from the environment once, at mpc_create (MPCGPU_<NAME IN CAPITALS>), and
+ * changed afterwards only through this call; value NULL restores the default.  Names: "pipeline" (0: one launch per kernel
+ * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances),
+ * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing"
+ * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
+int mpc_set_option(mpc_handle* h, const char* name, const char* value);
 
 /* ---- measurement helpers (bench.py / tests) ---------------------------------------------------------- */
 /* kernel timing of the LAST mpc_solve_batch[_dev] call, measured with HIP events on the solve stream when

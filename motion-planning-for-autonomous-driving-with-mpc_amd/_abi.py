@@ -45,7 +45,7 @@ EXPORTS = [
     "mpc_default_desc", "mpc_create", "mpc_destroy", "mpc_last_error", "mpc_set_bounds", "mpc_solve_batch",
     "mpc_solve_batch_dev", "mpc_plant_step", "mpc_set_profiling", "mpc_get_profile", "mpc_solve_batch_trace",
     "mpc_abi_version", "mpc_closed_loop_batch", "mpc_closed_loop_batch_dev", "mpc_metrics_batch", "mpc_forces_stage_eval", "mpc_forces_solve_batch",
-    "mpc_get_pipeline_profile",
+    "mpc_get_pipeline_profile", "mpc_plant_step_dev", "mpc_metrics_batch_dev", "mpc_forces_solve_batch_dev", "mpc_set_option",
 ]
 
 
@@ -113,6 +113,14 @@ def load_library(path: str | None = None):
     L.mpc_forces_stage_eval.restype = C.c_int
     L.mpc_forces_solve_batch.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, _dp, _ip, _ip, _dp]
     L.mpc_forces_solve_batch.restype = C.c_int
+    L.mpc_plant_step_dev.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    L.mpc_plant_step_dev.restype = C.c_int
+    L.mpc_metrics_batch_dev.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_double, C.c_int32, vp, vp, vp, vp]
+    L.mpc_metrics_batch_dev.restype = C.c_int
+    L.mpc_forces_solve_batch_dev.argtypes = [vp, C.c_int32, vp, vp, vp, _dp, _dp, _dp, _dp, C.c_int32, vp, vp, vp, vp, vp]
+    L.mpc_forces_solve_batch_dev.restype = C.c_int
+    L.mpc_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.mpc_set_option.restype = C.c_int
     L.mpc_abi_version.argtypes = []
     L.mpc_abi_version.restype = C.c_int
     if path == LIB_PATH:

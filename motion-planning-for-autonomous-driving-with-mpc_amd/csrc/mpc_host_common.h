@@ -39,6 +39,7 @@ inline int validate_desc(const mpc_problem_desc& d, std::string& err) {
     if (d.formulation != MPC_FORM_CASADI_EULER) { err = "unsupported formulation"; return MPC_ERR_INVALID; }
     if (!(d.dt > 0) || !(d.wheelbase > 0) || !(d.friction_div != 0) || !(d.tol > 0)) { err = "dt, wheelbase, tol must be > 0"; return MPC_ERR_INVALID; }
     if (d.obst_mult < 1 || d.max_iter < 1 || d.fixed_iters < 0) { err = "obst_mult>=1, max_iter>=1, fixed_iters>=0 required"; return MPC_ERR_INVALID; }
+    if (d.max_iter > 1024 || d.fixed_iters > 1024) { err = "max_iter / fixed_iters above 1024 (the convergence-poll table)"; return MPC_ERR_INVALID; }
     return MPC_OK;
 }
 

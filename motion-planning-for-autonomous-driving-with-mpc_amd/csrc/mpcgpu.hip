@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1116,9 +1117,67 @@ struct mpc_handle {
     int n_cu = 256;
     uint32_t xcd_mask = 0xFFu;          // XCDs seen by k_xcd_census
     std::vector<hipEvent_t> ev_pool;
+    bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
+    // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
+    // mpc_set_option -- no getenv on the solve path
+    struct Knobs {
+        int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
+        int rescue = 1;
+        uint32_t pipe_xcd_mask = 0;
+    } knobs;
+    // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
+    static constexpr int N_SCRATCH = 16;
+    void* scratch[N_SCRATCH] = {};
+    size_t scratch_cap[N_SCRATCH] = {};
 };
 
-static std::string g_create_error;
+// error text of the last failed mpc_create on this thread (a handle does not exist yet to carry it)
+static thread_local std::string g_create_error;
+
+static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
+    const std::string n(name ? name : "");
+    const char* v = value ? value : "";
+    const long iv = strtol(v, nullptr, 0);
+    const int on = (value == nullptr) ? 0 : ((v[0] == '\0') ? 1 : (int)iv);   // "" (variable set, no value) counts as on
+    if (n == "big_wg") k.big_wg = on != 0;
+    else if (n == "stage_timing") k.stage_timing = on != 0;
+    else if (n == "groups") k.groups = (int)iv;
+    else if (n == "pipeline") k.pipeline = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "pipe_ric") k.pipe_ric = (int)iv;
+    else if (n == "pipe_release") k.pipe_release = on != 0;
+    else if (n == "pipe_test_abort") k.pipe_test_abort = on != 0;
+    else if (n == "pipe_timing") k.pipe_timing = on != 0;
+    else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
+    else return MPC_ERR_INVALID;
+    return MPC_OK;
+}
+static void knobs_from_env(mpc_handle::Knobs& k) {
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "pipe_xcd_mask"};
+    for (const char* n : names) {
+        std::string env = "MPCGPU_";
+        for (const char* c = n; *c; ++c) env += (char)toupper(*c);
+        const char* v = getenv(env.c_str());
+        if (v) (void)set_knob(k, n, v);
+    }
+}
+// device scratch buffer `slot` of at least `bytes` (grow-only, owned by the handle)
+static void* scratch_get(mpc_handle* h, int slot, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (h->scratch_cap[slot] < bytes) {
+        if (h->scratch[slot]) (void)hipFree(h->scratch[slot]);
+        h->scratch[slot] = nullptr; h->scratch_cap[slot] = 0;
+        if (hipMalloc(&h->scratch[slot], bytes) != hipSuccess) return nullptr;
+        h->scratch_cap[slot] = bytes;
+    }
+    return h->scratch[slot];
+}
+// device buffer freed when it goes out of scope (debug / trace buffers of one call)
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
 
 #define HIP_TRY(h, expr)                                                                              \
     do {                                                                                              \
@@ -1169,6 +1228,7 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     if (!h) { g_create_error = "out of host memory"; return MPC_ERR_INVALID; }
     h->hp.desc = *desc;
     h->device = desc->device;
+    knobs_from_env(h->knobs);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT) != hipSuccess ||
         hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess) {
@@ -1215,6 +1275,7 @@ int mpc_destroy(mpc_handle* h) {
     if (h->h_pipe) (void)hipHostFree(h->h_pipe);
     if (h->d_tile_mask) (void)hipFree(h->d_tile_mask);
     if (h->d_state) (void)hipFree(h->d_state);
+    for (void* sp : h->scratch) if (sp) (void)hipFree(sp);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1247,6 +1308,13 @@ int mpc_set_profiling(mpc_handle* h, int32_t enable) {
     return MPC_OK;
 }
 
+int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
+    if (!h || !name) return MPC_ERR_INVALID;
+    const int rc = set_knob(h->knobs, name, value);
+    if (rc) h->err = std::string("unknown option: ") + name;
+    return rc;
+}
+
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]) {
     if (!h || !out) return MPC_ERR_INVALID;
     for (int i = 0; i < 8; ++i) out[i] = h->pipe_prof[i];
@@ -1264,7 +1332,6 @@ int mpc_get_profile(const mpc_handle* h, double out[6]) {
 static int ensure_ws(mpc_handle* h, size_t Bp) {
     if (Bp <= h->cap_Bp) return MPC_OK;
     free_ws(h);
-    // workspace addressing depends on Bp, so it is (re)allocated exactly for the padded batch size
     const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp);
     if (w.total * sizeof(double) >= ((size_t)1 << 32)) {
         h->err = "batch too large: the workspace must stay below 4 GiB (32-bit buffer offsets); split the batch";
@@ -1314,13 +1381,14 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                           double* trace, int32_t trace_rows, int32_t* n_it_out) {
     const mpc_problem_desc& d = h->hp.desc;
     const size_t Bp = ((size_t)B + 63) / 64 * 64;
-    // the SoA stride is Bp: keep one workspace per distinct padded size (re-allocate when it changes)
-    if (Bp != h->cap_Bp) { h->cap_Bp = 0; }
+    // tile-major layout: the rows of a tile do not depend on the batch size, so a smaller batch lives in the first tiles of
+    // a larger allocation (grow-only; the rescue path alternates between the full batch and a failed subset)
     int rc = ensure_ws(h, Bp);
     if (rc) return rc;
     // 256-thread stage workgroups (one wave per SIMD, the whole register file, no scratch) hold 8 instances up to N = 31 and
     // 4 up to N = 63 (N = 50, B = 4096: 2.49 ms against 3.25 ms with 512-thread workgroups, 1.99 ms in the pipeline)
-    const bool small_wg = 4 * (d.N + 1) <= 256 && getenv("MPCGPU_BIG_WG") == nullptr;
+    const mpc_handle::Knobs& kn = h->knobs;
+    const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
     const int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
@@ -1333,7 +1401,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     const int S = d.N + 1;
     const int threads = ((S * bx + 63) / 64) * 64;
-    const bool stage_timing = getenv("MPCGPU_STAGE_TIMING") != nullptr;
+    const bool stage_timing = kn.stage_timing != 0;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
     // LDS: reductions | the larger of (stage exchange, multiplier stash of the 256-thread variant) | prefetch images
@@ -1345,15 +1413,14 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((MPC_EV(Dim<NX>::NBLK) * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
     {
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[NX - 5]) {
+        if (!h->attr_set) {        // per handle: the attribute belongs to the function object of the handle's device
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            attr_set[NX - 5] = true;
+            h->attr_set = true;
         }
     }
 
@@ -1363,8 +1430,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (measured on MI355X at B = 4096: 4 groups gain 4 % in fixed-iteration mode and lose in converged mode, where
     //  every group polls on its own; the workgroups of the two kernels cannot share a CU, so the overlap is small.
     //  Kept as an opt-in: MPCGPU_GROUPS=2..4.)
-    if (!trace && !stage_timing && getenv("MPCGPU_GROUPS") != nullptr) {
-        G = atoi(getenv("MPCGPU_GROUPS"));
+    if (!trace && !stage_timing && kn.groups > 0) {
+        G = kn.groups;
         if (G > ntiles / 4) G = ntiles / 4;
         if (G < 1) G = 1;
         if (G > mpc_handle::MAX_GROUPS) G = mpc_handle::MAX_GROUPS;
@@ -1412,8 +1479,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
 
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     const int chunk = d.fixed_iters > 0 ? cap : 4;
+    DevTmp t_trace, t_dbg, t_pdbg;
     double* d_trace = nullptr;
-    if (trace) HIP_TRY(h, hipMalloc(&d_trace, sizeof(double) * 8 * (size_t)B));
+    if (trace) { HIP_TRY(h, hipMalloc(&t_trace.p, sizeof(double) * 8 * (size_t)B)); d_trace = t_trace.as<double>(); }
     auto record_trace = [&](int it) -> int {
         if (!trace || it >= trace_rows) return MPC_OK;
         hipLaunchKernelGGL(k_gather_trace, dim3((B + 255) / 256), dim3(256), 0, stream, h->d_ws + w.SC * 64, (uint32_t)w.tile_elems, B, d_trace);
@@ -1423,7 +1491,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     };
     unsigned long long* d_dbg = nullptr;
     if (stage_timing) {
-        HIP_TRY(h, hipMalloc(&d_dbg, sizeof(unsigned long long) * 16 * (size_t)nblk));
+        HIP_TRY(h, hipMalloc(&t_dbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk));
+        d_dbg = t_dbg.as<unsigned long long>();
         HIP_TRY(h, hipMemset(d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)nblk));
     }
     // Convergence polling: every stage launch adds the number of instances it leaves running to its own device counter;
@@ -1453,24 +1522,23 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     for (int i = 0; i < 8; ++i) h->pipe_prof[i] = 0;
     bool piped = false;
     {
-        const char* env = getenv("MPCGPU_PIPELINE");
         uint32_t xcd_mask = h->xcd_mask;
-        if (getenv("MPCGPU_PIPE_XCD_MASK")) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
-            const uint32_t m = (uint32_t)strtoul(getenv("MPCGPU_PIPE_XCD_MASK"), nullptr, 0) & h->xcd_mask;
+        if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
+            const uint32_t m = kn.pipe_xcd_mask & h->xcd_mask;
             if (m) xcd_mask = m;
         }
         const int n_xcd = __builtin_popcount(xcd_mask);
         const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
         const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
         int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
-        if (getenv("MPCGPU_PIPE_RIC")) n_ric = std::max(1, std::min(atoi(getenv("MPCGPU_PIPE_RIC")), std::min(cu_x / 2, tiles_x)));
+        if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
         // (measured: 7-11 % faster than one launch per kernel at B = 64 ... 1024, 31 % at B = 4096; at B = 8192 the early
         //  finishers of converged mode still gain 15 %, a fixed iteration count loses 8 % -- with two tiles per Riccati
         //  worker both roles are throughput bound and the split of the CUs only costs)
-        if (eligible && !h->pipe_disabled && !(env && env[0] == '0')) {
+        if (eligible && !h->pipe_disabled && kn.pipeline) {
             PipeArgs A;
             A.ntiles = (uint32_t)ntiles;
             A.n_ric = (uint32_t)n_ric;
@@ -1478,7 +1546,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.items = 64u / (uint32_t)bx;
             A.cap = 1;
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
-            A.flags = (getenv("MPCGPU_PIPE_RELEASE") != nullptr ? 1u : 0u) | (getenv("MPCGPU_PIPE_TEST_ABORT") != nullptr ? 2u : 0u);
+            A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u);
             const size_t words = pipe_ctl_words(A.ntiles, A.cap);
             if (h->pipe_words < words) {
                 if (h->d_pipe) (void)hipFree(h->d_pipe);
@@ -1490,8 +1558,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.ctl = h->d_pipe;
             HIP_TRY(h, hipMemsetAsync(h->d_pipe, 0, words * sizeof(uint32_t), stream));
             unsigned long long* d_pdbg = nullptr;
-            if (getenv("MPCGPU_PIPE_TIMING")) {
-                HIP_TRY(h, hipMalloc(&d_pdbg, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
+            if (kn.pipe_timing) {
+                HIP_TRY(h, hipMalloc(&t_pdbg.p, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
+                d_pdbg = t_pdbg.as<unsigned long long>();
                 HIP_TRY(h, hipMemsetAsync(d_pdbg, 0, sizeof(unsigned long long) * 16 * (size_t)h->n_cu, stream));
                 P.DBG = d_pdbg;
             }
@@ -1516,7 +1585,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (d_pdbg) {       // shader-clock stamps of every worker's LAST work item / tile pass
                 std::vector<unsigned long long> hd((size_t)16 * h->n_cu);
                 HIP_TRY(h, hipMemcpy(hd.data(), d_pdbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                (void)hipFree(d_pdbg);
                 double sa[16] = {0}, ra[4] = {0};
                 int ns = 0, nr = 0;
                 for (int bq = 0; bq < h->n_cu; ++bq) {
@@ -1604,7 +1672,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         ++chunk_id;
     }
     P.DBG = nullptr;
-    if (trace) { rc = record_trace(it); if (rc) return rc; (void)hipFree(d_trace); }
+    if (trace) { rc = record_trace(it); if (rc) return rc; }
     if (stage_timing) {
         HIP_TRY(h, hipStreamSynchronize(stream));
         std::vector<unsigned long long> hd((size_t)16 * nblk);
@@ -1634,7 +1702,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             }
             fprintf(stderr, "[mpcgpu riccati timing, ticks per workgroup, mean over %d] backward=%.0f forward=%.0f\n", c2, c2 ? bw / c2 : 0.0, c2 ? fw / c2 : 0.0);
         }
-        (void)hipFree(d_dbg);
     }
     if (n_it_out) *n_it_out = it;
     for (int g = 0; g < G; ++g) {
@@ -1726,24 +1793,36 @@ int mpc_solve_batch_trace(mpc_handle* h, int32_t B, const double* x0, const doub
     return solve_host(h, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it);
 }
 
+int mpc_plant_step_dev(mpc_handle* h, int32_t B, int32_t integrator, const double* d_x, const double* d_u, double* d_x_next, void* stream_) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !d_x || !d_u || !d_x_next || integrator < 0 || integrator > 1) { h->err = "bad plant-step arguments"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nx = h->hp.desc.nx;
+    hipStream_t s = (hipStream_t)stream_;
+    Params P{};
+    P.dt = h->hp.desc.dt; P.wheelbase = h->hp.desc.wheelbase; P.nx = nx;
+    if (nx == 5) hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 255) / 256), dim3(256), 0, s, P, d_x, d_u, d_x_next, B, integrator);
+    else hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 255) / 256), dim3(256), 0, s, P, d_x, d_u, d_x_next, B, integrator);
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
 int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x, const double* u, double* x_next) {
     if (!h) return MPC_ERR_INVALID;
     if (B <= 0 || !x || !u || !x_next || integrator < 0 || integrator > 1) { h->err = "bad plant-step arguments"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
-    const int nx = h->hp.desc.nx;
-    double *dx = nullptr, *du = nullptr, *dn = nullptr;
-    HIP_TRY(h, hipMalloc(&dx, (size_t)B * nx * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&du, (size_t)B * 2 * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&dn, (size_t)B * nx * sizeof(double)));
-    HIP_TRY(h, hipMemcpy(dx, x, (size_t)B * nx * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(du, u, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice));
-    Params P{};
-    P.dt = h->hp.desc.dt; P.wheelbase = h->hp.desc.wheelbase; P.nx = nx;
-    if (nx == 5) hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 255) / 256), dim3(256), 0, h->own_stream, P, dx, du, dn, B, integrator);
-    else hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 255) / 256), dim3(256), 0, h->own_stream, P, dx, du, dn, B, integrator);
-    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
-    HIP_TRY(h, hipMemcpy(x_next, dn, (size_t)B * nx * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
+    const size_t nx = (size_t)h->hp.desc.nx, nB = (size_t)B;
+    double* dx = static_cast<double*>(scratch_get(h, 0, nB * nx * 8));       // buffers stay with the handle: optimize() calls this every step
+    double* du = static_cast<double*>(scratch_get(h, 1, nB * 2 * 8));
+    double* dn = static_cast<double*>(scratch_get(h, 2, nB * nx * 8));
+    if (!dx || !du || !dn) { h->err = "plant step: out of device memory"; return MPC_ERR_HIP; }
+    hipStream_t s = h->own_stream;
+    HIP_TRY(h, hipMemcpyAsync(dx, x, nB * nx * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(du, u, nB * 2 * 8, hipMemcpyHostToDevice, s));
+    const int rc = mpc_plant_step_dev(h, B, integrator, dx, du, dn, (void*)s);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_next, dn, nB * nx * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
     return MPC_OK;
 }
 
@@ -1821,6 +1900,22 @@ int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const
     return rc;
 }
 
+int mpc_metrics_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* d_traj, const double* d_ref_path, const double* d_origin_path,
+                          double r_sum, int32_t all_pairs, double* d_deviation, double* d_rmsd, double* d_clearance, void* stream_) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L < 2 || !d_traj || (d_deviation && (!d_origin_path || Lo <= 0))) { h->err = "metrics: B > 0, L >= 2, traj (and origin_path with deviation) are required"; return MPC_ERR_INVALID; }
+    if (d_rmsd && !d_ref_path) { h->err = "metrics: rmsd needs ref_path"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream_;
+    double* dob = static_cast<double*>(scratch_get(h, 3, 6 * 8));
+    if (!dob) { h->err = "metrics: out of device memory"; return MPC_ERR_HIP; }
+    HIP_TRY(h, hipMemcpyAsync(dob, h->hp.desc.obstacle, 6 * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_metrics, dim3(B), dim3(256), 0, s, L, Lo, d_traj, d_ref_path, d_origin_path, dob, h->hp.desc.ego_offset, r_sum, (int)all_pairs,
+                       d_deviation, d_rmsd, d_clearance);
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
 int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* traj, const double* ref_path, const double* origin_path,
                       double r_sum, int32_t all_pairs, double* deviation, double* rmsd, double* clearance) {
     if (!h) return MPC_ERR_INVALID;
@@ -1828,26 +1923,23 @@ int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const dou
     if (rmsd && !ref_path) { h->err = "metrics: rmsd needs ref_path"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t nB = (size_t)B;
-    double *dt_ = nullptr, *dr = nullptr, *dorig = nullptr, *dob = nullptr, *ddev = nullptr, *drm = nullptr, *dcl = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dt_); (void)hipFree(dr); (void)hipFree(dorig); (void)hipFree(dob); (void)hipFree(ddev); (void)hipFree(drm); (void)hipFree(dcl); };
     hipStream_t s = h->own_stream;
-    bool ok = hipMalloc(&dt_, nB * L * 5 * 8) == hipSuccess && hipMalloc(&dob, 6 * 8) == hipSuccess &&
-              hipMemcpyAsync(dt_, traj, nB * L * 5 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
-              hipMemcpyAsync(dob, h->hp.desc.obstacle, 6 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok && rmsd) ok = hipMalloc(&dr, nB * L * 2 * 8) == hipSuccess && hipMalloc(&drm, nB * 2 * 8) == hipSuccess &&
-                         hipMemcpyAsync(dr, ref_path, nB * L * 2 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok && deviation) ok = hipMalloc(&dorig, nB * Lo * 2 * 8) == hipSuccess && hipMalloc(&ddev, nB * L * 8) == hipSuccess &&
-                              hipMemcpyAsync(dorig, origin_path, nB * Lo * 2 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok && clearance) ok = hipMalloc(&dcl, nB * 8) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_metrics, dim3(B), dim3(256), 0, s, L, Lo, dt_, dr, dorig, dob, h->hp.desc.ego_offset, r_sum, (int)all_pairs, ddev, drm, dcl);
-        if (deviation) ok = ok && hipMemcpyAsync(deviation, ddev, nB * L * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (rmsd) ok = ok && hipMemcpyAsync(rmsd, drm, nB * 2 * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (clearance) ok = ok && hipMemcpyAsync(clearance, dcl, nB * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-        ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    }
-    cleanup();
-    if (!ok) { h->err = "metrics: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
+    double* dt_ = static_cast<double*>(scratch_get(h, 4, nB * L * 5 * 8));
+    double* dr = rmsd ? static_cast<double*>(scratch_get(h, 5, nB * L * 2 * 8)) : nullptr;
+    double* drm = rmsd ? static_cast<double*>(scratch_get(h, 6, nB * 2 * 8)) : nullptr;
+    double* dorig = deviation ? static_cast<double*>(scratch_get(h, 7, nB * Lo * 2 * 8)) : nullptr;
+    double* ddev = deviation ? static_cast<double*>(scratch_get(h, 8, nB * L * 8)) : nullptr;
+    double* dcl = clearance ? static_cast<double*>(scratch_get(h, 9, nB * 8)) : nullptr;
+    if (!dt_ || (rmsd && (!dr || !drm)) || (deviation && (!dorig || !ddev)) || (clearance && !dcl)) { h->err = "metrics: out of device memory"; return MPC_ERR_HIP; }
+    HIP_TRY(h, hipMemcpyAsync(dt_, traj, nB * L * 5 * 8, hipMemcpyHostToDevice, s));
+    if (rmsd) HIP_TRY(h, hipMemcpyAsync(dr, ref_path, nB * L * 2 * 8, hipMemcpyHostToDevice, s));
+    if (deviation) HIP_TRY(h, hipMemcpyAsync(dorig, origin_path, nB * Lo * 2 * 8, hipMemcpyHostToDevice, s));
+    const int rc = mpc_metrics_batch_dev(h, B, L, Lo, dt_, dr, dorig, r_sum, all_pairs, ddev, drm, dcl, (void*)s);
+    if (rc) return rc;
+    if (deviation) HIP_TRY(h, hipMemcpyAsync(deviation, ddev, nB * L * 8, hipMemcpyDeviceToHost, s));
+    if (rmsd) HIP_TRY(h, hipMemcpyAsync(rmsd, drm, nB * 2 * 8, hipMemcpyDeviceToHost, s));
+    if (clearance) HIP_TRY(h, hipMemcpyAsync(clearance, dcl, nB * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
     return MPC_OK;
 }
 
@@ -1883,46 +1975,63 @@ int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const doub
     return MPC_OK;
 }
 
-int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* xinit, const double* all_parameters,
-                           const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
-                           double* x_out, int32_t* exitflag, int32_t* it, double* res) {
+int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_xinit, const double* d_all_parameters,
+                               const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
+                               double* d_x_out, int32_t* d_exitflag, int32_t* d_it, double* d_res, void* stream_) {
     if (!h) return MPC_ERR_INVALID;
-    if (B <= 0 || !x0 || !xinit || !all_parameters || !lb || !ub || !hl || !hu || !x_out) { h->err = "forces solve: null or empty argument"; return MPC_ERR_INVALID; }
+    if (B <= 0 || !d_x0 || !d_xinit || !d_all_parameters || !lb || !ub || !hl || !hu || !d_x_out) { h->err = "forces solve: null or empty argument"; return MPC_ERR_INVALID; }
     const mpc_problem_desc& d = h->hp.desc;
     if (d.nx != 5) { h->err = "the FORCES formulation has 5 states (z = [deltaDot, aLong, x, y, delta, v, psi])"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     const int N = d.N;
     const size_t nB = (size_t)B, Bp = (nB + 63) / 64 * 64;
-    double *dz = nullptr, *dxi = nullptr, *dpar = nullptr, *dout = nullptr, *dres = nullptr, *dws = nullptr;
-    int32_t *dflag = nullptr, *dit = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dz); (void)hipFree(dxi); (void)hipFree(dpar); (void)hipFree(dout); (void)hipFree(dres); (void)hipFree(dws); (void)hipFree(dflag); (void)hipFree(dit); };
+    hipStream_t s = (hipStream_t)stream_;
+    double* dws = static_cast<double*>(scratch_get(h, 10, (size_t)FQ_ROWS * N * Bp * 8));
+    int32_t* dflag = d_exitflag ? d_exitflag : static_cast<int32_t*>(scratch_get(h, 11, nB * 4));
+    int32_t* dit = d_it ? d_it : static_cast<int32_t*>(scratch_get(h, 12, nB * 4));
+    double* dres = d_res ? d_res : static_cast<double*>(scratch_get(h, 13, nB * 8));
+    if (!dws || !dflag || !dit || !dres) { h->err = "forces solve: out of device memory"; return MPC_ERR_HIP; }
+    ForcesQpArgs A{};
+    A.B = B; A.Bp = (int32_t)Bp; A.N = N; A.max_it = 60;
+    A.dt = d.dt; A.l = d.wheelbase; A.wb = d.friction_div; A.rho = d.ego_offset;
+    A.tol = 1e-4; A.tol_mu = 1e-6;
+    for (int i = 0; i < 5; ++i) { A.Q[i] = d.Q[i]; A.Pt[i] = d.P[i]; }
+    A.R[0] = d.R[0]; A.R[1] = d.R[1];
+    forces_hessian_diag(hessian_mode, A.Q, A.R, A.Pt, A.hd, A.hdN);
+    for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
+    for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
+    A.zbar = d_x0; A.params = d_all_parameters; A.xinit = d_xinit; A.z_out = d_x_out; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws;
+    hipLaunchKernelGGL(k_forces_qp, dim3((B + 63) / 64), dim3(64), 0, s, A);
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* xinit, const double* all_parameters,
+                           const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
+                           double* x_out, int32_t* exitflag, int32_t* it, double* res) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || !x0 || !xinit || !all_parameters || !lb || !ub || !hl || !hu || !x_out) { h->err = "forces solve: null or empty argument"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->hp.desc.N, nB = (size_t)B;
     hipStream_t s = h->own_stream;
-    bool ok = hipMalloc(&dz, nB * N * 7 * 8) == hipSuccess && hipMalloc(&dxi, nB * 5 * 8) == hipSuccess && hipMalloc(&dpar, nB * N * 10 * 8) == hipSuccess &&
-              hipMalloc(&dout, nB * N * 7 * 8) == hipSuccess && hipMalloc(&dres, nB * 8) == hipSuccess && hipMalloc(&dflag, nB * 4) == hipSuccess &&
-              hipMalloc(&dit, nB * 4) == hipSuccess && hipMalloc(&dws, (size_t)FQ_ROWS * N * Bp * 8) == hipSuccess;
-    ok = ok && hipMemcpyAsync(dz, x0, nB * N * 7 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(dxi, xinit, nB * 5 * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(dpar, all_parameters, nB * N * 10 * 8, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok) {
-        ForcesQpArgs A{};
-        A.B = B; A.Bp = (int32_t)Bp; A.N = N; A.max_it = 60;
-        A.dt = d.dt; A.l = d.wheelbase; A.wb = d.friction_div; A.rho = d.ego_offset;
-        A.tol = 1e-4; A.tol_mu = 1e-6;
-        for (int i = 0; i < 5; ++i) { A.Q[i] = d.Q[i]; A.Pt[i] = d.P[i]; }
-        A.R[0] = d.R[0]; A.R[1] = d.R[1];
-        forces_hessian_diag(hessian_mode, A.Q, A.R, A.Pt, A.hd, A.hdN);
-        for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
-        for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
-        A.zbar = dz; A.params = dpar; A.xinit = dxi; A.z_out = dout; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws;
-        hipLaunchKernelGGL(k_forces_qp, dim3((B + 63) / 64), dim3(64), 0, s, A);
-        ok = hipMemcpyAsync(x_out, dout, nB * N * 7 * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (exitflag) ok = ok && hipMemcpyAsync(exitflag, dflag, nB * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (it) ok = ok && hipMemcpyAsync(it, dit, nB * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-        if (res) ok = ok && hipMemcpyAsync(res, dres, nB * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-        ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    }
-    cleanup();
-    if (!ok) { h->err = "forces solve: HIP allocation, copy or launch failed"; return MPC_ERR_HIP; }
+    double* dz = static_cast<double*>(scratch_get(h, 4, nB * N * 7 * 8));
+    double* dxi = static_cast<double*>(scratch_get(h, 5, nB * 5 * 8));
+    double* dpar = static_cast<double*>(scratch_get(h, 6, nB * N * 10 * 8));
+    double* dout = static_cast<double*>(scratch_get(h, 7, nB * N * 7 * 8));
+    double* dres = static_cast<double*>(scratch_get(h, 13, nB * 8));
+    int32_t* dflag = static_cast<int32_t*>(scratch_get(h, 11, nB * 4));
+    int32_t* dit = static_cast<int32_t*>(scratch_get(h, 12, nB * 4));
+    if (!dz || !dxi || !dpar || !dout || !dres || !dflag || !dit) { h->err = "forces solve: out of device memory"; return MPC_ERR_HIP; }
+    HIP_TRY(h, hipMemcpyAsync(dz, x0, nB * N * 7 * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dxi, xinit, nB * 5 * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dpar, all_parameters, nB * N * 10 * 8, hipMemcpyHostToDevice, s));
+    const int rc = mpc_forces_solve_batch_dev(h, B, dz, dxi, dpar, lb, ub, hl, hu, hessian_mode, dout, dflag, dit, dres, (void*)s);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_out, dout, nB * N * 7 * 8, hipMemcpyDeviceToHost, s));
+    if (exitflag) HIP_TRY(h, hipMemcpyAsync(exitflag, dflag, nB * 4, hipMemcpyDeviceToHost, s));
+    if (it) HIP_TRY(h, hipMemcpyAsync(it, dit, nB * 4, hipMemcpyDeviceToHost, s));
+    if (res) HIP_TRY(h, hipMemcpyAsync(res, dres, nB * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
     return MPC_OK;
 }
 

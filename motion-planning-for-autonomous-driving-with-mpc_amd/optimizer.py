@@ -123,7 +123,8 @@ class NlpSolverHandle:
         be = self._backend
         x0a = np.asarray(x0.full() if hasattr(x0, "full") else x0, dtype=np.float64)
         pa = np.asarray(p.full() if hasattr(p, "full") else p, dtype=np.float64)
-        batched = x0a.ndim == 2 and x0a.shape[1] == be.n_w and x0a.shape[0] != be.n_w
+        # a batch is [B, n_w]; the reference's own column vector is (n_w, 1) (optimizer.py:602) -- B == n_w is a batch too
+        batched = x0a.ndim == 2 and x0a.shape[1] == be.n_w and x0a.shape != (be.n_w, 1)
         if not batched:
             x0a = x0a.reshape(1, -1)
             pa = pa.reshape(1, -1)
@@ -348,8 +349,9 @@ class ForcesSolverHandle(object):
     """`solver` of `model, solver = self.solver()`: `solver.solve(problem)` -> (output, exitflag, info)
     (test/FORCESNLPsolver/interface/FORCESNLPsolver_py.py:181-300), one SQP step per call on the device."""
 
-    def __init__(self, backend, model):
+    def __init__(self, backend, model, hessian_mode=0):
         self._backend, self._model = backend, model
+        self.hessian_mode = int(hessian_mode)
 
     def solve(self, problem):
         N = self._model.N
@@ -361,7 +363,7 @@ class ForcesSolverHandle(object):
         par = np.asarray(problem["all_parameters"], dtype=np.float64).reshape(B, N, 10)
         t_ = time.time()
         m = self._model
-        x, flag, it, res = self._backend.forces_solve(x0, xinit, par, m.lb, m.ub, m.hl, m.hu)
+        x, flag, it, res = self._backend.forces_solve(x0, xinit, par, m.lb, m.ub, m.hl, m.hu, hessian_mode=self.hessian_mode)
         dt = time.time() - t_
         fmt = "x{0:02d}" if N >= 10 else "x{0:1d}"
         if batched:
@@ -380,10 +382,17 @@ class ForcesproOptimizer(Optimizer):
     generated, licence-locked binary (FORCESNLPsolver.h:209-210): its numerics cannot be matched, only its formulation
     (stage functions pinned against the generated C, row a11) and its call surface."""
 
-    def __init__(self, configuration, init_values, predict_horizon, device=0):
+    # QP Hessian of the SQP step: 0 = exact Hessian of the least-squares cost (Gauss-Newton; the default HERE), 1 = the literal
+    # `bfgs_init = 2.5 I` of optimizer.py:234-237 (with one QP per call and a guess that is never refreshed it would stay
+    # 2.5 I; see csrc/mpc_forces_qp.h: forces_hessian_diag and INTEGRATION.md for why that is not the default)
+    hessian_mode = 0
+
+    def __init__(self, configuration, init_values, predict_horizon, device=0, hessian_mode=None):
         super(ForcesproOptimizer, self).__init__(configuration, init_values, predict_horizon)
         self._device = device
         self._pair = None
+        if hessian_mode is not None:
+            self.hessian_mode = int(hessian_mode)
 
     def inequal_constraint(self):
         """optimizer.py:100-119."""
@@ -406,7 +415,7 @@ class ForcesproOptimizer(Optimizer):
                                        friction_div=self.configuration.wheelbase, ego_offset=(disc_distance / 2) / 2, device=self._device)
             lb, ub, hl, hu = self.inequal_constraint()
             model = ForcesModel(self.predict_horizon, backend, lb, ub, hl, hu)
-            self._pair = (model, ForcesSolverHandle(backend, model))
+            self._pair = (model, ForcesSolverHandle(backend, model, self.hessian_mode))
         return self._pair
 
     def runtime_parameters(self, k, N):

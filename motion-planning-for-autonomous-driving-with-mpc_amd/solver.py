@@ -242,6 +242,12 @@ class BatchedMPCSolver:
                                                      _abi.as_ip(flag), _abi.as_ip(it), _abi.as_dp(res)))
         return out, flag, it, res
 
+    def set_option(self, name, value=None):
+        """run-time switch of the handle (include/mpcgpu.h: mpc_set_option); value None restores the default.  The
+        environment (MPCGPU_<NAME>) is only read when the handle is created."""
+        v = None if value is None else str(value).encode()
+        self._check(self._lib.mpc_set_option(self._h, str(name).encode(), v))
+
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))
 

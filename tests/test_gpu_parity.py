@@ -68,7 +68,7 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
     x0, p = synthetic_batch(cfg, 600, **kw)
     s = make_solver(cfg)
     ref = s.solve(x0, p)
-    monkeypatch.setenv(env, "2" if env == "MPCGPU_GROUPS" else "1")
+    s.set_option(env[len("MPCGPU_"):].lower(), "2" if env == "MPCGPU_GROUPS" else "1")
     for _ in range(4):
         alt = s.solve(x0, p)
         assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
@@ -86,10 +86,10 @@ def test_single_launch_pipeline_is_bit_identical(B, fixed, monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, B, **kw)
     s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     assert not s.get_pipeline_profile()["ran"]
-    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    s.set_option("pipeline", "1")
     for _ in range(3):                       # repeated: the hand-offs must not depend on what the caches hold from the last solve
         alt = s.solve(x0, p)
         pp = s.get_pipeline_profile()
@@ -104,9 +104,9 @@ def test_single_launch_pipeline_on_collision_avoidance(monkeypatch):
     x0, p = ca_batch(CA_CFG, B)
     s = make_solver(CA_CFG)
     set_cfg_bounds(s, CA_CFG)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
+    s.set_option("pipeline", "1")
     alt = s.solve(x0, p)
     assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
 
@@ -119,10 +119,10 @@ def test_pipeline_on_a_subset_of_the_xcds(mask, monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 1500, **kw)
     s = make_solver(cfg)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
-    monkeypatch.setenv("MPCGPU_PIPE_XCD_MASK", mask)
+    s.set_option("pipeline", "1")
+    s.set_option("pipe_xcd_mask", mask)
     alt = s.solve(x0, p)
     assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
 
@@ -134,15 +134,15 @@ def test_pipeline_release_protocol_and_restart(monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 2048, **kw)
     s = make_solver(cfg)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "0")
+    s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
-    monkeypatch.setenv("MPCGPU_PIPELINE", "1")
-    monkeypatch.setenv("MPCGPU_PIPE_RELEASE", "1")
+    s.set_option("pipeline", "1")
+    s.set_option("pipe_release", "1")
     assert _same(s.solve(x0, p), ref) and s.get_pipeline_profile()["ran"]
-    monkeypatch.delenv("MPCGPU_PIPE_RELEASE")
-    monkeypatch.setenv("MPCGPU_PIPE_TEST_ABORT", "1")
+    s.set_option("pipe_release", None)
+    s.set_option("pipe_test_abort", "1")
     assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]
-    monkeypatch.delenv("MPCGPU_PIPE_TEST_ABORT")
+    s.set_option("pipe_test_abort", None)
     assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]      # this handle stays on the per-kernel path
     assert _same(make_solver(cfg).solve(x0, p), ref)
 

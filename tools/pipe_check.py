@@ -16,7 +16,7 @@ for fixed in (0, 20):
     s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
     res = {}
     for mode in ("0", "1"):
-        os.environ["MPCGPU_PIPELINE"] = mode
+        s.set_option("pipeline", mode)
         r = s.solve(x0, p)
         pp = s.get_pipeline_profile()
         d = [torch.from_numpy(a).cuda() for a in (x0, p)]

@@ -24,9 +24,9 @@ cases.append(("collision avoidance", s, x0, p))
 bad = 0
 t0 = time.time()
 for fam, s, x0, p in cases:
-    os.environ["MPCGPU_PIPELINE"] = "0"
+    s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
-    os.environ["MPCGPU_PIPELINE"] = "1"
+    s.set_option("pipeline", "1")
     reps = max(3, n // len(cases) if "collision" not in fam else n // 40)
     ran = 0
     for _ in range(reps):

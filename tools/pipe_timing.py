@@ -15,6 +15,6 @@ cfg, kw = FAMILIES["zamlf_n30_nx6"]
 x0, p = synthetic_batch(cfg, B, **kw)
 s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
 s.solve(x0, p)                                  # warm-up (allocations, first-touch)
-os.environ["MPCGPU_PIPE_TIMING"] = "1"
+s.set_option("pipe_timing", "1")
 s.solve(x0, p)
 s.solve(x0, p)
