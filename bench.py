@@ -8,29 +8,46 @@ bench.py -- MPC steps/s of the batched NLP solve (the path of MPC_Planner/optimi
 
 One "step" = one pass of the hot path over one batch: B = 4096 independent instances of the N = 30, nx = 6,
 nu = 2 kinematic-bicycle lane-following NLP (BASELINE.json `metric`), synthetic references generated as
-SURVEY.md section 8(d) prescribes, inputs and outputs resident in HBM (mpc_solve_batch_dev).  Every instance is
-solved to the reference's IPOPT tolerance (tol 1e-8, max_iter 100): `value` counts converged NLP solves per
-second, whole job.  With N > 1 each rank solves its own B instances on its own GPU (weak scaling, instances are
-independent: no data-path collective) and the result rows are all-gathered over RCCL once per step.
+SURVEY.md section 8(d) prescribes (tools/workloads.py), inputs and outputs resident in HBM (mpc_solve_batch_dev).
+Every instance is solved to the reference's IPOPT tolerance (tol 1e-8, max_iter 100): `value` counts converged NLP
+solves per second, whole job.  With N > 1 each rank solves its own B instances on its own GPU (weak scaling, instances
+are independent: no data-path collective) and the result rows are all-gathered over RCCL once per step.
 
-Prints ONE JSON line on rank 0 (contract of the build driver) with two extra objects:
-  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the
-                solve stream, measured in a second, profiled pass over the same K steps) against the 8 TB/s HBM peak
-  cpu_baseline  the oracle (oracle/mpc_oracle.c, "port") on the host cores, bounded sample of the same workload
+`--gpus N` without a torch.distributed launcher (WORLD_SIZE unset) starts the N ranks itself and FAILS when fewer than N
+devices are visible; it never reports a smaller n_gpus than it was asked for.
+
+`--workload mixed` runs BASELINE configuration 5 instead (mixed scenario sweep: 4096 rows per GPU dealt over the three
+problem families, one handle per family, one padded all-gather at the end).
+
+Prints ONE JSON line on rank 0 (contract of the build driver) with extra objects:
+  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the solve
+                stream, measured in a second, profiled pass over the same K steps) against the 8 TB/s HBM peak, and
+                against the copy bandwidth measured in this process; `traffic` = HBM bytes per launch from rocprofv3
+                PMC passes run by this very process (FETCH_SIZE / WRITE_SIZE, gfx950 correction), see measure_traffic()
+  cpu_baseline  the oracle (oracle/mpc_oracle.c, "port") on the host cores, bounded sample of the same workload;
+                plus a run-time probe for CasADi/IPOPT (the reference's own solver) on the host
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 N_HORIZON, NX, NU, BATCH = 30, 6, 2, 4096
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PUBLISHED_CASADI = "25.1 steps/s (N=10, 1 instance, unknown CPU, graph rebuilt every step; BASELINE.md section 1: 36-41 ms per step)"
 
 
 def algorithmic_bytes(N, nx, nu=2):
@@ -47,16 +64,149 @@ def algorithmic_bytes(N, nx, nu=2):
     return dict(K=K, I=I, b_iter=b_iter, b_io=b_io, b_riccati=b_riccati, b_stage=b_stage)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes over this very
-    command, tools/pmc_run.sh + tools/pmc_summary.py; counters cannot be read from inside the timed process)."""
+def committed_traffic(kernel):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
     try:
         return json.load(open(path))[kernel]["hbm_bytes_per_launch_mean"]
-    except (KeyError, ValueError):
+    except (OSError, KeyError, ValueError):
         return None
+
+
+def measure_traffic(kernel_tag, timeout=240):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,
+    kernel trace only -- counters get their own runs, MI355X_MICROARCH.md) over `bench.py --pmc-child`, which performs three
+    converged-mode solves of the headline batch and nothing else.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: on gfx950
+    FETCH_SIZE counts 64 B per 128-byte request (the guide's correction; re-checked with tools/ubench/ldpat.hip).
+    Returns (bytes per launch | None, source text)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return committed_traffic("k_pipeline"), "rocprofv3 not found; committed profiles/pmc_traffic.json"
+    out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, ctr)
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--pmc-child"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        except (subprocess.SubprocessError, OSError) as e:
+            shutil.rmtree(out, ignore_errors=True)
+            return committed_traffic("k_pipeline"), "rocprofv3 pass failed (%s); committed profiles/pmc_traffic.json" % type(e).__name__
+        v = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        v.append(float(row["Counter_Value"]))
+        if not v:
+            shutil.rmtree(out, ignore_errors=True)
+            return committed_traffic("k_pipeline"), "no %s rows for %s; committed profiles/pmc_traffic.json" % (ctr, kernel_tag)
+        vals[ctr] = sum(v) / len(v)
+    shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this process (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+
+
+def copy_bandwidth(torch, dev):
+    """achievable HBM bandwidth by a plain device-to-device copy kernel (read + write bytes / time), GB/s"""
+    n = 1 << 28                                           # 2 GiB of doubles in, 2 GiB out
+    a = torch.empty(n, dtype=torch.float64, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(5):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
+
+
+def casadi_probe(fam, x0, p, wl):
+    """probe `import casadi` on this host; when it is there, time nlpsol('ipopt') on the restated NLP
+    (optimizer.py:373-558), solver built once and rebuilt per step (optimizer.py:605); when not, say so."""
+    try:
+        import casadi as ca
+    except Exception as e:                               # expected here: not installed, no network
+        return dict(available=False, note="import casadi failed on this host (%s): the reference's own CasADi/IPOPT path cannot be timed; "
+                                          "its only published figure is %s" % (type(e).__name__, PUBLISHED_CASADI))
+    try:
+        N, nx, dt = fam.N, 5, fam.dt
+        lbx, ubx, lbg, ubg = wl.bounds(wl.Family("probe", N, 5, fam.Q, fam.R))
+
+        def build():
+            U, X = ca.SX.sym("U", 2, N), ca.SX.sym("X", nx, N + 1)
+            Xr = ca.SX.sym("Xr", nx, N + 1)
+            Ur = ca.SX.sym("Ur", 2, N)
+            Q, R = ca.diag(ca.DM(list(fam.Q))), ca.diag(ca.DM(list(fam.R)))
+            f = lambda x, u: ca.vertcat(x[3] * ca.cos(x[4]), x[3] * ca.sin(x[4]), u[0], u[1], x[3] / 2.5789128 * ca.tan(x[2]))   # noqa: E731
+            J = 0
+            g = [ca.sqrt((U[1, 0] ** 2 + X[3, 0] * (ca.tan(X[2, 0]) * X[3, 0] / 2.578)) ** 2), X[:, 0] - Xr[:, 0]]
+            for i in range(N):
+                e = X[:, i] - Xr[:, i + 1]
+                J = J + ca.mtimes([e.T, Q, e]) + ca.mtimes([U[:, i].T, R, U[:, i]])
+                g.append(X[:, i + 1] - (X[:, i] + dt * f(X[:, i], U[:, i])))
+            for i in range(N + 1):
+                for j, sg in ((0, 0.0), (1, 1.0), (2, -1.0)):
+                    cx, cy = X[0, i] + sg * 0.75 * ca.cos(X[4, i]) + 100.0, X[1, i] + sg * 0.75 * ca.sin(X[4, i])
+                    g += [ca.sqrt(cx ** 2 + cy ** 2)] * 3
+            nlp = dict(f=J, x=ca.vertcat(ca.reshape(U, -1, 1), ca.reshape(X, -1, 1)), p=ca.vertcat(ca.reshape(Ur, -1, 1), ca.reshape(Xr, -1, 1)),
+                       g=ca.vertcat(*g))
+            return ca.nlpsol("solver", "ipopt", nlp, {"ipopt.max_iter": 100, "ipopt.print_level": 0, "print_time": 0,
+                                                      "ipopt.acceptable_tol": 1e-8, "ipopt.acceptable_obj_change_tol": 1e-6})
+        keep = np.r_[0:2 * N, [2 * N + 6 * k + i for k in range(N + 1) for i in range(5)]] if x0.shape[1] != 2 * N + 5 * (N + 1) else slice(None)
+        xs, ps = x0[:8, keep], p[:8, keep]
+        sol = build()
+        t0 = time.perf_counter()
+        for b in range(len(xs)):
+            sol(x0=xs[b], p=ps[b], lbg=lbg, ubg=ubg, lbx=lbx, ubx=ubx)
+        t_once = (time.perf_counter() - t0) / len(xs)
+        t0 = time.perf_counter()
+        for b in range(2):
+            build()(x0=xs[b], p=ps[b], lbg=lbg, ubg=ubg, lbx=lbx, ubx=ubx)
+        t_rebuild = (time.perf_counter() - t0) / 2
+        return dict(available=True, version=ca.__version__, steps_per_s_solver_built_once=1.0 / t_once, steps_per_s_rebuilt_per_step=1.0 / t_rebuild,
+                    threads=1, sample="%d instances of the N=%d nx=5 part of the same workload" % (len(xs), N))
+    except Exception as e:
+        return dict(available=True, error=repr(e), note="casadi imported but the timing failed; published figure: " + PUBLISHED_CASADI)
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: become `torch.distributed.run` with N ranks -- or fail; never measure fewer GPUs than asked"""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this host -- refusing to report a %d-GPU figure from fewer devices"
+                         % (args.gpus, have, args.gpus))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def pmc_child():
+    """the command the PMC passes profile: three converged-mode solves of the headline batch, nothing else"""
+    import torch
+    import mpc_amd  # noqa: F401
+    import workloads as wl
+    fam = wl.FAMILIES["zamlf_n30_nx6"]
+    x0, p = wl.batch(fam, BATCH)
+    dev = torch.device("cuda", 0)
+    d_x0, d_p = torch.from_numpy(x0).to(dev), torch.from_numpy(p).to(dev)
+    d_out = torch.empty_like(d_x0)
+    s = wl.make_solver(fam)
+    for _ in range(3):
+        s.solve_device(BATCH, d_x0.data_ptr(), d_p.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
 
 
 def main():
@@ -65,46 +215,73 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--workload", choices=("headline", "mixed"), default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic falls back to the committed figure)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                # does not return
 
     import torch
     import torch.distributed as dist
     import mpc_amd
     from mpc_amd import sharding
-    from oracle.nlp_numpy import NLPConfig, synthetic_batch
+    import workloads as wl
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-
-    B = args.batch
-    cfg = NLPConfig(N=N_HORIZON, nx=NX)                 # ZAM_Over-1_1 lane-following weights, dummy obstacle
-    x0, p = synthetic_batch(cfg, B, start=rank * B)     # per-instance rng(20240929 + global index)
-    d_x0, d_p = torch.from_numpy(x0).to(dev), torch.from_numpy(p).to(dev)
-    d_out = torch.empty_like(d_x0)
-    d_st = torch.empty(B, dtype=torch.int32, device=dev)
-    d_it = torch.empty(B, dtype=torch.int32, device=dev)
-    d_kkt = torch.empty(B, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def make(fixed):
-        return mpc_amd.BatchedMPCSolver(cfg.N, cfg.nx, Q=cfg.Qdiag, R=cfg.R, obstacle_centers=cfg.obstacle_centers,
-                                        fixed_iters=fixed, device=local_rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(step_fn, steps, warmup):
+        """contract timing: W untimed steps, then exactly K steps between two barrier + synchronize pairs, max over ranks;
+        the per-step host times (every converged-mode call ends with a stream synchronisation) give the median beside it"""
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts = time.perf_counter()
+            step_fn()
+            per.append(time.perf_counter() - ts)
+        barrier()
+        dt = time.perf_counter() - t0
+        return (sharding.max_over_ranks(dt, device=dev) if world > 1 else dt), per
+
+    if args.workload == "mixed":
+        return run_mixed(args, torch, dist, mpc_amd, sharding, wl, world, rank, local_rank, dev, stream, timed)
+
+    B = args.batch
+    fam = wl.FAMILIES["zamlf_n30_nx6"]                  # ZAM_Over-1_1 lane-following weights, dummy obstacle, N = 30, nx = 6
+    assert (fam.N, fam.nx) == (N_HORIZON, NX)
+    x0, p = wl.batch(fam, B, start=rank * B)            # per-instance rng(20240929 + global index)
+    d_x0, d_p = torch.from_numpy(x0).to(dev), torch.from_numpy(p).to(dev)
+    d_out = torch.empty_like(d_x0)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    d_it = torch.empty(B, dtype=torch.int32, device=dev)
+    d_kkt = torch.empty(B, dtype=torch.float64, device=dev)
     gathered = [torch.empty_like(d_out) for _ in range(world)] if world > 1 else None
 
     def step(solver):
@@ -113,27 +290,17 @@ def main():
         if world > 1:                                    # the only exchange of the path: final gather of the rows
             dist.all_gather(gathered, d_out)
 
-    def timed(solver, steps, warmup):
-        for _ in range(warmup):
-            step(solver)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(solver)
-        barrier()
-        dt = time.perf_counter() - t0
-        return sharding.max_over_ranks(dt, device=dev) if world > 1 else dt
-
-    solver = make(0)
-    dt = timed(solver, args.steps, args.warmup)
+    solver = wl.make_solver(fam, device=local_rank)
+    dt, per = timed(lambda: step(solver), args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    med = float(np.median(per))
     st, it, kkt = d_st.cpu().numpy(), d_it.cpu().numpy(), d_kkt.cpu().numpy()
     converged = float((st == 1).mean())
     mean_it, max_it = float(it.mean()), int(it.max())
 
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch
-    ab = algorithmic_bytes(cfg.N, cfg.nx)
+    ab = algorithmic_bytes(fam.N, fam.nx)
     solver.set_profiling(True)
     ric_ms = ric_n = stg_ms = stg_n = pipe_ms = pipe_n = 0.0
     pipe_stats = None
@@ -163,8 +330,16 @@ def main():
         kern[name] = dict(avg_us=avg_us, launches_per_step=n_per_step, bytes_per_launch=bytes_per_launch,
                           gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9, total_ms_per_step=ms / args.steps)
     dom = max(kern, key=lambda k: kern[k]["total_ms_per_step"])
+    copy_gbs = copy_bandwidth(torch, dev) if rank == 0 else None
+    traffic, traffic_src = None, "not measured (multi-GPU run or --no-traffic)"
+    if rank == 0 and world == 1 and not args.no_traffic:
+        tag = {"k_pipeline": "k_pipeline<6", "k_stage": "k_stage<6, false", "k_riccati": "k_riccati<6"}[dom]
+        traffic, traffic_src = measure_traffic(tag)
+    elif rank == 0:
+        traffic, traffic_src = committed_traffic(dom), "committed profiles/pmc_traffic.json"
     roofline = dict(bound="hbm", kernel=dom, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=pmc_traffic(dom),
+                    frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                    measured_copy_bw_gbs=copy_gbs, frac_vs_measured_copy_bw=(kern[dom]["gbs"] / copy_gbs) if copy_gbs else None,
                     avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
                     algorithmic_bytes_per_launch=kern[dom]["bytes_per_launch"],
                     other_kernel={k: v for k, v in kern.items() if k != dom},
@@ -173,19 +348,25 @@ def main():
                                     frac=value / world * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS),
                     profiled_ms_per_step=prof_ms_per_step, pipeline=pipe_stats)
 
-    # ---- deterministic-work variant (exactly 20 iterations per instance, no early exit)
-    fsolver = make(20)
-    dtf = timed(fsolver, args.steps, args.warmup)
+    # ---- deterministic-work variant (exactly 20 iterations per instance, no early exit).  NOT the headline: an
+    # instance that has reached the tolerance keeps iterating (steps accepted as they come), so only mean_iters / 20 of the
+    # instance-iterations below are iterations a solve needs; the rest is deterministic filler that shows what the pipeline moves.
+    fsolver = wl.make_solver(fam, device=local_rank, fixed_iters=20)
+    dtf, _ = timed(lambda: step(fsolver), args.steps, args.warmup)
     fixed20 = dict(value=world * B * args.steps / dtf, ms_per_step=dtf / args.steps * 1e3,
-                   hbm_frac=B * args.steps / dtf * (ab["b_io"] + 20 * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS)
+                   hbm_frac_all_iterations=B * args.steps / dtf * (ab["b_io"] + 20 * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS,
+                   useful_iteration_share=mean_it / 20.0,
+                   hbm_frac_useful_iterations=B * args.steps / dtf * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS,
+                   note="20 iterations per instance regardless of convergence; %.1f of them are needed on average -- not headline credit" % mean_it)
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, single-GPU run only)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.binding import OracleSolver
-        osol = OracleSolver(cfg)
+        from oracle.nlp_numpy import NLPConfig
+        osol = OracleSolver(NLPConfig(N=fam.N, nx=fam.nx, Q=fam.Q, R=fam.R))
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        xs, ps = synthetic_batch(cfg, 4096)
+        xs, ps = x0[:4096], p[:4096]
         best = None
         for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances; keep the best count
             osol.solve_batch(xs[:256], ps[:256], nthreads=cores)          # warm the thread pool
@@ -210,51 +391,15 @@ def main():
         except Exception:
             pass
         cpu_baseline = dict(value=reps * len(xs) / t_all, unit="MPC steps/s", cores=cores, kind="port",
-                            sample=f"{reps} x 4096 instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
+                            sample=f"{reps} x {len(xs)} instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
                                    f"OpenMP over instances, all converged={bool((ro['status'] == 1).all())}",
                             single_thread_value=1024 / t_one, cpu_model=model, host_cpus=avail,
-                            published_casadi_ipopt="25.1 steps/s (N=10, 1 instance, unknown CPU; BASELINE.md section 1)")
+                            casadi_ipopt=casadi_probe(fam, x0, p, wl), published_casadi_ipopt=PUBLISHED_CASADI)
 
     # ---- the paths around the solve, single-GPU run only, a few hundred milliseconds in total
     other_paths = None
     if rank == 0 and world == 1:
-        other_paths = {}
-        try:
-            s5 = mpc_amd.BatchedMPCSolver(N_HORIZON, 5, Q=cfg.Qdiag[:5], R=cfg.R, obstacle_centers=cfg.obstacle_centers, device=local_rank)
-            s5.set_bounds()                                                      # the reference's default limits
-            L, Bc = 60, B
-            k = np.arange(L)
-            path = np.stack([k * 1.5 * np.cos(0.1), k * 1.5 * np.sin(0.1)], axis=1)
-            rng = np.random.default_rng(0)
-            init = np.tile([0.0, 0.0, 0.0, 15.0, 0.1], (Bc, 1))
-            init[:, 1] += rng.uniform(-0.5, 0.5, Bc)
-            init[:, 3] *= rng.uniform(0.9, 1.1, Bc)
-            P_, O_ = np.tile(path, (Bc, 1, 1)), np.full((Bc, L), 0.1)
-            s5.closed_loop(init[:64], P_[:64], O_[:64], np.full(64, 15.0), L)
-            t0 = time.perf_counter()
-            _, _, st_ = s5.closed_loop(init, P_, O_, np.full(Bc, 15.0), L)
-            tcl = time.perf_counter() - t0
-            other_paths["closed_loop"] = dict(ego_steps_per_s=Bc * L / tcl, ms_per_step_of_batch=tcl / L * 1e3, batch=Bc, steps=L, horizon=N_HORIZON,
-                                              converged_frac=float((st_ == 1).mean()),
-                                              note="mpc_closed_loop_batch, nx=5, host buffers in/out once per call (row f1)")
-            sf = mpc_amd.BatchedMPCSolver(10, 5, Q=(2.0, 2.0, 50.0, 0.1, 5.0), R=(2.0, 0.2), P=(4.0, 4.0, 100.0, 0.2, 10.0), device=local_rank)
-            zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 19.0, 0.03495])
-            zb = np.tile(zi, (B, 10, 1))
-            kk = np.arange(1, 11)
-            par = np.tile(np.hstack([np.stack([zi[2] + kk * 2 * np.cos(0.03495), zi[3] + kk * 2 * np.sin(0.03495)], 1), np.full((10, 1), 20.0),
-                                     np.full((10, 1), 0.03495), np.tile([-100.0, 0, -100, 0, -100, 0], (10, 1))]), (B, 1, 1))
-            lbf = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])
-            ubf = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
-            hlf, huf = np.concatenate(([0.0], np.full(9, 1.44))), np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
-            sf.forces_solve(zb[:64], zb[:64, 0, 2:], par[:64], lbf, ubf, hlf, huf)
-            t0 = time.perf_counter()
-            _, fl_, it_, _ = sf.forces_solve(zb, zb[:, 0, 2:], par, lbf, ubf, hlf, huf)
-            tf = time.perf_counter() - t0
-            other_paths["forces_sqp_step"] = dict(solves_per_s=B / tf, ms_per_batch=tf * 1e3, batch=B, horizon=10, solved_frac=float((fl_ == 1).mean()),
-                                                  mean_qp_iterations=float(it_.mean()),
-                                                  note="mpc_forces_solve_batch, host buffers incl. PCIe and per-call allocation (row f3)")
-        except Exception as e:      # never let the side measurements take the bench line down
-            other_paths["error"] = repr(e)
+        other_paths = side_paths(torch, mpc_amd, fam, B, local_rank)
 
     if rank == 0:
         out = dict(metric="MPC steps/sec (N=30, nx=6 nu=2) at batch=4096", value=value, unit="MPC steps/s", n_gpus=world,
@@ -262,10 +407,120 @@ def main():
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload="N=30 nx=6 nu=2 kinematic-bicycle lane-following (ZAM_Over-1_1 LF weights, dummy "
                                         "obstacle), batch=%d per GPU, solved to tol 1e-8 (max_iter 100)" % B,
-                               batch_per_gpu=B, horizon=cfg.N, nx=cfg.nx, nu=2, parallelism="independent instances x%d" % world,
+                               batch_per_gpu=B, horizon=fam.N, nx=fam.nx, nu=2, parallelism="independent instances x%d" % world,
                                mode="converged", gpu=torch.cuda.get_device_name(dev)),
+                   ms_per_step_median=med * 1e3, value_median_batch=world * B / med if world == 1 else None,
                    converged_frac=converged, mean_iters=mean_it, max_iters=max_it, kkt_max=float(kkt.max()),
                    fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, other_paths=other_paths)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def side_paths(torch, mpc_amd, fam, B, local_rank):
+    other_paths = {}
+    try:
+        s5 = mpc_amd.BatchedMPCSolver(N_HORIZON, 5, Q=fam.Q, R=fam.R, device=local_rank)
+        s5.set_bounds()                                                      # the reference's default limits
+        L, Bc = 60, B
+        k = np.arange(L)
+        path = np.stack([k * 1.5 * np.cos(0.1), k * 1.5 * np.sin(0.1)], axis=1)
+        rng = np.random.default_rng(0)
+        init = np.tile([0.0, 0.0, 0.0, 15.0, 0.1], (Bc, 1))
+        init[:, 1] += rng.uniform(-0.5, 0.5, Bc)
+        init[:, 3] *= rng.uniform(0.9, 1.1, Bc)
+        P_, O_ = np.tile(path, (Bc, 1, 1)), np.full((Bc, L), 0.1)
+        s5.closed_loop(init[:64], P_[:64], O_[:64], np.full(64, 15.0), L)
+        t0 = time.perf_counter()
+        _, _, st_ = s5.closed_loop(init, P_, O_, np.full(Bc, 15.0), L)
+        tcl = time.perf_counter() - t0
+        other_paths["closed_loop"] = dict(ego_steps_per_s=Bc * L / tcl, ms_per_step_of_batch=tcl / L * 1e3, batch=Bc, steps=L, horizon=N_HORIZON,
+                                          converged_frac=float((st_ == 1).mean()),
+                                          note="mpc_closed_loop_batch, nx=5, host buffers in/out once per call (row f1)")
+        sf = mpc_amd.BatchedMPCSolver(10, 5, Q=(2.0, 2.0, 50.0, 0.1, 5.0), R=(2.0, 0.2), P=(4.0, 4.0, 100.0, 0.2, 10.0), device=local_rank)
+        zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 19.0, 0.03495])
+        zb = np.tile(zi, (B, 10, 1))
+        kk = np.arange(1, 11)
+        par = np.tile(np.hstack([np.stack([zi[2] + kk * 2 * np.cos(0.03495), zi[3] + kk * 2 * np.sin(0.03495)], 1), np.full((10, 1), 20.0),
+                                 np.full((10, 1), 0.03495), np.tile([-100.0, 0, -100, 0, -100, 0], (10, 1))]), (B, 1, 1))
+        lbf = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])
+        ubf = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
+        hlf, huf = np.concatenate(([0.0], np.full(9, 1.44))), np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
+        dev = torch.device("cuda", local_rank)
+        d_z, d_xi, d_par = torch.from_numpy(zb).to(dev), torch.from_numpy(np.ascontiguousarray(zb[:, 0, 2:])).to(dev), torch.from_numpy(par).to(dev)
+        d_o = torch.empty_like(d_z)
+        d_fl = torch.empty(B, dtype=torch.int32, device=dev)
+        d_it = torch.empty(B, dtype=torch.int32, device=dev)
+        d_rs = torch.empty(B, dtype=torch.float64, device=dev)
+
+        def fstep():
+            sf.forces_solve_device(B, d_z.data_ptr(), d_xi.data_ptr(), d_par.data_ptr(), lbf, ubf, hlf, huf, d_o.data_ptr(), d_fl.data_ptr(),
+                                   d_it.data_ptr(), d_rs.data_ptr())
+        fstep()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fstep()
+        e1.record()
+        e1.synchronize()
+        tf = e0.elapsed_time(e1) * 1e-3 / 5
+        fl_, it_ = d_fl.cpu().numpy(), d_it.cpu().numpy()
+        # bytes a QP iteration has to move per instance: stage blocks (Hessian 7x7 sym, [A B] 5x7, gradient 7, defect 5, 10 rows of
+        # inequality Jacobian 10x7 + residuals) written and read once, iterate + multipliers + slacks read and written
+        nq = 10 * (28 + 35 + 7 + 5 + 70 + 10)
+        ni = 10 * (7 + 5 + 2 * (14 + 10) * 2)
+        b_it = 8 * 2 * (nq + ni)
+        other_paths["forces_sqp_step"] = dict(solves_per_s=B / tf, ms_per_batch=tf * 1e3, batch=B, horizon=10, solved_frac=float((fl_ == 1).mean()),
+                                              mean_qp_iterations=float(it_.mean()),
+                                              roofline=dict(bound="hbm", achieved=B * float(it_.mean()) * b_it / tf / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                                            frac=B * float(it_.mean()) * b_it / tf / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                                            algorithmic_bytes_per_instance_iteration=b_it),
+                                              note="mpc_forces_solve_batch_dev, device-resident buffers, HIP events (row f3)")
+    except Exception as e:      # never let the side measurements take the bench line down
+        other_paths["error"] = repr(e)
+    return other_paths
+
+
+def run_mixed(args, torch, dist, mpc_amd, sharding, wl, world, rank, local_rank, dev, stream, timed):
+    """BASELINE configuration 5: mixed scenario sweep, 4096 rows per GPU (32 768 over 8), one handle per family on every rank,
+    the three solves back to back, ONE all-gather of the padded result rows at the end of the step"""
+    per_gpu = wl.MIXED_SHARD
+    shard = wl.mixed_shard(rank, world, total=per_gpu * world)
+    W = wl.MIXED_ROW_WIDTH
+    d_res = torch.zeros(per_gpu, W, dtype=torch.float64, device=dev)          # result rows in global order, padded to one width
+    gathered = [torch.empty_like(d_res) for _ in range(world)] if world > 1 else None
+    parts = []
+    for name in wl.MIXED_ORDER:
+        rows, x0, p = shard[name]
+        fam = wl.FAMILIES[name]
+        nB = len(rows)
+        parts.append(dict(fam=fam, B=nB, solver=wl.make_solver(fam, device=local_rank), x0=torch.from_numpy(x0).to(dev), p=torch.from_numpy(p).to(dev),
+                          out=torch.empty(nB, fam.n_w, dtype=torch.float64, device=dev), st=torch.empty(nB, dtype=torch.int32, device=dev),
+                          it=torch.empty(nB, dtype=torch.int32, device=dev), local=torch.from_numpy(rows - rank * per_gpu).to(dev)))
+
+    def step():
+        for q in parts:
+            q["solver"].solve_device(q["B"], q["x0"].data_ptr(), q["p"].data_ptr(), q["out"].data_ptr(), q["st"].data_ptr(), q["it"].data_ptr(), 0,
+                                     stream=stream)
+            d_res[q["local"], : q["fam"].n_w] = q["out"]
+        if world > 1:
+            dist.all_gather(gathered, d_res)
+
+    dt, per = timed(step, args.steps, args.warmup)
+    value = world * per_gpu * args.steps / dt
+    fams = {}
+    for q in parts:
+        st, it = q["st"].cpu().numpy(), q["it"].cpu().numpy()
+        fams[q["fam"].name] = dict(rows_per_gpu=q["B"], converged_frac=float((st == 1).mean()), mean_iters=float(it.mean()), max_iters=int(it.max()))
+    if rank == 0:
+        out = dict(metric="MPC steps/sec, mixed scenario sweep (BASELINE configuration 5)", value=value, unit="MPC steps/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, ms_per_step_median=float(np.median(per)) * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload="mixed scenario sweep: %d rows per GPU dealt row by row over %s (tools/workloads.py), one handle per family, "
+                                        "solved to tol 1e-8" % (per_gpu, ", ".join(wl.MIXED_ORDER)), rows_total=per_gpu * world,
+                               parallelism="contiguous shards x%d, one padded all-gather per step" % world, gpu=torch.cuda.get_device_name(dev)),
+                   families=fams)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

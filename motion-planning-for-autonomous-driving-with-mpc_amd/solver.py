@@ -242,6 +242,17 @@ class BatchedMPCSolver:
                                                      _abi.as_ip(flag), _abi.as_ip(it), _abi.as_dp(res)))
         return out, flag, it, res
 
+    def forces_solve_device(self, B, d_x0, d_xinit, d_par, lb, ub, hl, hu, d_x_out, d_flag=0, d_it=0, d_res=0, hessian_mode=0, stream=0):
+        """mpc_forces_solve_batch_dev: device pointers (ints) for x0 [B,N,7], xinit [B,5], all_parameters [B,N,10] and the outputs;
+        lb / ub / hl / hu are small host arrays.  Enqueues on `stream`; nothing is synchronised."""
+        def big(a, n):
+            a = np.asarray(a, dtype=np.float64).reshape(n)
+            return _abi.f64(np.where(np.isfinite(a), a, np.sign(a) * 1e308))
+        vp = C.c_void_p
+        self._check(self._lib.mpc_forces_solve_batch_dev(self._h, int(B), vp(d_x0), vp(d_xinit), vp(d_par), _abi.as_dp(big(lb, 7)), _abi.as_dp(big(ub, 7)),
+                                                         _abi.as_dp(big(hl, 10)), _abi.as_dp(big(hu, 10)), int(hessian_mode), vp(d_x_out), vp(d_flag or None),
+                                                         vp(d_it or None), vp(d_res or None), vp(stream or None)))
+
     def set_option(self, name, value=None):
         """run-time switch of the handle (include/mpcgpu.h: mpc_set_option); value None restores the default.  The
         environment (MPCGPU_<NAME>) is only read when the handle is created."""

@@ -388,3 +388,30 @@ def test_bad_inputs_are_contained_and_reported():
     assert L.mpc_solve_batch(h, 0, abi.as_dp(x0), abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
     assert L.mpc_solve_batch(h, 4, None, abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
     assert b"required" in L.mpc_last_error(h)
+
+
+def test_mixed_sweep_shard_matches_oracle():
+    """BASELINE configuration 5, one shard on one GPU: 4096 rows dealt over the three problem families (tools/workloads.py), one
+    handle per family; a sample of every family is checked against the oracle, every converged row against its own constraints"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import workloads as wl
+    shard = wl.mixed_shard(0, 8)
+    assert sum(len(v[0]) for v in shard.values()) == wl.MIXED_SHARD
+    for name, (rows, x0, p) in shard.items():
+        fam = wl.FAMILIES[name]
+        cfg = NLPConfig(N=fam.N, nx=fam.nx, dt=fam.dt, Q=fam.Q, R=fam.R, obstacle=fam.obstacle)
+        s = wl.make_solver(fam)
+        r = s.solve(x0, p)
+        ok = r.status == 1
+        assert ok.mean() >= (0.98 if fam.kind == "ca" else 1.0), (name, ok.mean())
+        sel = np.arange(0, len(rows), max(1, len(rows) // 48))[:48]
+        ro = OracleSolver(cfg).solve_batch(x0[sel], p[sel], nthreads=8)
+        both = ok[sel] & (ro["status"] == 1)
+        assert both.mean() >= 0.95
+        assert np.abs(r.x[sel][both] - ro["x"][both]).max() < (1e-6 if fam.kind == "ca" else TOL_ORACLE), name
+        nlp = BicycleNLP(cfg)
+        lbg, ubg, lbx, ubx = nlp.bounds()
+        for b in np.nonzero(ok)[0][:: max(1, int(ok.sum()) // 64)]:
+            g = nlp.g(r.x[b], p[b])
+            assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6) and np.all(r.x[b] >= lbx - 1e-7) and np.all(r.x[b] <= ubx + 1e-7)

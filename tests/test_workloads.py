@@ -1,0 +1,112 @@
+"""CPU: the product-side workload generators (tools/workloads.py -- what bench.py times) produce exactly the rows the oracle-side
+generators of the tests produce; the mixed scenario sweep (BASELINE configuration 5) partitions its rows by shard and family
+without loss; bench.py refuses to report fewer GPUs than it was asked for; the mixed shard -> family mapping under a 2-rank gloo
+group with the per-rank solves done by the kernel emulation harness."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import CA_CFG, FAMILIES, ROOT, ca_batch, emu_solve
+from oracle.nlp_numpy import BicycleNLP, NLPConfig, synthetic_batch
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import workloads as wl  # noqa: E402
+
+
+def _cfg_of(fam):
+    return NLPConfig(N=fam.N, nx=fam.nx, dt=fam.dt, Q=fam.Q, R=fam.R, obstacle=fam.obstacle)
+
+
+def test_generators_agree_with_the_oracle_side():
+    for name, kw in (("zamlf_n30_nx6", {}), ("usalf_n50_nx5", dict(v_range=(5.0, 9.0)))):
+        fam = wl.FAMILIES[name]
+        x0, p = wl.batch(fam, 9, start=5)
+        xo, po = synthetic_batch(FAMILIES[name][0], 9, start=5, **kw)
+        assert np.array_equal(x0, xo) and np.array_equal(p, po)
+    fam = wl.FAMILIES["zamca_n30_nx5"]
+    x0, p = wl.batch(fam, 7, start=3)
+    xo, po = ca_batch(CA_CFG, 7, start=3)
+    assert np.array_equal(x0, xo) and np.array_equal(p, po)
+
+
+@pytest.mark.parametrize("name", list(wl.FAMILIES))
+def test_bounds_agree_with_the_oracle_side(name):
+    fam = wl.FAMILIES[name]
+    lbx, ubx, lbg, ubg = wl.bounds(fam)
+    olbg, oubg, olbx, oubx = BicycleNLP(_cfg_of(fam)).bounds()
+    for a, b in ((lbx, olbx), (ubx, oubx), (lbg, olbg), (ubg, oubg)):
+        assert np.array_equal(a, b)
+    assert fam.n_w == _cfg_of(fam).n_w and fam.n_g == _cfg_of(fam).n_g
+
+
+def test_mixed_sweep_partition():
+    """32 768 rows, 8 shards of 4096, three families dealt row by row: every row exactly once, shards contiguous"""
+    seen = np.zeros(wl.MIXED_TOTAL, dtype=int)
+    for r in range(8):
+        rows = wl.mixed_shard_rows(r, 8)
+        allr = np.sort(np.concatenate(list(rows.values())))
+        assert allr[0] == r * wl.MIXED_SHARD and allr[-1] == (r + 1) * wl.MIXED_SHARD - 1 and len(allr) == wl.MIXED_SHARD
+        for i, name in enumerate(wl.MIXED_ORDER):
+            assert np.all(rows[name] % 3 == i)
+            assert 1365 <= len(rows[name]) <= 1366
+        seen[allr] += 1
+    assert np.all(seen == 1)
+    assert wl.MIXED_ROW_WIDTH == 355
+
+
+def test_bench_refuses_to_shrink_the_job():
+    """no GPU here: `--gpus 2` without a launcher must fail loudly, never print an n_gpus = 1 line; a launcher whose world size
+    disagrees with --gpus must fail too"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "must agree" in (r.stderr + r.stdout)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+TOTAL = 24          # a small "sweep": 2 shards of 12 rows, 4 rows per family and shard
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = TOTAL // world
+    res = torch.zeros(per, wl.MIXED_ROW_WIDTH, dtype=torch.float64)
+    for name, (rows, x0, p) in wl.mixed_shard(rank, world, total=TOTAL).items():
+        fam = wl.FAMILIES[name]
+        r = emu_solve(_cfg_of(fam), x0, p)                          # one "handle" per family on every rank
+        assert np.all(r["status"] == 1)
+        res[torch.from_numpy(rows - rank * per), : fam.n_w] = torch.from_numpy(r["x"])
+    outs = [torch.empty_like(res) for _ in range(world)]
+    dist.all_gather(outs, res)                                       # the one collective of the path
+    if rank == 0:
+        np.save(os.path.join(outdir, "mixed.npy"), torch.cat(outs).numpy())
+    dist.destroy_process_group()
+
+
+def test_mixed_sweep_two_ranks_gloo(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "mixed.npy")
+    assert got.shape == (TOTAL, wl.MIXED_ROW_WIDTH)
+    for g in range(TOTAL):
+        fam = wl.FAMILIES[wl.MIXED_ORDER[g % 3]]
+        x0, p = wl.instance(fam, g)
+        ref = emu_solve(_cfg_of(fam), x0[None], p[None])["x"][0]
+        assert np.abs(got[g, : fam.n_w] - ref).max() < 1e-12 and np.all(got[g, fam.n_w:] == 0.0)

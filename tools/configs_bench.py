@@ -47,3 +47,7 @@ if __name__ == "__main__":
     run("config 4: USA_Lanker weights, N=50 long horizon", cfg, *synthetic_batch(cfg, 4096, **kw))
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     run("metric config: N=30 nx=6, batch 4096", cfg, *synthetic_batch(cfg, 4096, **kw))
+    # config 5, one shard of the mixed scenario sweep on one GPU (bench.py --workload mixed is the N-GPU form)
+    import subprocess
+    print("config 5 (one 4096-row shard of the mixed sweep, three handles back to back):", flush=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mixed", "--steps", "10", "--warmup", "2"], check=False)
