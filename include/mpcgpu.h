@@ -105,6 +105,15 @@ int mpc_set_bounds(mpc_handle* h, const double* lbx, const double* ubx, const do
 int mpc_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* p, const double* obst,
                     double* x_out, int32_t* status, int32_t* iters, double* kkt);
 
+/* Second chance (both entry points, on unless the option "rescue" is "0"; not in fixed_iters mode): instances whose line search
+ * or regularisation gave up (status -7, where IPOPT would enter its feasibility-restoration phase) or that ran out of
+ * iterations are re-solved on the device with the lower bound of the circle-distance rows raised in steps from 0 to its value,
+ * each level warm-started from the last; the final level is the original problem, so a row that comes back with status 1 is a
+ * KKT point of the ORIGINAL NLP to the original tolerance (possibly another local optimum than IPOPT's); rows that still fail keep
+ * their first result and status.  iters[] includes the iterations of the second chance.  mpc_last_rescued: how many instances
+ * of the last solve took it.                                                                                              */
+int mpc_last_rescued(const mpc_handle* h);
+
 /* Device-buffer entry point: same arguments as device pointers, work enqueued on `stream` (a hipStream_t,
  * NULL = default stream).  Returns after enqueueing + the convergence polls; the outputs are complete when
  * the stream is synchronised (the call itself synchronises the stream unless fixed_iters > 0).            */

@@ -45,7 +45,7 @@ EXPORTS = [
     "mpc_default_desc", "mpc_create", "mpc_destroy", "mpc_last_error", "mpc_set_bounds", "mpc_solve_batch",
     "mpc_solve_batch_dev", "mpc_plant_step", "mpc_set_profiling", "mpc_get_profile", "mpc_solve_batch_trace",
     "mpc_abi_version", "mpc_closed_loop_batch", "mpc_closed_loop_batch_dev", "mpc_metrics_batch", "mpc_forces_stage_eval", "mpc_forces_solve_batch",
-    "mpc_get_pipeline_profile", "mpc_plant_step_dev", "mpc_metrics_batch_dev", "mpc_forces_solve_batch_dev", "mpc_set_option",
+    "mpc_get_pipeline_profile", "mpc_plant_step_dev", "mpc_metrics_batch_dev", "mpc_forces_solve_batch_dev", "mpc_set_option", "mpc_last_rescued",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library(path: str | None = None):
     L.mpc_forces_solve_batch_dev.restype = C.c_int
     L.mpc_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.mpc_set_option.restype = C.c_int
+    L.mpc_last_rescued.argtypes = [vp]
+    L.mpc_last_rescued.restype = C.c_int
     L.mpc_abi_version.argtypes = []
     L.mpc_abi_version.restype = C.c_int
     if path == LIB_PATH:

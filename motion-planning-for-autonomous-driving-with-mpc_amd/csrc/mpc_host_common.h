@@ -21,6 +21,7 @@ struct HostProblem {
     std::vector<double> LB, UB;         // [(N+1)*NZ] relaxed, +-inf = absent
     int has_fl = 0, has_fu = 0, has_ol = 0, has_ou = 0;
     double fl = 0, fu = 0, ol = 0, ou = 0;
+    double ol_raw = 0;                  // lower bound of the obstacle rows as the caller gave it (before relaxation)
     int n_mult = 0, n_z = 0;
     bool bounds_set = false;
     int NZ() const { return desc.nx + 2; }
@@ -101,6 +102,7 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
     hp.fl = relax_lo(flo); hp.fu = relax_hi(fhi);
     hp.has_ol = std::isfinite(olo); hp.has_ou = std::isfinite(ohi);
     hp.ol = relax_lo(olo); hp.ou = relax_hi(ohi);
+    hp.ol_raw = olo;
     const int m = d.obst_mult;
     // per-instance parts (friction row or its presolved bound on a_0) are added in phase_finish()
     hp.n_mult = nx * (N + 1) + 3 * m * (N + 1);

@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
 }
 
 template <int NX>
-__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if) {
+__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if, uint32_t* fail_count) {
     __shared__ double tile[64][65];
     if (skip_if != nullptr && *skip_if != 0u) return;        // abandoned pipeline launch: the host starts over, the caller's buffers stay untouched
     const int N = P.N, nw = 2 * N + NX * (N + 1);
@@ -751,13 +751,17 @@ __global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* s
     if (blockIdx.y != 0) return;
     if (threadIdx.x < 64) {
         const uint32_t b = t0 + (uint32_t)lane;
+        int st = 1;
         if (b < (uint32_t)P.B) {
-            int st = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_STATUS) + 2u * lane];
+            st = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_STATUS) + 2u * lane];
             if (st == ST_RUNNING) st = 0;          // iteration budget of the launch loop exhausted
             if (P.status_out) P.status_out[b] = st;
             if (P.iters_out) P.iters_out[b] = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_ITERS) + 2u * lane];
             if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)tl * P.tile_elems + mpc_prow((uint32_t)SC_E0) + 2u * lane];
         }
+        // how many instances of the batch did not converge (the host decides from this whether a second chance is due)
+        const int nbad = __popcll(__ballot(st != 1 ? 1 : 0));
+        if (fail_count != nullptr && lane == 0 && nbad) atomicAdd(fail_count, (uint32_t)nbad);
     }
 }
 
@@ -1044,6 +1048,56 @@ __global__ void __launch_bounds__(128) k_loop_advance(const Params P, const Loop
     }
 }
 
+// ---- second chance for stalled instances (see rescue_dev on the host side) ---------------------------------------------
+// ordered list of the instances whose status is not "converged": one workgroup, ballot-based compaction
+__global__ void __launch_bounds__(1024) k_rescue_select(const int32_t* status, int B, int32_t* idx, int32_t* count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + t;
+        const int bad = (b < B && status[b] != 1) ? 1 : 0;
+        const unsigned long long m = __ballot(bad);
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        if (bad) idx[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+        __syncthreads();
+        if (t == 0) { int s = 0; for (int q = 0; q < 16; ++q) s += wsum[q]; base += s; }
+        __syncthreads();
+    }
+    if (t == 0) *count = base;
+}
+// rows of the selected instances -> compact sub-batch (first call), converged rows of a level -> warm start of the next
+__global__ void k_rescue_gather(const int32_t* idx, int nw, const double* x0, const double* p, const double* obst, double* xs, double* ps, double* os,
+                                int32_t* it_acc) {
+    const int j = blockIdx.x, b = idx[j];
+    for (int q = threadIdx.x; q < nw; q += blockDim.x) { xs[(size_t)j * nw + q] = x0[(size_t)b * nw + q]; ps[(size_t)j * nw + q] = p[(size_t)b * nw + q]; }
+    if (obst != nullptr && threadIdx.x < 6) os[(size_t)j * 6 + threadIdx.x] = obst[(size_t)b * 6 + threadIdx.x];
+    if (threadIdx.x == 0) it_acc[j] = 0;
+}
+__global__ void k_rescue_carry(int nw, const int32_t* st, const int32_t* it, const double* out, double* xs, int32_t* it_acc) {
+    const int j = blockIdx.x;
+    if (threadIdx.x == 0) it_acc[j] += it[j];
+    if (st[j] != 1) return;
+    for (int q = threadIdx.x; q < nw; q += blockDim.x) xs[(size_t)j * nw + q] = out[(size_t)j * nw + q];
+}
+// result of the last level (the ORIGINAL problem) back into the caller's rows -- only where it converged
+__global__ void k_rescue_scatter(const int32_t* idx, int nw, const int32_t* st, const double* out, const double* kkt, const int32_t* it_acc, double* x_out,
+                                 int32_t* status, int32_t* iters, double* kkt_out) {
+    const int j = blockIdx.x, b = idx[j];
+    if (st[j] != 1) return;
+    for (int q = threadIdx.x; q < nw; q += blockDim.x) x_out[(size_t)b * nw + q] = out[(size_t)j * nw + q];
+    if (threadIdx.x == 0) {
+        status[b] = 1;
+        if (iters) iters[b] += it_acc[j];
+        if (kkt_out) kkt_out[b] = kkt[j];
+    }
+}
+
 template <int NX>
 __global__ void k_plant_step(const Params P, const double* x, const double* u, double* xn, int B, int integrator) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1117,6 +1171,9 @@ struct mpc_handle {
     int n_cu = 256;
     uint32_t xcd_mask = 0xFFu;          // XCDs seen by k_xcd_census
     std::vector<hipEvent_t> ev_pool;
+    uint32_t* d_fail = nullptr;         // instances of the last solve that did not converge (counted by k_egest)
+    uint32_t* h_fail = nullptr;         // pinned copy
+    int rescued_last = 0;               // instances the last solve handed to the second chance (rescue_dev)
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
     // mpc_set_option -- no getenv on the solve path
@@ -1231,7 +1288,8 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     knobs_from_env(h->knobs);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT) != hipSuccess ||
-        hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess) {
+        hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess ||
+        hipMalloc(&h->d_fail, sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&h->h_fail, sizeof(uint32_t)) != hipSuccess) {
         g_create_error = "HIP stream/counter allocation failed";
         delete h;
         return MPC_ERR_HIP;
@@ -1277,6 +1335,8 @@ int mpc_destroy(mpc_handle* h) {
     if (h->d_state) (void)hipFree(h->d_state);
     for (void* sp : h->scratch) if (sp) (void)hipFree(sp);
     if (h->h_counter) (void)hipHostFree(h->h_counter);
+    if (h->d_fail) (void)hipFree(h->d_fail);
+    if (h->h_fail) (void)hipHostFree(h->h_fail);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int g = 0; g < mpc_handle::MAX_GROUPS; ++g)
@@ -1314,6 +1374,8 @@ int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
     if (rc) h->err = std::string("unknown option: ") + name;
     return rc;
 }
+
+int mpc_last_rescued(const mpc_handle* h) { return h ? h->rescued_last : MPC_ERR_INVALID; }
 
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]) {
     if (!h || !out) return MPC_ERR_INVALID;
@@ -1395,6 +1457,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
     const WsLayout w = ws_layout(d.N, d.nx, Bp);
     Prof prof{h, stream};
+    HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
     if (d_obst) {
         P.per_inst_obst = 1;
         hipLaunchKernelGGL(k_transpose_obst, dim3((B + 255) / 256), dim3(256), 0, stream, d_obst, h->d_ws + w.OBST * 64, B, (uint32_t)w.tile_elems);
@@ -1570,9 +1633,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
             // synchronisation of the call is the last thing that happens
             prof.begin(2, stream);
-            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT));
+            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_fail);
             prof.end(stream);
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, hipStreamSynchronize(stream));
             if (h->h_pipe[0] != 0u) {
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
@@ -1710,7 +1774,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Params Pg = P;
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg, (const uint32_t*)nullptr, h->d_fail);
         prof.end(q.st);
         if (G > 1) {
             HIP_TRY(h, hipEventRecord(h->ev_join[g], q.st));
@@ -1719,11 +1783,65 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     HIP_TRY(h, hipGetLastError());
     h->prof[5] = it;
+    if (!piped) HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (d.fixed_iters <= 0 || h->profiling) HIP_TRY(h, hipStreamSynchronize(stream));
     const double its = it;
     prof.collect();
     h->prof[5] = its;
     return MPC_OK;
+}
+
+static int solve_dev_any(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
+                         int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream, double* trace, int32_t trace_rows, int32_t* n_it) {
+    if (h->hp.desc.nx == 5)
+        return solve_dev_impl<5>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+    return solve_dev_impl<6>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+}
+
+// Second chance for the instances of a batch that did not converge, on the device and behind the C-ABI.  IPOPT hands a start
+// that is locally infeasible -- typically a guess that runs straight through the obstacle, where the linearised circle rows
+// cannot be met within the fraction-to-the-boundary rule -- to its feasibility-restoration phase, which is not restated here
+// (DESIGN.md section 2).  Instead: the failed instances are compacted into a sub-batch and re-solved with the lower bound of the
+// circle-distance rows (optimizer.py:426-428) raised in steps from 0 to its true value, each level warm-started from the last
+// one that converged; the last level is the ORIGINAL problem, so what is written back is a KKT point of the original NLP to the
+// original tolerance -- or nothing (the original failure stays).  Two passes: levels {0, 1}, then {0, 0.4, 0.7, 0.9, 1} for
+// what is still open.  Everything stays in device memory; the only host traffic is the count of open instances.
+static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
+                      int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream) {
+    const size_t nw = h->hp.n_w(), nB = (size_t)B;
+    int32_t* idx = static_cast<int32_t*>(scratch_get(h, 14, (nB + 1) * 4));
+    if (!idx) { h->err = "rescue: out of device memory"; return MPC_ERR_HIP; }
+    int32_t* cnt = idx + nB;
+    static const double pass1[] = {0.0, 1.0}, pass2[] = {0.0, 0.4, 0.7, 0.9, 1.0};
+    const double ol_keep = h->hp.ol;
+    h->rescued_last = 0;
+    int rc = MPC_OK;
+    for (int pass = 0; pass < 2 && rc == MPC_OK; ++pass) {
+        hipLaunchKernelGGL(k_rescue_select, dim3(1), dim3(1024), 0, stream, d_status, B, idx, cnt);
+        int32_t n = 0;
+        HIP_TRY(h, hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        if (n <= 0) break;
+        // sub-batch buffers: [xs | ps | out] rows, obstacle rows, status / iterations / kkt of a level, accumulated iterations
+        double* buf = static_cast<double*>(scratch_get(h, 15, ((size_t)n * (3 * nw + 6 + 1)) * 8 + (size_t)n * 3 * 4 + 64));
+        if (!buf) { h->err = "rescue: out of device memory"; return MPC_ERR_HIP; }
+        double *xs = buf, *ps = xs + (size_t)n * nw, *out = ps + (size_t)n * nw, *os = out + (size_t)n * nw, *kk = os + (size_t)n * 6;
+        int32_t *st = reinterpret_cast<int32_t*>(kk + n), *it = st + n, *acc = it + n;
+        hipLaunchKernelGGL(k_rescue_gather, dim3(n), dim3(128), 0, stream, idx, (int)nw, d_x0, d_p, d_obst, xs, ps, os, acc);
+        const double* fr = pass == 0 ? pass1 : pass2;
+        const int nfr = pass == 0 ? 2 : 5;
+        for (int q = 0; q < nfr && rc == MPC_OK; ++q) {
+            h->hp.ol = relax_lo(fr[q] * h->hp.ol_raw);
+            rc = solve_dev_any(h, n, xs, ps, d_obst ? os : nullptr, out, st, it, kk, stream, nullptr, 0, nullptr);
+            if (rc == MPC_OK) hipLaunchKernelGGL(k_rescue_carry, dim3(n), dim3(128), 0, stream, (int)nw, st, it, out, xs, acc);
+        }
+        h->hp.ol = ol_keep;
+        if (rc == MPC_OK) hipLaunchKernelGGL(k_rescue_scatter, dim3(n), dim3(128), 0, stream, idx, (int)nw, st, out, kk, acc, d_x_out, d_status, d_iters, d_kkt);
+        if (pass == 0) h->rescued_last = n;
+    }
+    h->hp.ol = ol_keep;
+    if (rc == MPC_OK) { HIP_TRY(h, hipGetLastError()); HIP_TRY(h, hipStreamSynchronize(stream)); }
+    return rc;
 }
 
 static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
@@ -1733,9 +1851,24 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
     if (B <= 0 || !d_x0 || !d_p || !d_x_out) { h->err = "B > 0 and x0, p, x_out are required"; return MPC_ERR_INVALID; }
     if (!h->hp.bounds_set) { h->err = "mpc_set_bounds has not been called"; return MPC_ERR_STATE; }
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->hp.desc.nx == 5)
-        return solve_dev_impl<5>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
-    return solve_dev_impl<6>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+    h->rescued_last = 0;
+    // the second chance needs the per-instance status: an internal row when the caller did not ask for it
+    const bool rescue = h->knobs.rescue && h->hp.desc.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0;
+    if (rescue && !d_status) {
+        d_status = static_cast<int32_t*>(scratch_get(h, 11, (size_t)B * 4));
+        if (!d_status) { h->err = "out of device memory"; return MPC_ERR_HIP; }
+    }
+    const int rc = solve_dev_any(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
+    if (rc != MPC_OK || !rescue || h->h_fail[0] == 0u) return rc;       // (converged mode: the solve has synchronised the stream)
+    double prof_keep[6], pipe_keep[8];
+    const int mode_keep = h->last_mode;
+    memcpy(prof_keep, h->prof, sizeof prof_keep);
+    memcpy(pipe_keep, h->pipe_prof, sizeof pipe_keep);
+    const int rr = rescue_dev(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream);
+    memcpy(h->prof, prof_keep, sizeof prof_keep);          // the measurement helpers describe the main solve
+    memcpy(h->pipe_prof, pipe_keep, sizeof pipe_keep);
+    h->last_mode = mode_keep;
+    return rr;
 }
 
 static int ensure_io(mpc_handle* h, size_t B) {

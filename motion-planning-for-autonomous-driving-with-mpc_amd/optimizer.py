@@ -113,7 +113,10 @@ class NlpSolverHandle:
     """`ca.nlpsol('solver', 'ipopt', nlp_prob, opts)` look-alike (optimizer.py:558): callable with the same
     keyword arguments as optimizer.py:607.  Accepts a single instance ((n_w,1) / (n_w,)) or a batch [B, n_w]."""
 
-    rescue = True       # failed instances get a second chance by homotopy on the obstacle radius (solver.rescue_failed)
+    # failed instances get a second chance by homotopy on the obstacle radius: on the device, behind the C-ABI
+    # (mpc_solve_batch; include/mpcgpu.h).  A backend without that (the stand-in backends of the tests) gets the same
+    # procedure from solver.rescue_failed.
+    rescue = True
 
     def __init__(self, backend: BatchedMPCSolver):
         self._backend = backend
@@ -132,7 +135,8 @@ class NlpSolverHandle:
             be.set_bounds(lbx, ubx, lbg, ubg)
         res = be.solve(x0a, pa)
         rescued = np.zeros(res.status.shape[0], dtype=bool)
-        if self.rescue and not np.all(res.status == 1) and lbg is not None and lbx is not None and ubg is not None and ubx is not None:
+        if (self.rescue and not isinstance(be, BatchedMPCSolver) and not np.all(res.status == 1) and lbg is not None and lbx is not None
+                and ubg is not None and ubx is not None):
             res, rescued = rescue_failed(be, x0a, pa, res, (lbx, ubx, lbg, ubg))      # stands in for IPOPT's restoration phase
         self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(), rescued=rescued,
                            success=bool(np.all(res.status == 1)),

@@ -122,17 +122,23 @@ class BatchedMPCSolver:
                                               _abi.as_ip(status), _abi.as_ip(iters), _abi.as_dp(kkt)))
         return SolveResult(out, status, iters, kkt)
 
-    def solve_with_rescue(self, x0, p, fractions=RESCUE_FRACTIONS):
-        """solve(); instances that did not converge get a second chance by homotopy on the obstacle radius (rescue_failed).
-        Needs explicit bounds (set_bounds with the four lists).  Returns (SolveResult, rescued mask)."""
+    def last_rescued(self):
+        """instances of the last solve that took the second chance of the C-ABI (mpc_last_rescued)"""
+        return int(self._lib.mpc_last_rescued(self._h))
+
+    def solve_with_rescue(self, x0, p):
+        """diagnostic form of solve(): the second chance for stalled instances (homotopy on the obstacle radius) runs on the
+        device behind the C-ABI in every solve; this returns the result together with the mask of the instances that needed
+        it, found by solving once with the option "rescue" off.  Returns (SolveResult, rescued mask)."""
+        self.set_option("rescue", "0")
+        try:
+            plain = self.solve(x0, p)
+        finally:
+            self.set_option("rescue", None)
+        if np.all(plain.status == 1):
+            return plain, np.zeros(plain.status.shape[0], dtype=bool)
         res = self.solve(x0, p)
-        if np.all(res.status == 1):
-            return res, np.zeros(res.status.shape[0], dtype=bool)
-        if getattr(self, "_bounds", None) is None:
-            raise MpcError(_abi.MPC_ERR_STATE, "solve_with_rescue needs explicit bounds (set_bounds(lbx, ubx, lbg, ubg))")
-        x0 = np.atleast_2d(_abi.f64(x0))
-        p = np.atleast_2d(_abi.f64(p))
-        return rescue_failed(self, x0, p, res, self._bounds, fractions)
+        return res, (plain.status != 1) & (res.status == 1)
 
     def solve_trace(self, x0, p, obst=None):
         x0 = _abi.f64(x0)

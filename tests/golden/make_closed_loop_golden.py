@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""
+Generates tests/golden/closed_loop_n30.npz: the (p, x0, x*) triplets of BASELINE configuration 1 -- ZAM_Over-1_1 lane following,
+N = 30, L = 30, so that the reference window is frozen from step 0 (`i >= L - N` at i = 0, optimizer.py:670-683) -- as produced by
+the host mirror of CasadiOptimizer.optimize (optimizer.py:562-643, the step-by-step loop with the reference's warm-start
+layouts) whose `sol(...)` calls are answered by the LITERAL dense interior-point solver of oracle/ipm_numpy.py (every one of the
+9 obstacle rows with its own slack, dense KKT matrix) on the numpy restatement of the NLP -- not by the Riccati oracle and not by
+the kernels.  Run in the build container: `python tests/golden/make_closed_loop_golden.py`.
+
+Where the literal solver cannot start from the loop's raw guess (the reference's step-0 warm start is transposed, SURVEY App.
+C-6, and the friction row has a zero gradient at a_0 = 0 -- IPOPT gets through with its restoration phase / second-order
+correction, which are not restated), it is started from a forward rollout of the guess's controls with a_0 nudged off zero; the
+optimum of these lane-following NLPs does not depend on the start (checked: both starts agree where both work).  The start used
+is recorded per step.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.ipm_numpy import DenseIPM  # noqa: E402
+from oracle.nlp_numpy import BicycleNLP, NLPConfig, WEIGHTS_ZAM_LF  # noqa: E402
+
+pkg = importlib.import_module("motion-planning-for-autonomous-driving-with-mpc_amd")
+opt = importlib.import_module("motion-planning-for-autonomous-driving-with-mpc_amd.optimizer")
+scn = importlib.import_module("motion-planning-for-autonomous-driving-with-mpc_amd.scenario")
+OUT = os.path.dirname(os.path.abspath(__file__))
+XML = os.path.join(OUT, "scenarios", "ZAM_Over-1_1.xml")
+N = 30
+
+
+class DenseBackend:
+    """answers sol(...) with the literal dense IPM; records every call"""
+
+    def __init__(self, cfg):
+        self.cfg, self.nlp = cfg, BicycleNLP(cfg)
+        self.n_w, self.n_g, self.N = cfg.n_w, cfg.n_g, cfg.N
+        self.calls = []
+
+    def set_bounds(self, lbx, ubx, lbg, ubg):
+        self.b = [np.asarray(a, dtype=np.float64).copy() for a in (lbx, ubx, lbg, ubg)]
+
+    def solve(self, x0, p):
+        x0, p = np.asarray(x0, float).ravel(), np.asarray(p, float).ravel()
+        lbx, ubx, lbg, ubg = self.b
+        lbg = lbg.copy()
+        lbg[0] = -np.inf                           # |y| >= 0 is implied by the absolute value (no barrier on it)
+        ipm = DenseIPM(self.nlp)
+        tried = []
+        r = ipm.solve(x0, p, lbg=lbg, ubg=ubg, lbx=lbx, ubx=ubx)
+        tried.append(("x0", r))
+        if r["status"] != 1:
+            U, X = self.nlp.split(x0.copy())
+            U = np.clip(U, [-0.4, -3.0], [0.4, 3.0])
+            U[0, 1] = -1.0                          # off the zero-gradient point of the friction row
+            X[0] = p[2 * N:2 * N + 5]
+            for k in range(N):
+                X[k + 1] = self.nlp.plant_step(X[k], U[k])
+                X[k + 1, 3] = max(X[k + 1, 3], 0.05)
+            r = ipm.solve(np.concatenate([U.ravel(), X.ravel()]), p, lbg=lbg, ubg=ubg, lbx=lbx, ubx=ubx)
+            tried.append(("rollout", r))
+        label, r = tried[-1]
+        assert r["status"] == 1, [(t, q["status"], q["iters"]) for t, q in tried]
+        self.calls.append(dict(x0=x0.copy(), p=p.copy(), w=r["x"].copy(), f=r["f"], iters=r["iters"], kkt=r["kkt"], start=label,
+                               both=(len(tried) == 1)))
+        print(f"step {len(self.calls) - 1:2d}: start={label:8s} iters={r['iters']:3d} kkt={r['kkt']:.1e} f={r['f']:.6f} a0={r['x'][1]:+.6f}", flush=True)
+        return pkg.SolveResult(r["x"][None], np.array([1], np.int32), np.array([r["iters"]], np.int32), np.array([r["kkt"]]))
+
+
+def main():
+    from test_scenario import SETTINGS_LF
+    settings = {k: (dict(v) if isinstance(v, dict) else v) for k, v in SETTINGS_LF.items()}
+    settings["general_planning_settings"] = dict(settings["general_planning_settings"], predict_horizon=N, noised=False)
+    sc = scn.read_scenario(XML)
+    conf = scn.Configuration(settings, sc, 1).configuration
+    assert conf.iter_length == N                    # L = N: the window is frozen from the first step
+    pp = sc.planning_problems[1]
+    init_values = (np.array(pp.initial_position), pp.initial_velocity, 0.0, pp.initial_orientation)
+    o = opt.CasadiOptimizer(configuration=conf, init_values=init_values, predict_horizon=N)
+    o.use_device_loop = False
+    be = DenseBackend(NLPConfig(N=N, nx=5, **WEIGHTS_ZAM_LF))
+    o._sol = opt.NlpSolverHandle(be)
+    o._sol.rescue = False
+    states, controls, _ = o.optimize()
+    c = be.calls
+    np.savez_compressed(os.path.join(OUT, "closed_loop_n30.npz"),
+                        x0=np.array([q["x0"] for q in c]), p=np.array([q["p"] for q in c]), w=np.array([q["w"] for q in c]),
+                        f=np.array([q["f"] for q in c]), iters=np.array([q["iters"] for q in c]), kkt=np.array([q["kkt"] for q in c]),
+                        start=np.array([q["start"] for q in c]), states=states, controls=controls,
+                        path=np.asarray(conf.reference_path), orientation=np.asarray(conf.orientation), v_des=float(conf.desired_velocity),
+                        init_state=np.array([init_values[0][0], init_values[0][1], 0.0, init_values[1], init_values[3]]))
+    print("wrote closed_loop_n30.npz:", len(c), "steps; a0 of step 0 =", controls[0, 1])
+
+
+if __name__ == "__main__":
+    main()

@@ -100,65 +100,149 @@ def ca_instance(cfg, b):
     return x0, p
 
 
+# ---- the optima grid: {ZAM-LF, ZAM-CA, USA-LF weights} x N in {10, 30, 50} x 8 instances, the nx = 6
+# headline family, and the first-step (tiled reference) cases.  Every optimum comes from COLD starts of scipy solvers on the numpy
+# restatement; nothing is seeded by the oracle or the kernels.  The nonconvex collision-avoidance family is solved from several
+# cold starts (the caller's straight-through guess, swerves to either side, perturbed guesses) and EVERY distinct local optimum
+# found is kept (`w_alt`): the tests accept whichever basin the solver under test lands in and report it.
+GRID_COUNT = 8
+FIRST_STATES = [[29.9948, -1.1501, 0.0, 20.0, 0.03495],       # ZAM_Over-1_1.xml:3260-3282
+                [0.0, 0.0, 0.0, 6.8062, -0.4268],              # USA_Lanker-2_18_T-1.xml:113282-113317
+                [10.0, 3.0, 0.0, 12.0, 1.2]]
+MAX_ALT = 4
+
+
+def grid_families():
+    fam = {}
+    for N in (10, 30, 50):
+        fam[f"zamlf_n{N}_nx5"] = (NLPConfig(N=N, nx=5, **WEIGHTS_ZAM_LF), "syn", GRID_COUNT)
+        fam[f"usalf_n{N}_nx5"] = (NLPConfig(N=N, nx=5, **WEIGHTS_USA_LF), "syn_usa", GRID_COUNT)
+        fam[f"zamca_n{N}_nx5"] = (NLPConfig(N=N, nx=5, obstacle=OBSTACLE_ZAM, **WEIGHTS_ZAM_CA), "ca", GRID_COUNT)
+        fam[f"first_n{N}_nx5"] = (NLPConfig(N=N, nx=5, **WEIGHTS_ZAM_LF), "first", 3)
+    fam["zamlf_n30_nx6"] = (NLPConfig(N=30, nx=6, **WEIGHTS_ZAM_LF), "syn", GRID_COUNT)
+    return fam
+
+
+def ca_cold_starts(cfg, x0, p, b):
+    """cold starts for the nonconvex family: none of them comes from a solver"""
+    N, nx = cfg.N, cfg.nx
+    starts = [("x0", x0)]
+    Xr = p[2 * N:].reshape(N + 1, nx)
+    ox, oy = cfg.obstacle[0], cfg.obstacle[1]
+    for side, label in ((+1.0, "swerve_left"), (-1.0, "swerve_right")):
+        X = Xr.copy()
+        X[0] = Xr[0]
+        bump = side * 4.5 * np.exp(-0.5 * ((X[1:, 0] - ox) / 8.0) ** 2)
+        X[1:, 1] = oy + bump * (np.abs(X[1:, 0] - ox) < 30.0) + Xr[1:, 1] * (np.abs(X[1:, 0] - ox) >= 30.0)
+        starts.append((label, np.concatenate([np.zeros(2 * N), X.ravel()])))
+    rng = np.random.default_rng(1000 + b)
+    for q in range(2):
+        X = np.tile(Xr[0], (N + 1, 1))
+        X[1:, 1] += rng.normal(0.0, 1.5)
+        starts.append((f"shifted{q}", np.concatenate([np.zeros(2 * N), X.ravel()])))
+    return starts
+
+
+def generic_cold_starts(cfg, nlp, x0, p):
+    """further cold starts for the (locally unique) lane-following families, used when SLSQP does not get through from the
+    caller's guess: a zero-input rollout from the initial state, and the reference itself as the state guess"""
+    N, nx = cfg.N, cfg.nx
+    U, X = nlp.split(x0.copy())
+    X = X.copy()
+    X[0] = p[2 * N:2 * N + nx]
+    for k in range(N):
+        X[k + 1] = nlp.plant_step(X[k], np.zeros(2))
+    Xr = p[2 * N:].reshape(N + 1, nx)
+    return [("rollout", np.concatenate([np.zeros(2 * N), X.ravel()])), ("reference", np.concatenate([np.zeros(2 * N), Xr.ravel()]))]
+
+
+def feasible(nlp, w, p, tol=1e-7):
+    lbg, ubg, lbx, ubx = nlp.bounds()
+    g = nlp.g(w, p)
+    return bool(np.all(g >= lbg - tol) and np.all(g <= ubg + tol) and np.all(w >= lbx - tol) and np.all(w <= ubx + tol))
+
+
+def solve_job(job):
+    name, b = job
+    cfg, kind, _ = grid_families()[name]
+    nlp = BicycleNLP(cfg)
+    if kind == "syn":
+        x0, p = synthetic_instance(cfg, b)
+    elif kind == "syn_usa":
+        x0, p = synthetic_instance(cfg, b, v_range=(5.0, 9.0))
+    elif kind == "ca":
+        x0, p = ca_instance(cfg, b)
+    else:
+        x0, p = first_step_instance(cfg, FIRST_STATES[b])
+    t = time.time()
+    cache = os.path.join(os.environ.get("GOLDEN_CACHE", "/tmp/golden_cache"), f"{name}_{b}.npz")
+    if os.path.exists(cache):
+        c = np.load(cache, allow_pickle=True)
+        return name, b, c["x0"], c["p"], [tuple(q) for q in c["checked"]]
+    starts = ca_cold_starts(cfg, x0, p, b) if kind == "ca" else [("x0", x0)] + generic_cold_starts(cfg, nlp, x0, p)
+    found = []                                           # (f, w, label)
+    for label, s0 in starts:
+        r = scipy_slsqp(nlp, s0, p)
+        # SLSQP with ftol 1e-13 often ends with status 8 ("positive directional derivative") AT the optimum: accept a feasible end
+        # point whose restart does not move (the independent trust-constr run below then checks that it is a KKT point)
+        if r.status not in (0, 8) or not feasible(nlp, r.x, p):
+            continue
+        r2 = scipy_slsqp(nlp, r.x, p)
+        if r2.status not in (0, 8) or not feasible(nlp, r2.x, p) or np.abs(r2.x - r.x).max() > 1e-5:
+            continue
+        r = r2
+        if any(np.abs(r.x - w).max() < 1e-4 for _, w, _ in found):
+            continue
+        found.append((float(r.fun), r.x, label))
+        if kind != "ca":
+            break                                        # locally unique: the first cold start that gets through is the optimum
+    assert found, (name, b, "no cold start converged")
+    found.sort(key=lambda q: q[0])
+    # second, independent solver (interior-point trust-region) on every optimum kept: started from a perturbation of the SLSQP
+    # point it acts as an independent KKT check of that point; from the cold start when that works (recorded in `start`)
+    checked = []
+    for f, w, label in found[:MAX_ALT]:
+        tcstart = "x0"
+        rt = scipy_trust_constr(nlp, x0, p) if kind != "ca" else None
+        dtc = float(np.abs(rt.x - w).max()) if rt is not None else np.inf
+        if dtc > 1e-5:
+            pert = np.random.default_rng(b).normal(0.0, 1e-3, w.size)
+            rt = scipy_trust_constr(nlp, w + pert, p)
+            dtc = float(np.abs(rt.x - w).max())
+            tcstart = "slsqp+1e-3"
+        checked.append((f, w, label + "|" + tcstart, dtc))
+    os.makedirs(os.path.dirname(cache), exist_ok=True)
+    np.savez(cache, x0=x0, p=p, checked=np.array(checked, dtype=object))
+    print(f"{name}[{b}] {len(found)} optimum/optima: " + ", ".join(f"f={c[0]:.6f} ({c[2]}, |dw|={c[3]:.1e})" for c in checked) + f"  {time.time() - t:.0f}s", flush=True)
+    return name, b, x0, p, checked
+
+
 def make_optima():
-    fam = {
-        "zamlf_n10_nx5": (NLPConfig(N=10, nx=5, **WEIGHTS_ZAM_LF), "syn", 8),
-        "zamlf_n30_nx5": (NLPConfig(N=30, nx=5, **WEIGHTS_ZAM_LF), "syn", 6),
-        "zamlf_n30_nx6": (NLPConfig(N=30, nx=6, **WEIGHTS_ZAM_LF), "syn", 6),
-        "usalf_n50_nx5": (NLPConfig(N=50, nx=5, **WEIGHTS_USA_LF), "syn_usa", 3),
-        "zamca_n30_nx5": (NLPConfig(N=30, nx=5, obstacle=OBSTACLE_ZAM, **WEIGHTS_ZAM_CA), "ca", 4),
-        "first_n10_nx5": (NLPConfig(N=10, nx=5, **WEIGHTS_ZAM_LF), "first", 3),
-        "first_n30_nx5": (NLPConfig(N=30, nx=5, **WEIGHTS_ZAM_LF), "first", 1),
-    }
-    first_states = [[29.9948, -1.1501, 0.0, 20.0, 0.03495],       # ZAM_Over-1_1.xml:3260-3282
-                    [0.0, 0.0, 0.0, 6.8062, -0.4268],              # USA_Lanker-2_18_T-1.xml:113282-113317
-                    [10.0, 3.0, 0.0, 12.0, 1.2]]
+    import multiprocessing as mp
+    fam = grid_families()
+    jobs = [(name, b) for name, (_, _, count) in fam.items() for b in range(count)]
+    jobs.sort(key=lambda j: -fam[j[0]][0].N)             # long horizons first
+    with mp.Pool(int(os.environ.get("GOLDEN_PROCS", "6"))) as pool:
+        results = pool.map(solve_job, jobs, chunksize=1)
     out = {}
     for name, (cfg, kind, count) in fam.items():
-        nlp = BicycleNLP(cfg)
-        X0, P, W, F, DTC, START = [], [], [], [], [], []
-        for b in range(count):
-            if kind == "syn":
-                x0, p = synthetic_instance(cfg, b)
-            elif kind == "syn_usa":
-                x0, p = synthetic_instance(cfg, b, v_range=(5.0, 9.0))
-            elif kind == "ca":
-                x0, p = ca_instance(cfg, b)
-            else:
-                x0, p = first_step_instance(cfg, first_states[b])
-            t = time.time()
-            start = "x0"
-            r = scipy_slsqp(nlp, x0, p)
-            if kind == "ca":
-                # nonconvex (pass left / right): make sure SLSQP and the oracle sit in the same basin by
-                # polishing from the oracle's answer when the cold-start optima differ; recorded in `start`
-                from oracle.binding import OracleSolver
-                ro = OracleSolver(cfg).solve(x0, p)
-                if not r.success or np.abs(r.x - ro["x"]).max() > 1e-4:
-                    r2 = scipy_slsqp(nlp, ro["x"], p)
-                    print(f"   [ca] cold SLSQP f={r.fun:.6f} (ok={r.success}) vs oracle f={ro['f']:.6f}; polished f={r2.fun:.6f}")
-                    r, start = r2, "oracle"
-            t1 = time.time() - t
-            # second, independent solver (interior-point trust-region).  From the cold start it sometimes stops at
-            # its iteration limit far from any optimum; then it is restarted from a perturbation of the SLSQP
-            # point and acts as an independent KKT check of that point (recorded in `tcstart`).
-            tcstart = "x0"
-            rt = scipy_trust_constr(nlp, r.x if kind == "ca" else x0, p)
-            dtc = float(np.abs(rt.x - r.x).max())
-            if dtc > 1e-5:
-                pert = np.random.default_rng(b).normal(0.0, 1e-3, r.x.size)
-                rt = scipy_trust_constr(nlp, r.x + pert, p)
-                dtc = float(np.abs(rt.x - r.x).max())
-                tcstart = "slsqp+1e-3"
-            print(f"{name}[{b}] slsqp ok={r.success} nit={r.nit} f={r.fun:.9f} ({t1:.1f}s)  trust-constr f={rt.fun:.9f} |dw|={dtc:.2e}",
-                  flush=True)
-            X0.append(x0); P.append(p); W.append(r.x); F.append(r.fun); DTC.append(dtc); START.append(start + '|' + tcstart)
-        out[f"{name}__x0"] = np.array(X0)
-        out[f"{name}__p"] = np.array(P)
-        out[f"{name}__w"] = np.array(W)
-        out[f"{name}__f"] = np.array(F)
-        out[f"{name}__dtc"] = np.array(DTC)
-        out[f"{name}__start"] = np.array(START)
+        rs = sorted([r for r in results if r[0] == name], key=lambda r: r[1])
+        nw = cfg.n_w
+        out[f"{name}__x0"] = np.array([r[2] for r in rs])
+        out[f"{name}__p"] = np.array([r[3] for r in rs])
+        out[f"{name}__w"] = np.array([r[4][0][1] for r in rs])                      # the lowest optimum found
+        out[f"{name}__f"] = np.array([r[4][0][0] for r in rs])
+        out[f"{name}__dtc"] = np.array([r[4][0][3] for r in rs])
+        out[f"{name}__start"] = np.array([r[4][0][2] for r in rs])
+        alt = np.full((count, MAX_ALT, nw), np.nan)
+        altf = np.full((count, MAX_ALT), np.nan)
+        altd = np.full((count, MAX_ALT), np.nan)
+        for i, r in enumerate(rs):
+            for k, c in enumerate(r[4]):
+                alt[i, k], altf[i, k], altd[i, k] = c[1], c[0], c[3]
+        out[f"{name}__w_alt"] = alt                                                  # every distinct local optimum found (row 0 = w)
+        out[f"{name}__f_alt"] = altf
+        out[f"{name}__dtc_alt"] = altd
         out[f"{name}__cfg"] = np.array([cfg.N, cfg.nx, cfg.dt, *cfg.Q, *cfg.R, *cfg.obstacle])
     np.savez_compressed(os.path.join(OUT, "nlp_optima.npz"), **out)
 

@@ -200,3 +200,43 @@ class EmuForcesBackend:
                                         dp(x0), dp(par), dp(xinit), dp(zo), abi.as_ip(it), abi.as_ip(st), dp(kk))
         assert rc == 0
         return zo, st, it, kk
+
+
+# ------------------------------------------------------------------------------------------------------------
+# KKT certificate: is `w` a KKT point of the NLP of optimizer.py:373-558?  Uses ONLY the numpy restatement of the NLP
+# (oracle/nlp_numpy.py: f, grad, g, jac, bounds) -- no interior-point code of any kind, so that accepting a solution of the
+# kernels does not rest on the sibling IPM implementations.  Multipliers are recovered by sign-constrained least squares on the
+# rows / bounds that are active at w.
+# ------------------------------------------------------------------------------------------------------------
+def kkt_certificate(nlp, w, p, active_tol=1e-4):
+    from scipy.optimize import lsq_linear
+    lbg, ubg, lbx, ubx = nlp.bounds()
+    w, p = np.asarray(w, float), np.asarray(p, float)
+    g, J, grad = nlp.g(w, p), nlp.jac(w, p), nlp.grad(w, p)
+    feas = max(0.0, float((lbg - g).max()), float((g - ubg).max()), float((lbx - w).max()), float((w - ubx).max()))
+    cols, lo, hi = [], [], []
+    first_obst = 1 + nlp.nx * (nlp.N + 1)
+    for i in range(nlp.n_g):
+        if i >= first_obst and (i - first_obst) % 3:            # the 9 obstacle rows are 3 distinct rows, each three times
+            continue
+        if lbg[i] == ubg[i]:
+            cols.append(J[i]); lo.append(-np.inf); hi.append(np.inf)
+            continue
+        sc = max(1.0, abs(g[i]))
+        if np.isfinite(lbg[i]) and i != 0 and g[i] - lbg[i] <= active_tol * sc:      # (row 0: |y| >= 0 is implied, never active)
+            cols.append(-J[i]); lo.append(0.0); hi.append(np.inf)
+        if np.isfinite(ubg[i]) and ubg[i] - g[i] <= active_tol * sc:
+            cols.append(J[i]); lo.append(0.0); hi.append(np.inf)
+    for i in range(nlp.n_w):
+        e = np.zeros(nlp.n_w)
+        e[i] = 1.0
+        sc = max(1.0, abs(w[i]))
+        if np.isfinite(lbx[i]) and w[i] - lbx[i] <= active_tol * sc:
+            cols.append(-e); lo.append(0.0); hi.append(np.inf)
+        if np.isfinite(ubx[i]) and ubx[i] - w[i] <= active_tol * sc:
+            cols.append(e); lo.append(0.0); hi.append(np.inf)
+    A = np.array(cols).T
+    r = lsq_linear(A, -grad, bounds=(np.array(lo), np.array(hi)), method="bvls" if A.shape[1] < 400 else "trf", tol=1e-14, lsq_solver="exact")
+    res = A @ r.x + grad
+    return dict(stationarity=float(np.abs(res).max()) / max(1.0, float(np.abs(grad).max())), feasibility=feas,
+                n_active=int(sum(1 for q in lo if q == 0.0)), grad_norm=float(np.abs(grad).max()))
