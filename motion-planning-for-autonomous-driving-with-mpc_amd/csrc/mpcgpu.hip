@@ -1300,11 +1300,13 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     }
     {
         // the pipeline routes a tile's work by the XCD a workgroup really runs on: learn the set once (d_counter[0] as scratch)
+        // (memset, kernel and read-back all on the handle's own stream: that stream does not synchronise with the null stream, a
+        //  hipMemset there could land after the kernel's atomics and leave an empty mask)
         uint32_t m = 0;
-        if (hipMemset(h->d_counter, 0, sizeof(uint32_t)) == hipSuccess) {
+        if (hipMemsetAsync(h->d_counter, 0, sizeof(uint32_t), h->own_stream) == hipSuccess) {
             hipLaunchKernelGGL(k_xcd_census, dim3(4 * h->n_cu), dim3(64), 0, h->own_stream, reinterpret_cast<uint32_t*>(h->d_counter));
-            if (hipStreamSynchronize(h->own_stream) == hipSuccess &&
-                hipMemcpy(&m, h->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess && m != 0u && __builtin_popcount(m) <= 8) h->xcd_mask = m;
+            if (hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, h->own_stream) == hipSuccess &&
+                hipStreamSynchronize(h->own_stream) == hipSuccess && (m = (uint32_t)h->h_counter[0]) != 0u && __builtin_popcount(m) <= 8) h->xcd_mask = m;
             else h->pipe_disabled = true;
         }
     }
@@ -1556,7 +1558,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (stage_timing) {
         HIP_TRY(h, hipMalloc(&t_dbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk));
         d_dbg = t_dbg.as<unsigned long long>();
-        HIP_TRY(h, hipMemset(d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)nblk));
+        HIP_TRY(h, hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)nblk, stream));
     }
     // Convergence polling: every stage launch adds the number of instances it leaves running to its own device counter;
     // after each chunk the last counter is copied to pinned memory.  The host looks at the poll of chunk c-1 only after
@@ -1813,7 +1815,7 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
     if (!idx) { h->err = "rescue: out of device memory"; return MPC_ERR_HIP; }
     int32_t* cnt = idx + nB;
     static const double pass1[] = {0.0, 1.0}, pass2[] = {0.0, 0.4, 0.7, 0.9, 1.0};
-    const double ol_keep = h->hp.ol;
+    const double ol_keep = h->hp.ol, tol_keep = h->hp.desc.tol;
     h->rescued_last = 0;
     int rc = MPC_OK;
     for (int pass = 0; pass < 2 && rc == MPC_OK; ++pass) {
@@ -1832,14 +1834,17 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
         const int nfr = pass == 0 ? 2 : 5;
         for (int q = 0; q < nfr && rc == MPC_OK; ++q) {
             h->hp.ol = relax_lo(fr[q] * h->hp.ol_raw);
+            h->hp.desc.tol = (q + 1 < nfr) ? std::max(tol_keep, 1e-4) : tol_keep;      // intermediate levels only produce warm starts
             rc = solve_dev_any(h, n, xs, ps, d_obst ? os : nullptr, out, st, it, kk, stream, nullptr, 0, nullptr);
             if (rc == MPC_OK) hipLaunchKernelGGL(k_rescue_carry, dim3(n), dim3(128), 0, stream, (int)nw, st, it, out, xs, acc);
         }
         h->hp.ol = ol_keep;
+        h->hp.desc.tol = tol_keep;
         if (rc == MPC_OK) hipLaunchKernelGGL(k_rescue_scatter, dim3(n), dim3(128), 0, stream, idx, (int)nw, st, out, kk, acc, d_x_out, d_status, d_iters, d_kkt);
         if (pass == 0) h->rescued_last = n;
     }
     h->hp.ol = ol_keep;
+    h->hp.desc.tol = tol_keep;
     if (rc == MPC_OK) { HIP_TRY(h, hipGetLastError()); HIP_TRY(h, hipStreamSynchronize(stream)); }
     return rc;
 }
