@@ -10,7 +10,14 @@
 //    s.t.    x_1 = xinit,   x_{k+1} = c(zbar_k) + C_k dz_k,   lb <= zbar + dz <= ub,   hl <= h(zbar_k) + J_k dz_k <= hu
 //
 // (z = [deltaDot, aLong, x, y, delta, v, psi]; stage functions: forces_stage_functions below = FORCESNLPsolver_model.c, row a11.)
-// One instance per thread; the workspace is [row][Bp] so that a wavefront reads 64 consecutive doubles per row.
+//
+// Mapping: ONE THREAD PER (instance, stage).  Everything that is local to a stage -- building the QP, residuals, condensing
+// the inequality rows into the stage Hessian, slack / multiplier steps, step lengths, updates -- runs for all stages at once;
+// only the Riccati recursion itself is a chain over the stages, walked by handing the turn from stage to stage inside the
+// workgroup (cost-to-go and step travel through the workspace rows of the neighbouring stage).  Per-instance sums / minima over
+// the stages are combined in stage order, so the CPU driver below (forces_qp_instance: the same phase functions called stage
+// after stage, used by the emulation harness) and the GPU kernel (k_forces_qp in mpcgpu.hip) produce the same numbers.
+// The workspace is [stage][row][Bp]: the threads of one stage read consecutive doubles per row.
 // Shared by the HIP kernel (mpcgpu.hip) and the CPU emulation harness (tests/emu); oracle: oracle/forces_qp_numpy.py.
 #pragma once
 #include <math.h>
@@ -41,8 +48,7 @@ enum FqpRow {
     FQ_C = 0,                      // 35  RK4 Jacobian C = [B A] (5x7, row-major)
     FQ_E = FQ_C + 35,              // 5   c(zbar_k) - zbar_{k+1}[2:7]
     FQ_G = FQ_E + 5,               // 7   grad f
-    FQ_JH = FQ_G + 7,              // 70  Jacobian of h (10x7)
-    FQ_D = FQ_JH + 70,             // 34  right-hand sides d of G dz <= d: [7 lower bounds | 7 upper bounds | 10 h upper | 10 h lower]
+    FQ_D = FQ_G + 7,               // 34  right-hand sides d of G dz <= d: [7 lower bounds | 7 upper bounds | 10 h upper | 10 h lower]
     FQ_W = FQ_D + 34,              // 7   dz
     FQ_S = FQ_W + 7,               // 34  slacks
     FQ_LAM = FQ_S + 34,            // 34  inequality multipliers
@@ -57,8 +63,14 @@ enum FqpRow {
     FQ_DS = FQ_DW + 7,             // 34
     FQ_DL = FQ_DS + 34,            // 34
     FQ_DPI = FQ_DL + 34,           // 5   new equality multipliers of the step
-    FQ_ROWS = FQ_DPI + 5
+    FQ_PV = FQ_DPI + 5,            // 5   cost-to-go vector p_k (handed to stage k - 1 in the backward recursion)
+    FQ_DXIN = FQ_PV + 5,           // 5   dx_k as handed over by stage k - 1 in the forward recursion
+    FQ_JHS = FQ_DXIN + 5,          // 30  Jacobian of h, nonzeros only: friction row (columns 1, 4, 5), nine distance rows (columns 2, 3, 6)
+    FQ_ROWS = FQ_JHS + 30
 };
+// the rows the recursions hand from stage to stage, and the stage's RK4 Jacobian, live in LDS on the device: [row][thread],
+// the neighbouring stage of the same instance is IB threads away (on the host they are workspace rows like the others)
+enum FqLocal { FL_C = 0, FL_P = 35, FL_PV = 50, FL_DXIN = 55, FL_ROWS = 60 };
 constexpr int FQ_MI = 34;
 
 // Diagonal Hessian of the QP.  mode 0 (default): the exact Hessian of the reference's least-squares cost, 2 diag(R, Q) per
@@ -168,345 +180,465 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
     }
 }
 
-#define FQW(k_, row_) A.ws[((size_t)(k_) * FQ_ROWS + (size_t)(row_)) * (size_t)A.Bp + (size_t)b]
+#define FQW(k_, row_) A.ws[((size_t)(k_) * FQ_ROWS + (size_t)(row_)) * (size_t)A.Bp + (size_t)c.b]
+// FQL(dk, GRP, i): entry i of row group GRP (C, P, PV, DXIN) of stage k + dk of the same instance
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQL(dk_, grp_, i_) c.loc[(FL_##grp_ + (i_)) * c.T + c.t + (dk_) * c.IB]
+#define FQ_UNROLL _Pragma("unroll")
+#else
+#define FQL(dk_, grp_, i_) FQW(c.k + (dk_), FQ_##grp_ + (i_))
+#define FQ_UNROLL
+#endif
 
-// (G_k v)_q for a vector v (7) held in registers
-MPC_HD double fq_gdot(const ForcesQpArgs& A, int b, int k, int q, const double* v) {
-    if (q < 7) return -v[q];
-    if (q < 14) return v[q - 7];
-    const int j = (q < 24) ? q - 14 : q - 24;
-    double s = 0.0;
-    for (int i = 0; i < 7; ++i) s += (double)FQW(k, FQ_JH + j * 7 + i) * v[i];
-    return (q < 24) ? s : -s;
+// per-(instance, stage) thread state that lives in registers across the phases of one solve
+struct FqCtx {
+    int b, k;
+    bool valid;          // k < N and b < B
+    bool run;            // the instance is still iterating (the same for all stages of an instance)
+    int it, status;
+    double gscale, kkt;
+    double rho[7], Phi[28], eps[5];      // what newton_prep hands to the stage's turn in the backward recursion
+    double* loc;         // device: LDS rows [FL_ROWS][T]
+    int t, T, IB;        // device: thread index, threads per workgroup, instances per workgroup
+};
+struct FqRed { double a, b, c, d; };      // partial of one stage / combined value of one instance (meaning per phase)
+
+// Visits the inequality rows of stage k that are present: f(q, n, c0, c1, c2, v0, v1, v2) with the n (1 or 3) nonzeros of row q of
+// G_k -- columns c0 < c1 < c2, values v*.  Bound rows have one nonzero (-1 / +1 on their variable); the rows of h three
+// (friction: columns 1, 4, 5; squared distances: columns 2, 3, 6), negated for the lower-bound form.  The column numbers are
+// literals at every call of f, so register arrays indexed by them stay in registers.  Row order: bounds of variable 0, 1, ..., 6
+// (lower, upper), friction (upper, lower), distances 1..9 (upper, lower).
+template <class F>
+MPC_HD void fq_each_row(const ForcesQpArgs& A, const FqCtx& c, F f) {
+    const int k = c.k;
+    FQ_UNROLL
+    for (int i = 0; i < 7; ++i) {
+        if (fq_row_on(A, k, i)) f(i, 1, i, 0, 0, -1.0, 0.0, 0.0);
+        if (fq_row_on(A, k, 7 + i)) f(7 + i, 1, i, 0, 0, 1.0, 0.0, 0.0);
+    }
+    {
+        const double a = FQW(k, FQ_JHS + 0), b2 = FQW(k, FQ_JHS + 1), d = FQW(k, FQ_JHS + 2);
+        if (fq_row_on(A, k, 14)) f(14, 3, 1, 4, 5, a, b2, d);
+        if (fq_row_on(A, k, 24)) f(24, 3, 1, 4, 5, -a, -b2, -d);
+    }
+    for (int j = 1; j < 10; ++j) {
+        const double a = FQW(k, FQ_JHS + 3 * j), b2 = FQW(k, FQ_JHS + 3 * j + 1), d = FQW(k, FQ_JHS + 3 * j + 2);
+        if (fq_row_on(A, k, 14 + j)) f(14 + j, 3, 2, 3, 6, a, b2, d);
+        if (fq_row_on(A, k, 24 + j)) f(24 + j, 3, 2, 3, 6, -a, -b2, -d);
+    }
 }
-// out += coef * G_k' e_q
-MPC_HD void fq_gt_axpy(const ForcesQpArgs& A, int b, int k, int q, double coef, double* out) {
-    if (q < 7) { out[q] -= coef; return; }
-    if (q < 14) { out[q - 7] += coef; return; }
-    const int j = (q < 24) ? q - 14 : q - 24;
-    const double sg = (q < 24) ? coef : -coef;
-    for (int i = 0; i < 7; ++i) out[i] += sg * (double)FQW(k, FQ_JH + j * 7 + i);
+#define FQ_ROW_ARGS int q, int n, int c0, int c1, int c2, double v0, double v1, double v2
+#define FQ_PHI(i_, j_) ((i_) * 7 - (i_) * ((i_) - 1) / 2 + ((j_) - (i_)))
+
+// ---- phase: build the QP of stage k at zbar.  partial.a = largest cost-gradient entry of the stage
+MPC_HD void fq_build(const ForcesQpArgs& A, FqCtx& c, FqRed& part) {
+    part = FqRed{1.0, 0.0, 0.0, 0.0};
+    if (!c.valid) return;
+    const int N = A.N, k = c.k;
+    double z[7], p[10], gf[7], cc[5], jc[35], h[10], jh[70], fv;
+    for (int i = 0; i < 7; ++i) z[i] = A.zbar[((size_t)c.b * N + k) * 7 + i];
+    for (int i = 0; i < 10; ++i) p[i] = A.params[((size_t)c.b * N + k) * 10 + i];
+    const bool term = (k == N - 1);
+    forces_stage_functions(A, z, p, term, fv, gf, term ? nullptr : cc, jc, h, jh);
+    double gs = 1.0;
+    for (int i = 0; i < 7; ++i) { FQW(k, FQ_G + i) = gf[i]; FQW(k, FQ_W + i) = 0.0; gs = fmax(gs, fabs(gf[i])); }
+    FQW(k, FQ_JHS + 0) = jh[1]; FQW(k, FQ_JHS + 1) = jh[4]; FQW(k, FQ_JHS + 2) = jh[5];
+    for (int j = 1; j < 10; ++j) { FQW(k, FQ_JHS + 3 * j) = jh[j * 7 + 2]; FQW(k, FQ_JHS + 3 * j + 1) = jh[j * 7 + 3]; FQW(k, FQ_JHS + 3 * j + 2) = jh[j * 7 + 6]; }
+    if (!term) {
+        for (int i = 0; i < 35; ++i) FQL(0, C, i) = jc[i];
+        for (int i = 0; i < 5; ++i) FQW(k, FQ_E + i) = cc[i] - (double)A.zbar[((size_t)c.b * N + k + 1) * 7 + 2 + i];
+    }
+    for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = 0.0;
+    for (int q = 0; q < FQ_MI; ++q) {
+        double d = 0.0;
+        if (q < 7) d = z[q] - A.lb[q];
+        else if (q < 14) d = A.ub[q - 7] - z[q - 7];
+        else if (q < 24) d = A.hu[q - 14] - h[q - 14];
+        else d = h[q - 24] - A.hl[q - 24];
+        const bool on = fq_row_on(A, k, q);
+        FQW(k, FQ_D + q) = on ? d : 0.0;
+        FQW(k, FQ_S + q) = on ? fmax(d, 1.0) : 1.0;
+        FQW(k, FQ_LAM + q) = on ? 1.0 / fmax(d, 1.0) : 0.0;          // centred start: s * lam = 1 on every row
+    }
+    part.a = gs;
 }
 
-// Newton step for complementarity target rc (per row: rc_q = s lam [+ ds_aff dl_aff - sigma mu]); `factor`: also (re)build
-// the matrix part of the Riccati recursion.  corr: 0 = predictor (rc = s lam), 1 = corrector (uses FQ_DS / FQ_DL of the predictor)
-MPC_HD void fq_newton(const ForcesQpArgs& A, int b, bool corr, double sigma_mu) {
-    const int N = A.N;
-    double P[15], pv[5];
-    for (int i = 0; i < 15; ++i) P[i] = 0.0;
-    for (int i = 0; i < 5; ++i) pv[i] = 0.0;
-    // ---------------- backward
-    for (int k = N - 1; k >= 0; --k) {
-        double w[7], rho[7], Phi[28];                       // Phi: symmetric 7x7, upper, index i*7 - i(i-1)/2 + (j-i)
-        for (int i = 0; i < 7; ++i) w[i] = FQW(k, FQ_W + i);
-        const double* hd = (k == N - 1) ? A.hdN : A.hd;
-        for (int i = 0; i < 7; ++i) rho[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i);
-        if (!corr) {
-            for (int i = 0; i < 28; ++i) Phi[i] = 0.0;
-            for (int i = 0; i < 7; ++i) Phi[i * 7 - i * (i - 1) / 2] = hd[i];
+// ---- phase: residuals of stage k.  partial: a = sum s lam, b = rows, c = max primal / equality residual, d = max dual residual
+MPC_HD void fq_residual(const ForcesQpArgs& A, const FqCtx& c, FqRed& part) {
+    part = FqRed{0.0, 0.0, 0.0, 0.0};
+    if (!(c.valid && c.run)) return;
+    const int N = A.N, k = c.k;
+    double w[7], rd[7], mu = 0.0, rmax = 0.0, rdmax = 0.0;
+    int M = 0;
+    const double* hd = (k == N - 1) ? A.hdN : A.hd;
+    for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); rd[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i); }
+    for (int i = 0; i < 5; ++i) rd[2 + i] += (double)FQW(k, FQ_PI + i);
+    if (k < N - 1)
+        for (int j = 0; j < 7; ++j) {
+            double t = 0.0;
+            for (int r = 0; r < 5; ++r) t += (double)FQL(0, C, r * 7 + j) * (double)FQW(k + 1, FQ_PI + r);
+            rd[j] -= t;
         }
-        for (int q = 0; q < FQ_MI; ++q) {
-            if (!fq_row_on(A, k, q)) continue;
-            const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), d = FQW(k, FQ_D + q);
-            const double rp = fq_gdot(A, b, k, q, w) + s - d;
-            double rc = s * lam;
-            if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
-            const double D = lam / s;
-            fq_gt_axpy(A, b, k, q, lam + D * rp - rc / s, rho);
-            if (!corr) {
-                double gq[7] = {0, 0, 0, 0, 0, 0, 0};
-                fq_gt_axpy(A, b, k, q, 1.0, gq);
-                for (int i = 0; i < 7; ++i) {
-                    if (gq[i] == 0.0) continue;
-                    for (int j = i; j < 7; ++j) Phi[i * 7 - i * (i - 1) / 2 + (j - i)] += D * gq[i] * gq[j];
-                }
+    fq_each_row(A, c, [&](FQ_ROW_ARGS) {
+        const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q);
+        double gw = v0 * w[c0];
+        rd[c0] += lam * v0;
+        if (n == 3) { gw += v1 * w[c1] + v2 * w[c2]; rd[c1] += lam * v1; rd[c2] += lam * v2; }
+        rmax = fmax(rmax, fabs(gw + s - (double)FQW(k, FQ_D + q)));
+        mu += s * lam;
+        ++M;
+    });
+    for (int i = 0; i < 7; ++i) rdmax = fmax(rdmax, fabs(rd[i]));
+    for (int i = 0; i < 5; ++i) {
+        double re;
+        if (k == 0) re = w[2 + i] - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i]);
+        else {
+            re = w[2 + i] - (double)FQW(k - 1, FQ_E + i);
+            for (int j = 0; j < 7; ++j) re -= (double)FQL(-1, C, i * 7 + j) * (double)FQW(k - 1, FQ_W + j);
+        }
+        rmax = fmax(rmax, fabs(re));
+    }
+    part = FqRed{mu, (double)M, rmax, rdmax};
+}
+MPC_HD void fq_residual_combine(FqRed& a, const FqRed& p) { a.a += p.a; a.b += p.b; a.c = fmax(a.c, p.c); a.d = fmax(a.d, p.d); }
+
+// termination test on the combined residuals (every thread of the instance takes the same decision); returns mu
+MPC_HD double fq_decide(const ForcesQpArgs& A, FqCtx& c, const FqRed& tot) {
+    if (!(c.valid && c.run)) return 0.0;
+    const double M = tot.b, rmax = tot.c, rdmax = tot.d;
+    const double mu = M > 0 ? tot.a / M : 0.0;
+    c.kkt = fmax(fmax(rmax, rdmax / c.gscale), mu);
+    if (!(rmax == rmax) || !(rdmax == rdmax) || !(mu == mu) || c.kkt > 1e300) { c.kkt = NAN; c.status = -6; c.run = false; return mu; }
+    // Stage-wise elimination condenses the inequality rows into the stage Hessians with weights lam/s, which grow like
+    // 1/mu for active rows; past mu ~ 1e-7 the Riccati recursion loses the small entries next to them.  The targets are
+    // therefore the accuracy an SQP step needs (FORCESPRO is called with tolerances of 1e-1, optimizer.py:272-273):
+    // primal / equality residuals <= tol (metres, m/s, rad), dual residual <= tol relative to the largest cost gradient.
+    if (rmax <= A.tol && rdmax <= A.tol * c.gscale && mu <= A.tol_mu) { c.status = 1; c.run = false; return mu; }
+    if (mu > 1e6) { c.status = -7; c.run = false; return mu; }                   // multipliers diverge: the linearised constraints are inconsistent
+    if (c.it >= A.max_it) { c.status = 0; c.run = false; return mu; }
+    return mu;
+}
+
+// ---- phase (all stages at once): the stage-local part of a Newton step for the complementarity target rc (per row:
+// rc_q = s lam [+ ds_aff dl_aff - sigma mu]): condensed gradient rho, condensed Hessian Phi (predictor only; the corrector
+// reuses the factorisation), eps_k = e_k - w_{k+1}[2:7] + C_k w_k
+MPC_HD void fq_newton_prep(const ForcesQpArgs& A, FqCtx& c, bool corr, double sigma_mu) {
+    if (!(c.valid && c.run)) return;
+    const int N = A.N, k = c.k;
+    double w[7];
+    for (int i = 0; i < 7; ++i) w[i] = FQW(k, FQ_W + i);
+    const double* hd = (k == N - 1) ? A.hdN : A.hd;
+    for (int i = 0; i < 7; ++i) c.rho[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i);
+    if (!corr) {
+        for (int i = 0; i < 28; ++i) c.Phi[i] = 0.0;
+        for (int i = 0; i < 7; ++i) c.Phi[i * 7 - i * (i - 1) / 2] = hd[i];
+    }
+    fq_each_row(A, c, [&](FQ_ROW_ARGS) {
+        const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), d = FQW(k, FQ_D + q);
+        double gw = v0 * w[c0];
+        if (n == 3) gw += v1 * w[c1] + v2 * w[c2];
+        const double rp = gw + s - d;
+        double rc = s * lam;
+        if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
+        const double D = lam / s, cf = lam + D * rp - rc / s;
+        c.rho[c0] += cf * v0;
+        if (n == 3) { c.rho[c1] += cf * v1; c.rho[c2] += cf * v2; }
+        if (!corr) {
+            c.Phi[FQ_PHI(c0, c0)] += D * v0 * v0;
+            if (n == 3) {
+                c.Phi[FQ_PHI(c0, c1)] += D * v0 * v1; c.Phi[FQ_PHI(c0, c2)] += D * v0 * v2;
+                c.Phi[FQ_PHI(c1, c1)] += D * v1 * v1; c.Phi[FQ_PHI(c1, c2)] += D * v1 * v2;
+                c.Phi[FQ_PHI(c2, c2)] += D * v2 * v2;
             }
         }
-        // Q-function blocks.  Stage N-1 has no successor; otherwise eps_k = -r_e(k+1)
-        double Huu[3], Hux[10], Hxx[15], hu[2], hx[5];
-        if (!corr) {
-            Huu[0] = Phi[0]; Huu[1] = Phi[1]; Huu[2] = Phi[7];
-            for (int j = 0; j < 5; ++j) { Hux[j] = Phi[2 + j]; Hux[5 + j] = Phi[7 + 1 + j]; }
-            for (int i = 0; i < 5; ++i)
-                for (int j = i; j < 5; ++j) Hxx[fq_sidx(i, j)] = Phi[(i + 2) * 7 - (i + 2) * (i + 1) / 2 + (j - i)];
+    });
+    for (int i = 0; i < 5; ++i) c.eps[i] = 0.0;
+    if (k < N - 1)
+        for (int i = 0; i < 5; ++i) {
+            double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
+            for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * w[j];
+            c.eps[i] = t;
         }
-        hu[0] = rho[0]; hu[1] = rho[1];
-        for (int i = 0; i < 5; ++i) hx[i] = rho[2 + i];
-        double Cm[35], eps[5] = {0, 0, 0, 0, 0};
-        if (k < N - 1) {
-            double q5[5];
-            for (int i = 0; i < 35; ++i) Cm[i] = FQW(k, FQ_C + i);
-            // eps = -(w_{k+1}[2:7] - C w_k - e_k)
+}
+
+// ---- the stage's turn in the backward recursion (stages N-1, N-2, ..., 0 one after the other): cost-to-go P_{k+1}, p_{k+1}
+// come from the workspace rows of stage k + 1, this stage leaves P_k, p_k, the gains and k_ff in its own
+MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
+    if (!(c.valid && c.run)) return;
+    const int N = A.N, k = c.k;
+    const double* rho = c.rho;
+    const double* Phi = c.Phi;
+    const double* eps = c.eps;
+    double Pp[15], pv[5];
+    for (int i = 0; i < 15; ++i) Pp[i] = (k < N - 1) ? (double)FQL(1, P, i) : 0.0;
+    for (int i = 0; i < 5; ++i) pv[i] = (k < N - 1) ? (double)FQL(1, PV, i) : 0.0;
+    // Q-function blocks.  Stage N-1 has no successor
+    double Huu[3], Hux[10], hu[2], hx[5];
+    if (!corr) {
+        Huu[0] = Phi[0]; Huu[1] = Phi[1]; Huu[2] = Phi[7];
+        for (int j = 0; j < 5; ++j) { Hux[j] = Phi[2 + j]; Hux[5 + j] = Phi[7 + 1 + j]; }
+    }
+    hu[0] = rho[0]; hu[1] = rho[1];
+    for (int i = 0; i < 5; ++i) hx[i] = rho[2 + i];
+    double Cm[35];
+    if (k < N - 1) {
+        double q5[5];
+        for (int i = 0; i < 35; ++i) Cm[i] = FQL(0, C, i);
+        if (!corr) {
+            double Pe[5];
             for (int i = 0; i < 5; ++i) {
-                double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
-                for (int j = 0; j < 7; ++j) t += Cm[i * 7 + j] * w[j];
-                eps[i] = t;
-            }
-            if (!corr) {
-                double Pe[5];
-                for (int i = 0; i < 5; ++i) {
-                    double t = 0.0;
-                    for (int j = 0; j < 5; ++j) t += P[fq_sidx(i, j)] * eps[j];
-                    Pe[i] = t;
-                    FQW(k, FQ_PE + i) = t;
-                }
-                // M = P C (5x7), then C' M
-                double M[35];
-                for (int i = 0; i < 5; ++i)
-                    for (int j = 0; j < 7; ++j) {
-                        double t = 0.0;
-                        for (int r = 0; r < 5; ++r) t += P[fq_sidx(i, r)] * Cm[r * 7 + j];
-                        M[i * 7 + j] = t;
-                    }
-                for (int i = 0; i < 7; ++i)
-                    for (int j = i; j < 7; ++j) {
-                        double t = 0.0;
-                        for (int r = 0; r < 5; ++r) t += Cm[r * 7 + i] * M[r * 7 + j];
-                        if (i < 2 && j < 2) Huu[i + j] += t;
-                        else if (i < 2) Hux[i * 5 + (j - 2)] += t;
-                        else Hxx[fq_sidx(i - 2, j - 2)] += t;
-                    }
-                for (int i = 0; i < 5; ++i) q5[i] = Pe[i] + pv[i];
-            } else {
-                for (int i = 0; i < 5; ++i) q5[i] = (double)FQW(k, FQ_PE + i) + pv[i];
-            }
-            for (int j = 0; j < 7; ++j) {
                 double t = 0.0;
-                for (int r = 0; r < 5; ++r) t += Cm[r * 7 + j] * q5[r];
-                if (j < 2) hu[j] += t; else hx[j - 2] += t;
+                for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * eps[j];
+                Pe[i] = t;
+                FQW(k, FQ_PE + i) = t;
             }
-        }
-        double hi[3], Kk[10], Puu[3], Pxu[10];
-        if (!corr) {
-            Puu[0] = Phi[0]; Puu[1] = Phi[1]; Puu[2] = Phi[7];
-            for (int j = 0; j < 5; ++j) { Pxu[j] = Phi[2 + j]; Pxu[5 + j] = Phi[8 + j]; }
-            const double det = Huu[0] * Huu[2] - Huu[1] * Huu[1];
-            hi[0] = Huu[2] / det; hi[1] = -Huu[1] / det; hi[2] = Huu[0] / det;
-            for (int j = 0; j < 5; ++j) {
-                Kk[j] = -(hi[0] * Hux[j] + hi[1] * Hux[5 + j]);
-                Kk[5 + j] = -(hi[1] * Hux[j] + hi[2] * Hux[5 + j]);
-            }
-            for (int i = 0; i < 3; ++i) { FQW(k, FQ_HUI + i) = hi[i]; FQW(k, FQ_PHU + i) = Puu[i]; }
-            for (int i = 0; i < 10; ++i) { FQW(k, FQ_K + i) = Kk[i]; FQW(k, FQ_HXU + i) = Pxu[i]; }
-        } else {
-            for (int i = 0; i < 3; ++i) { hi[i] = FQW(k, FQ_HUI + i); Puu[i] = FQW(k, FQ_PHU + i); }
-            for (int i = 0; i < 10; ++i) { Kk[i] = FQW(k, FQ_K + i); Pxu[i] = FQW(k, FQ_HXU + i); }
-        }
-        const double kf0 = -(hi[0] * hu[0] + hi[1] * hu[1]), kf1 = -(hi[1] * hu[0] + hi[2] * hu[1]);
-        // Cost-to-go in the symmetric ("Joseph") form: with u = K x + kff and A_cl = A + B K,
-        //    P_k = [K; I]' Phi [K; I] + A_cl' P+ A_cl,   p_k = rho_x + K' rho_u + (Phi_xu + K' Phi_uu) kff + A_cl' (P+ (B kff + eps) + p+)
-        // -- sums of terms of one sign.  The textbook form Hxx - Hxu Huu^-1 Hux subtracts two numbers of size lam/s (1e10 and
-        // more for active rows late in the iteration) and loses the O(1) entries that decide the step.
-        double Acl[25], t5[5] = {0, 0, 0, 0, 0}, Pp[15];
-        if (k < N - 1) {
-            for (int i = 0; i < 15; ++i) Pp[i] = corr ? (double)FQW(k + 1, FQ_P + i) : P[i];
-            double off[5];
-            for (int i = 0; i < 5; ++i) {
-                off[i] = eps[i] + Cm[i * 7 + 0] * kf0 + Cm[i * 7 + 1] * kf1;
-                for (int j = 0; j < 5; ++j) Acl[i * 5 + j] = Cm[i * 7 + 2 + j] + Cm[i * 7 + 0] * Kk[j] + Cm[i * 7 + 1] * Kk[5 + j];
-            }
-            for (int i = 0; i < 5; ++i) {
-                double t = pv[i];
-                for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * off[j];
-                t5[i] = t;
-            }
-        }
-        double pn[5];
-        for (int i = 0; i < 5; ++i) {
-            double t = rho[2 + i] + Kk[i] * rho[0] + Kk[5 + i] * rho[1];
-            t += (Pxu[i] + Kk[i] * Puu[0] + Kk[5 + i] * Puu[1]) * kf0 + (Pxu[5 + i] + Kk[i] * Puu[1] + Kk[5 + i] * Puu[2]) * kf1;
-            if (k < N - 1)
-                for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * t5[r];
-            pn[i] = t;
-        }
-        if (!corr) {
-            double PA[25];                                  // P+ A_cl
-            if (k < N - 1)
-                for (int i = 0; i < 5; ++i)
-                    for (int j = 0; j < 5; ++j) {
-                        double t = 0.0;
-                        for (int r = 0; r < 5; ++r) t += Pp[fq_sidx(i, r)] * Acl[r * 5 + j];
-                        PA[i * 5 + j] = t;
-                    }
+            // the u-rows of C' (P C): M = P C (5x7), then rows 0, 1 of C' M
+            double M[35];
             for (int i = 0; i < 5; ++i)
-                for (int j = i; j < 5; ++j) {
-                    double t = Phi[(i + 2) * 7 - (i + 2) * (i + 1) / 2 + (j - i)];
-                    t += Pxu[i] * Kk[j] + Pxu[5 + i] * Kk[5 + j] + Kk[i] * Pxu[j] + Kk[5 + i] * Pxu[5 + j];
-                    t += Kk[i] * (Puu[0] * Kk[j] + Puu[1] * Kk[5 + j]) + Kk[5 + i] * (Puu[1] * Kk[j] + Puu[2] * Kk[5 + j]);
-                    if (k < N - 1)
-                        for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * PA[r * 5 + j];
-                    P[fq_sidx(i, j)] = t;
-                }
-            for (int i = 0; i < 15; ++i) FQW(k, FQ_P + i) = P[i];
-        }
-        for (int i = 0; i < 5; ++i) pv[i] = pn[i];
-        // the step of u_k is finished in the forward sweep; keep kff and p_k (in the DW / DPI rows for now)
-        FQW(k, FQ_DW + 0) = kf0;
-        FQW(k, FQ_DW + 1) = kf1;
-        for (int i = 0; i < 5; ++i) FQW(k, FQ_DPI + i) = pv[i];
-    }
-    // ---------------- forward
-    double dx[5];
-    for (int i = 0; i < 5; ++i) dx[i] = -((double)FQW(0, FQ_W + 2 + i) - ((double)A.xinit[(size_t)b * 5 + i] - (double)A.zbar[((size_t)b * N) * 7 + 2 + i]));
-    for (int k = 0; k < N; ++k) {
-        double du[2] = {FQW(k, FQ_DW + 0), FQW(k, FQ_DW + 1)};
-        for (int j = 0; j < 5; ++j) { du[0] += (double)FQW(k, FQ_K + j) * dx[j]; du[1] += (double)FQW(k, FQ_K + 5 + j) * dx[j]; }
-        double dw[7] = {du[0], du[1], dx[0], dx[1], dx[2], dx[3], dx[4]};
-        for (int i = 0; i < 7; ++i) FQW(k, FQ_DW + i) = dw[i];
-        // new equality multipliers of block k: -(P_k dx_k + p_k)
-        for (int i = 0; i < 5; ++i) {
-            double t = FQW(k, FQ_DPI + i);
-            for (int j = 0; j < 5; ++j) t += (double)FQW(k, FQ_P + fq_sidx(i, j)) * dx[j];
-            FQW(k, FQ_DPI + i) = -t;
-        }
-        double w[7];
-        for (int i = 0; i < 7; ++i) w[i] = FQW(k, FQ_W + i);
-        for (int q = 0; q < FQ_MI; ++q) {
-            if (!fq_row_on(A, k, q)) continue;
-            const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), d = FQW(k, FQ_D + q);
-            const double rp = fq_gdot(A, b, k, q, w) + s - d;
-            double rc = s * lam;
-            if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
-            const double ds = -rp - fq_gdot(A, b, k, q, dw);
-            const double dl = -(rc + lam * ds) / s;
-            FQW(k, FQ_DS + q) = ds;
-            FQW(k, FQ_DL + q) = dl;
-        }
-        if (k < N - 1) {
-            double dn[5];
-            for (int i = 0; i < 5; ++i) {
-                // dx_{k+1} = C dw + eps,  eps = e_k - w_{k+1}[2:7] + C w_k
-                double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
-                for (int j = 0; j < 7; ++j) t += (double)FQW(k, FQ_C + i * 7 + j) * (w[j] + dw[j]);
-                dn[i] = t;
-            }
-            for (int i = 0; i < 5; ++i) dx[i] = dn[i];
-        }
-    }
-}
-
-// one SQP step of instance b
-MPC_HD void forces_qp_instance(const ForcesQpArgs& A, int b) {
-    const int N = A.N;
-    // ---------------- build the QP at zbar
-    double gscale = 1.0;
-    for (int k = 0; k < N; ++k) {
-        double z[7], p[10], gf[7], c[5], jc[35], h[10], jh[70], fv;
-        for (int i = 0; i < 7; ++i) z[i] = A.zbar[((size_t)b * N + k) * 7 + i];
-        for (int i = 0; i < 10; ++i) p[i] = A.params[((size_t)b * N + k) * 10 + i];
-        const bool term = (k == N - 1);
-        forces_stage_functions(A, z, p, term, fv, gf, term ? nullptr : c, jc, h, jh);
-        for (int i = 0; i < 7; ++i) { FQW(k, FQ_G + i) = gf[i]; FQW(k, FQ_W + i) = 0.0; gscale = fmax(gscale, fabs(gf[i])); }
-        for (int i = 0; i < 70; ++i) FQW(k, FQ_JH + i) = jh[i];
-        if (!term) {
-            for (int i = 0; i < 35; ++i) FQW(k, FQ_C + i) = jc[i];
-            for (int i = 0; i < 5; ++i) FQW(k, FQ_E + i) = c[i] - (double)A.zbar[((size_t)b * N + k + 1) * 7 + 2 + i];
-        }
-        for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = 0.0;
-        for (int q = 0; q < FQ_MI; ++q) {
-            double d = 0.0;
-            if (q < 7) d = z[q] - A.lb[q];
-            else if (q < 14) d = A.ub[q - 7] - z[q - 7];
-            else if (q < 24) d = A.hu[q - 14] - h[q - 14];
-            else d = h[q - 24] - A.hl[q - 24];
-            const bool on = fq_row_on(A, k, q);
-            FQW(k, FQ_D + q) = on ? d : 0.0;
-            FQW(k, FQ_S + q) = on ? fmax(d, 1.0) : 1.0;
-            FQW(k, FQ_LAM + q) = on ? 1.0 / fmax(d, 1.0) : 0.0;          // centred start: s * lam = 1 on every row
-        }
-    }
-    // ---------------- Mehrotra predictor-corrector
-    int it = 0, status = 0;
-    double kkt = INFINITY;
-    for (;; ++it) {
-        // residual norms
-        double mu = 0.0, rmax = 0.0, rdmax = 0.0;      // rmax: primal + equality residuals, rdmax: dual residual
-        int M = 0;
-        for (int k = 0; k < N; ++k) {
-            double w[7], rd[7];
-            const double* hd = (k == N - 1) ? A.hdN : A.hd;
-            for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); rd[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i); }
-            for (int i = 0; i < 5; ++i) rd[2 + i] += (double)FQW(k, FQ_PI + i);
-            if (k < N - 1)
                 for (int j = 0; j < 7; ++j) {
                     double t = 0.0;
-                    for (int r = 0; r < 5; ++r) t += (double)FQW(k, FQ_C + r * 7 + j) * (double)FQW(k + 1, FQ_PI + r);
-                    rd[j] -= t;
+                    for (int r = 0; r < 5; ++r) t += Pp[fq_sidx(i, r)] * Cm[r * 7 + j];
+                    M[i * 7 + j] = t;
                 }
-            for (int q = 0; q < FQ_MI; ++q) {
-                if (!fq_row_on(A, k, q)) continue;
-                const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q);
-                fq_gt_axpy(A, b, k, q, lam, rd);
-                rmax = fmax(rmax, fabs(fq_gdot(A, b, k, q, w) + s - (double)FQW(k, FQ_D + q)));
-                mu += s * lam;
-                ++M;
-            }
-            for (int i = 0; i < 7; ++i) rdmax = fmax(rdmax, fabs(rd[i]));
-            for (int i = 0; i < 5; ++i) {
-                double re;
-                if (k == 0) re = w[2 + i] - ((double)A.xinit[(size_t)b * 5 + i] - (double)A.zbar[((size_t)b * N) * 7 + 2 + i]);
-                else {
-                    re = w[2 + i] - (double)FQW(k - 1, FQ_E + i);
-                    for (int j = 0; j < 7; ++j) re -= (double)FQW(k - 1, FQ_C + i * 7 + j) * (double)FQW(k - 1, FQ_W + j);
+            for (int i = 0; i < 2; ++i)
+                for (int j = i; j < 7; ++j) {
+                    double t = 0.0;
+                    for (int r = 0; r < 5; ++r) t += Cm[r * 7 + i] * M[r * 7 + j];
+                    if (j < 2) Huu[i + j] += t;
+                    else Hux[i * 5 + (j - 2)] += t;
                 }
-                rmax = fmax(rmax, fabs(re));
-            }
+            for (int i = 0; i < 5; ++i) q5[i] = Pe[i] + pv[i];
+        } else {
+            for (int i = 0; i < 5; ++i) q5[i] = (double)FQW(k, FQ_PE + i) + pv[i];
         }
-        mu = M > 0 ? mu / M : 0.0;
-        kkt = fmax(fmax(rmax, rdmax / gscale), mu);
-        if (!(rmax == rmax) || !(rdmax == rdmax) || !(mu == mu) || kkt > 1e300) { kkt = NAN; status = -6; break; }
-        // Stage-wise elimination condenses the inequality rows into the stage Hessians with weights lam/s, which grow like
-        // 1/mu for active rows; past mu ~ 1e-7 the Riccati recursion loses the small entries next to them.  The targets are
-        // therefore the accuracy an SQP step needs (FORCESPRO is called with tolerances of 1e-1, optimizer.py:272-273):
-        // primal / equality residuals <= tol (metres, m/s, rad), dual residual <= tol relative to the largest cost gradient.
-        if (rmax <= A.tol && rdmax <= A.tol * gscale && mu <= A.tol_mu) { status = 1; break; }
-        if (mu > 1e6) { status = -7; break; }                   // multipliers diverge: the linearised constraints are inconsistent
-        if (it >= A.max_it) { status = 0; break; }
-        // predictor
-        fq_newton(A, b, false, 0.0);
-        double a_aff = 1.0;
-        for (int k = 0; k < N; ++k)
-            for (int q = 0; q < FQ_MI; ++q) {
-                if (!fq_row_on(A, k, q)) continue;
-                const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), ds = FQW(k, FQ_DS + q), dl = FQW(k, FQ_DL + q);
-                if (ds < 0) a_aff = fmin(a_aff, -s / ds);
-                if (dl < 0) a_aff = fmin(a_aff, -lam / dl);
-            }
-        double mu_aff = 0.0;
-        for (int k = 0; k < N; ++k)
-            for (int q = 0; q < FQ_MI; ++q) {
-                if (!fq_row_on(A, k, q)) continue;
-                mu_aff += ((double)FQW(k, FQ_S + q) + a_aff * (double)FQW(k, FQ_DS + q)) * ((double)FQW(k, FQ_LAM + q) + a_aff * (double)FQW(k, FQ_DL + q));
-            }
-        mu_aff /= M;
-        const double sg = mu_aff / mu, sigma = sg * sg * sg;
-        // corrector
-        fq_newton(A, b, true, sigma * mu);
-        double a_p = 1.0, a_d = 1.0;
-        for (int k = 0; k < N; ++k)
-            for (int q = 0; q < FQ_MI; ++q) {
-                if (!fq_row_on(A, k, q)) continue;
-                const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), ds = FQW(k, FQ_DS + q), dl = FQW(k, FQ_DL + q);
-                if (ds < 0) a_p = fmin(a_p, -0.995 * s / ds);
-                if (dl < 0) a_d = fmin(a_d, -0.995 * lam / dl);
-            }
-        for (int k = 0; k < N; ++k) {
-            for (int i = 0; i < 7; ++i) FQW(k, FQ_W + i) = (double)FQW(k, FQ_W + i) + a_p * (double)FQW(k, FQ_DW + i);
-            for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = (double)FQW(k, FQ_PI + i) + a_d * ((double)FQW(k, FQ_DPI + i) - (double)FQW(k, FQ_PI + i));
-            for (int q = 0; q < FQ_MI; ++q) {
-                if (!fq_row_on(A, k, q)) continue;
-                FQW(k, FQ_S + q) = (double)FQW(k, FQ_S + q) + a_p * (double)FQW(k, FQ_DS + q);
-                FQW(k, FQ_LAM + q) = (double)FQW(k, FQ_LAM + q) + a_d * (double)FQW(k, FQ_DL + q);
-            }
+        for (int j = 0; j < 7; ++j) {
+            double t = 0.0;
+            for (int r = 0; r < 5; ++r) t += Cm[r * 7 + j] * q5[r];
+            if (j < 2) hu[j] += t; else hx[j - 2] += t;
         }
     }
-    for (int k = 0; k < N; ++k)
-        for (int i = 0; i < 7; ++i) A.z_out[((size_t)b * N + k) * 7 + i] = (double)A.zbar[((size_t)b * N + k) * 7 + i] + (double)FQW(k, FQ_W + i);
-    if (A.iters) A.iters[b] = it;
-    if (A.status) A.status[b] = status;
-    if (A.kkt) A.kkt[b] = kkt;
+    double hi[3], Kk[10], Puu[3], Pxu[10];
+    if (!corr) {
+        Puu[0] = Phi[0]; Puu[1] = Phi[1]; Puu[2] = Phi[7];
+        for (int j = 0; j < 5; ++j) { Pxu[j] = Phi[2 + j]; Pxu[5 + j] = Phi[8 + j]; }
+        const double det = Huu[0] * Huu[2] - Huu[1] * Huu[1];
+        hi[0] = Huu[2] / det; hi[1] = -Huu[1] / det; hi[2] = Huu[0] / det;
+        for (int j = 0; j < 5; ++j) {
+            Kk[j] = -(hi[0] * Hux[j] + hi[1] * Hux[5 + j]);
+            Kk[5 + j] = -(hi[1] * Hux[j] + hi[2] * Hux[5 + j]);
+        }
+        for (int i = 0; i < 3; ++i) { FQW(k, FQ_HUI + i) = hi[i]; FQW(k, FQ_PHU + i) = Puu[i]; }
+        for (int i = 0; i < 10; ++i) { FQW(k, FQ_K + i) = Kk[i]; FQW(k, FQ_HXU + i) = Pxu[i]; }
+    } else {
+        for (int i = 0; i < 3; ++i) { hi[i] = FQW(k, FQ_HUI + i); Puu[i] = FQW(k, FQ_PHU + i); }
+        for (int i = 0; i < 10; ++i) { Kk[i] = FQW(k, FQ_K + i); Pxu[i] = FQW(k, FQ_HXU + i); }
+    }
+    const double kf0 = -(hi[0] * hu[0] + hi[1] * hu[1]), kf1 = -(hi[1] * hu[0] + hi[2] * hu[1]);
+    // Cost-to-go in the symmetric ("Joseph") form: with u = K x + kff and A_cl = A + B K,
+    //    P_k = [K; I]' Phi [K; I] + A_cl' P+ A_cl,   p_k = rho_x + K' rho_u + (Phi_xu + K' Phi_uu) kff + A_cl' (P+ (B kff + eps) + p+)
+    // -- sums of terms of one sign.  The textbook form Hxx - Hxu Huu^-1 Hux subtracts two numbers of size lam/s (1e10 and
+    // more for active rows late in the iteration) and loses the O(1) entries that decide the step.
+    double Acl[25], t5[5] = {0, 0, 0, 0, 0};
+    if (k < N - 1) {
+        double off[5];
+        for (int i = 0; i < 5; ++i) {
+            off[i] = eps[i] + Cm[i * 7 + 0] * kf0 + Cm[i * 7 + 1] * kf1;
+            for (int j = 0; j < 5; ++j) Acl[i * 5 + j] = Cm[i * 7 + 2 + j] + Cm[i * 7 + 0] * Kk[j] + Cm[i * 7 + 1] * Kk[5 + j];
+        }
+        for (int i = 0; i < 5; ++i) {
+            double t = pv[i];
+            for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * off[j];
+            t5[i] = t;
+        }
+    }
+    double pn[5];
+    for (int i = 0; i < 5; ++i) {
+        double t = rho[2 + i] + Kk[i] * rho[0] + Kk[5 + i] * rho[1];
+        t += (Pxu[i] + Kk[i] * Puu[0] + Kk[5 + i] * Puu[1]) * kf0 + (Pxu[5 + i] + Kk[i] * Puu[1] + Kk[5 + i] * Puu[2]) * kf1;
+        if (k < N - 1)
+            for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * t5[r];
+        pn[i] = t;
+    }
+    if (!corr) {
+        double PA[25], P[15];                                  // P+ A_cl
+        if (k < N - 1)
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 5; ++j) {
+                    double t = 0.0;
+                    for (int r = 0; r < 5; ++r) t += Pp[fq_sidx(i, r)] * Acl[r * 5 + j];
+                    PA[i * 5 + j] = t;
+                }
+        for (int i = 0; i < 5; ++i)
+            for (int j = i; j < 5; ++j) {
+                double t = Phi[(i + 2) * 7 - (i + 2) * (i + 1) / 2 + (j - i)];
+                t += Pxu[i] * Kk[j] + Pxu[5 + i] * Kk[5 + j] + Kk[i] * Pxu[j] + Kk[5 + i] * Pxu[5 + j];
+                t += Kk[i] * (Puu[0] * Kk[j] + Puu[1] * Kk[5 + j]) + Kk[5 + i] * (Puu[1] * Kk[j] + Puu[2] * Kk[5 + j]);
+                if (k < N - 1)
+                    for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * PA[r * 5 + j];
+                P[fq_sidx(i, j)] = t;
+            }
+        for (int i = 0; i < 15; ++i) FQL(0, P, i) = P[i];
+    }
+    // the step of u_k is finished in the forward sweep; keep kff (in the DW rows for now) and p_k
+    FQW(k, FQ_DW + 0) = kf0;
+    FQW(k, FQ_DW + 1) = kf1;
+    for (int i = 0; i < 5; ++i) FQL(0, PV, i) = pn[i];
+}
+
+// ---- the stage's turn in the forward recursion (stages 0, 1, ..., N-1): dx_k arrives in the stage's own DW rows (written by
+// stage k - 1), leaves dw_k, the new equality multipliers, and dx_{k+1} in the rows of stage k + 1
+MPC_HD void fq_newton_fwd(const ForcesQpArgs& A, FqCtx& c) {
+    if (!(c.valid && c.run)) return;
+    const int N = A.N, k = c.k;
+    double dx[5];
+    for (int i = 0; i < 5; ++i)
+        dx[i] = (k == 0) ? -((double)FQW(0, FQ_W + 2 + i) - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i]))
+                         : (double)FQL(0, DXIN, i);
+    double du[2] = {FQW(k, FQ_DW + 0), FQW(k, FQ_DW + 1)};
+    for (int j = 0; j < 5; ++j) { du[0] += (double)FQW(k, FQ_K + j) * dx[j]; du[1] += (double)FQW(k, FQ_K + 5 + j) * dx[j]; }
+    const double dw[7] = {du[0], du[1], dx[0], dx[1], dx[2], dx[3], dx[4]};
+    for (int i = 0; i < 7; ++i) FQW(k, FQ_DW + i) = dw[i];
+    // new equality multipliers of block k: -(P_k dx_k + p_k)
+    for (int i = 0; i < 5; ++i) {
+        double t = FQL(0, PV, i);
+        for (int j = 0; j < 5; ++j) t += (double)FQL(0, P, fq_sidx(i, j)) * dx[j];
+        FQW(k, FQ_DPI + i) = -t;
+    }
+    if (k < N - 1) {
+        for (int i = 0; i < 5; ++i) {
+            // dx_{k+1} = C dw + eps,  eps = e_k - w_{k+1}[2:7] + C w_k
+            double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
+            for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * ((double)FQW(k, FQ_W + j) + dw[j]);
+            FQL(1, DXIN, i) = t;
+        }
+    }
+}
+
+// ---- phase (all stages at once): slack and multiplier steps of the rows of stage k
+MPC_HD void fq_newton_rows(const ForcesQpArgs& A, const FqCtx& c, bool corr, double sigma_mu) {
+    if (!(c.valid && c.run)) return;
+    const int k = c.k;
+    double w[7], dw[7];
+    for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); dw[i] = FQW(k, FQ_DW + i); }
+    fq_each_row(A, c, [&](FQ_ROW_ARGS) {
+        const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), d = FQW(k, FQ_D + q);
+        double gw = v0 * w[c0], gdw = v0 * dw[c0];
+        if (n == 3) { gw += v1 * w[c1] + v2 * w[c2]; gdw += v1 * dw[c1] + v2 * dw[c2]; }
+        const double rp = gw + s - d;
+        double rc = s * lam;
+        if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
+        const double ds = -rp - gdw;
+        const double dl = -(rc + lam * ds) / s;
+        FQW(k, FQ_DS + q) = ds;
+        FQW(k, FQ_DL + q) = dl;
+    });
+}
+
+// ---- phase: largest step to the boundary over the rows of stage k; partial.a = primal, .b = dual (both <= 1), scaled by `frac`
+MPC_HD void fq_steplen(const ForcesQpArgs& A, const FqCtx& c, double frac, FqRed& part) {
+    part = FqRed{1.0, 1.0, 0.0, 0.0};
+    if (!(c.valid && c.run)) return;
+    const int k = c.k;
+    double a_p = 1.0, a_d = 1.0;
+    for (int q = 0; q < FQ_MI; ++q) {
+        if (!fq_row_on(A, k, q)) continue;
+        const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), ds = FQW(k, FQ_DS + q), dl = FQW(k, FQ_DL + q);
+        if (ds < 0) a_p = fmin(a_p, -frac * s / ds);
+        if (dl < 0) a_d = fmin(a_d, -frac * lam / dl);
+    }
+    part.a = a_p;
+    part.b = a_d;
+}
+MPC_HD void fq_steplen_combine(FqRed& a, const FqRed& p) { a.a = fmin(a.a, p.a); a.b = fmin(a.b, p.b); }
+
+// ---- phase: complementarity after the affine step of length a_aff; partial.a = sum over the rows of stage k
+MPC_HD void fq_mu_aff(const ForcesQpArgs& A, const FqCtx& c, double a_aff, FqRed& part) {
+    part = FqRed{0.0, 0.0, 0.0, 0.0};
+    if (!(c.valid && c.run)) return;
+    const int k = c.k;
+    double m = 0.0;
+    for (int q = 0; q < FQ_MI; ++q) {
+        if (!fq_row_on(A, k, q)) continue;
+        m += ((double)FQW(k, FQ_S + q) + a_aff * (double)FQW(k, FQ_DS + q)) * ((double)FQW(k, FQ_LAM + q) + a_aff * (double)FQW(k, FQ_DL + q));
+    }
+    part.a = m;
+}
+MPC_HD void fq_sum_combine(FqRed& a, const FqRed& p) { a.a += p.a; }
+MPC_HD void fq_max_combine(FqRed& a, const FqRed& p) { a.a = fmax(a.a, p.a); }
+
+// ---- phase: take the step
+MPC_HD void fq_update(const ForcesQpArgs& A, FqCtx& c, double a_p, double a_d) {
+    if (!(c.valid && c.run)) return;
+    const int k = c.k;
+    for (int i = 0; i < 7; ++i) FQW(k, FQ_W + i) = (double)FQW(k, FQ_W + i) + a_p * (double)FQW(k, FQ_DW + i);
+    for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = (double)FQW(k, FQ_PI + i) + a_d * ((double)FQW(k, FQ_DPI + i) - (double)FQW(k, FQ_PI + i));
+    for (int q = 0; q < FQ_MI; ++q) {
+        if (!fq_row_on(A, k, q)) continue;
+        FQW(k, FQ_S + q) = (double)FQW(k, FQ_S + q) + a_p * (double)FQW(k, FQ_DS + q);
+        FQW(k, FQ_LAM + q) = (double)FQW(k, FQ_LAM + q) + a_d * (double)FQW(k, FQ_DL + q);
+    }
+    ++c.it;
+}
+
+// ---- phase: output rows of stage k (the stage-0 thread also reports the instance)
+MPC_HD void fq_output(const ForcesQpArgs& A, const FqCtx& c) {
+    if (!c.valid) return;
+    const int N = A.N, k = c.k;
+    for (int i = 0; i < 7; ++i) A.z_out[((size_t)c.b * N + k) * 7 + i] = (double)A.zbar[((size_t)c.b * N + k) * 7 + i] + (double)FQW(k, FQ_W + i);
+    if (k == 0) {
+        if (A.iters) A.iters[c.b] = c.it;
+        if (A.status) A.status[c.b] = c.status;
+        if (A.kkt) A.kkt[c.b] = c.kkt;
+    }
 }
 
 #undef FQW
+#undef FQL
+#undef FQ_UNROLL
+#undef FQ_ROW_ARGS
+#undef FQ_PHI
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// One SQP step of instance b on the CPU (emulation harness): the phase functions above, stage after stage, with the per-instance
+// reductions taken in stage order -- the order the kernel's reductions use as well.
+inline void forces_qp_instance(const ForcesQpArgs& A, int b) {
+    const int N = A.N;
+    FqCtx* cs = new FqCtx[N];
+    FqRed part, tot;
+    for (int k = 0; k < N; ++k) { cs[k] = FqCtx{}; cs[k].b = b; cs[k].k = k; cs[k].valid = true; cs[k].run = true; cs[k].it = 0; cs[k].status = 0; cs[k].kkt = INFINITY; }
+    tot = FqRed{1.0, 0, 0, 0};
+    for (int k = 0; k < N; ++k) { fq_build(A, cs[k], part); fq_max_combine(tot, part); }
+    for (int k = 0; k < N; ++k) cs[k].gscale = tot.a;
+    for (;;) {
+        tot = FqRed{0, 0, 0, 0};
+        for (int k = 0; k < N; ++k) { fq_residual(A, cs[k], part); fq_residual_combine(tot, part); }
+        double mu = 0.0;
+        const double n_rows = tot.b;
+        for (int k = 0; k < N; ++k) mu = fq_decide(A, cs[k], tot);
+        if (!cs[0].run) break;
+        for (int corr = 0; corr < 2; ++corr) {
+            double sigma_mu = 0.0;
+            if (corr) {
+                tot = FqRed{1.0, 1.0, 0, 0};
+                for (int k = 0; k < N; ++k) { fq_steplen(A, cs[k], 1.0, part); fq_steplen_combine(tot, part); }
+                const double a_aff = fmin(tot.a, tot.b);
+                tot = FqRed{0, 0, 0, 0};
+                for (int k = 0; k < N; ++k) { fq_mu_aff(A, cs[k], a_aff, part); fq_sum_combine(tot, part); }
+                const double mu_aff = tot.a / n_rows, sg = mu_aff / mu;
+                sigma_mu = sg * sg * sg * mu;
+            }
+            for (int k = 0; k < N; ++k) fq_newton_prep(A, cs[k], corr != 0, sigma_mu);
+            for (int k = N - 1; k >= 0; --k) fq_newton_back(A, cs[k], corr != 0);
+            for (int k = 0; k < N; ++k) fq_newton_fwd(A, cs[k]);
+            for (int k = 0; k < N; ++k) fq_newton_rows(A, cs[k], corr != 0, sigma_mu);
+        }
+        tot = FqRed{1.0, 1.0, 0, 0};
+        for (int k = 0; k < N; ++k) { fq_steplen(A, cs[k], 0.995, part); fq_steplen_combine(tot, part); }
+        for (int k = 0; k < N; ++k) fq_update(A, cs[k], tot.a, tot.b);
+    }
+    for (int k = 0; k < N; ++k) fq_output(A, cs[k]);
+    delete[] cs;
+}
+#endif
 
 }  // namespace mpc

@@ -989,10 +989,72 @@ __global__ void __launch_bounds__(128) k_forces_stage(const ForcesArgs A) {
     }
 }
 
-// FORCES-mode SQP step (row f3): one instance per thread, workspace [row][Bp] (mpc_forces_qp.h)
-__global__ void __launch_bounds__(64) k_forces_qp(const ForcesQpArgs A) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < A.B) forces_qp_instance(A, b);
+// FORCES-mode SQP step (row f3; phases in mpc_forces_qp.h): one thread per (instance, stage), a workgroup holds all N stages of
+// IB instances (thread t: stage t / IB, instance t % IB -- the threads of one stage read consecutive doubles of a workspace
+// row).  Stage-local work runs for all stages at once; the Riccati recursion hands the turn from stage to stage between
+// workgroup barriers, cost-to-go and step travelling through the workspace rows of the neighbouring stage (same workgroup,
+// same CU: ordered by the barrier).  Per-instance reductions combine the stage partials in stage order.
+template <class Combine>
+__device__ __forceinline__ FqRed fq_block_reduce(const FqRed& part, FqRed acc, Combine comb, double* lds, int IB, int N) {
+    const int t = threadIdx.x, T = blockDim.x, i = t % IB;
+    lds[t] = part.a; lds[T + t] = part.b; lds[2 * T + t] = part.c; lds[3 * T + t] = part.d;
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const FqRed p{lds[k * IB + i], lds[T + k * IB + i], lds[2 * T + k * IB + i], lds[3 * T + k * IB + i]};
+        comb(acc, p);
+    }
+    __syncthreads();
+    return acc;
+}
+__global__ void __launch_bounds__(256) k_forces_qp(const ForcesQpArgs A, const int IB) {
+    extern __shared__ __attribute__((aligned(16))) double fq_lds[];
+    const int t = threadIdx.x, N = A.N;
+    FqCtx c{};
+    c.k = t / IB;
+    c.b = (int)blockIdx.x * IB + t % IB;
+    c.valid = (c.k < N) && (c.b < A.B);
+    c.run = c.valid;
+    c.it = 0; c.status = 0; c.kkt = INFINITY; c.gscale = 1.0;
+    c.t = t; c.T = (int)blockDim.x; c.IB = IB;
+    c.loc = fq_lds + 4 * blockDim.x;                       // behind the reduction scratch
+    FqRed part, tot;
+    fq_build(A, c, part);
+    tot = fq_block_reduce(part, FqRed{1.0, 0.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_max_combine(a, p); }, fq_lds, IB, N);
+    c.gscale = tot.a;
+    for (;;) {
+        fq_residual(A, c, part);
+        tot = fq_block_reduce(part, FqRed{0.0, 0.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_residual_combine(a, p); }, fq_lds, IB, N);
+        const double n_rows = tot.b;
+        const double mu = fq_decide(A, c, tot);
+        if (!__syncthreads_or(c.run ? 1 : 0)) break;
+        double sigma_mu = 0.0;
+        for (int corr = 0; corr < 2; ++corr) {
+            if (corr) {
+                fq_steplen(A, c, 1.0, part);
+                tot = fq_block_reduce(part, FqRed{1.0, 1.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_steplen_combine(a, p); }, fq_lds, IB, N);
+                const double a_aff = fmin(tot.a, tot.b);
+                fq_mu_aff(A, c, a_aff, part);
+                tot = fq_block_reduce(part, FqRed{0.0, 0.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_sum_combine(a, p); }, fq_lds, IB, N);
+                const double mu_aff = tot.a / n_rows, sg = mu_aff / mu;
+                sigma_mu = sg * sg * sg * mu;
+            }
+            fq_newton_prep(A, c, corr != 0, sigma_mu);
+            for (int step = 0; step < N; ++step) {
+                if (c.k == N - 1 - step) fq_newton_back(A, c, corr != 0);
+                __syncthreads();
+            }
+            for (int step = 0; step < N; ++step) {
+                if (c.k == step) fq_newton_fwd(A, c);
+                __syncthreads();
+            }
+            fq_newton_rows(A, c, corr != 0, sigma_mu);
+        }
+        fq_steplen(A, c, 0.995, part);
+        tot = fq_block_reduce(part, FqRed{1.0, 1.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_steplen_combine(a, p); }, fq_lds, IB, N);
+        fq_update(A, c, tot.a, tot.b);
+        __syncthreads();
+    }
+    fq_output(A, c);
 }
 
 // closed-loop driver around the solve (row f1): one instance per thread, row-major buffers
@@ -1174,6 +1236,7 @@ struct mpc_handle {
     uint32_t* d_fail = nullptr;         // instances of the last solve that did not converge (counted by k_egest)
     uint32_t* h_fail = nullptr;         // pinned copy
     int rescued_last = 0;               // instances the last solve handed to the second chance (rescue_dev)
+    bool attr_set_fq = false;
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
     // mpc_set_option -- no getenv on the solve path
@@ -2139,7 +2202,14 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
     for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
     A.zbar = d_x0; A.params = d_all_parameters; A.xinit = d_xinit; A.z_out = d_x_out; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws;
-    hipLaunchKernelGGL(k_forces_qp, dim3((B + 63) / 64), dim3(64), 0, s, A);
+    int IB = 1;
+    while (IB * 2 * N <= 256 && IB < 64) IB *= 2;                       // instances per workgroup: all N stages of IB instances in <= 256 threads
+    const int threads = ((IB * N + 63) / 64) * 64;
+    if (!h->attr_set_fq) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forces_qp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + FL_ROWS) * 256 * sizeof(double))));
+        h->attr_set_fq = true;
+    }
+    hipLaunchKernelGGL(k_forces_qp, dim3((B + IB - 1) / IB), dim3(threads), (size_t)(4 + FL_ROWS) * threads * sizeof(double), s, A, IB);
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
 }
