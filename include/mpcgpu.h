@@ -130,12 +130,28 @@ int mpc_plant_step_dev(mpc_handle* h, int32_t B, int32_t integrator, const doubl
  * without host round trips between the solves -- per step: mpc_solve_batch_dev, first control, forward-Euler plant
  * step (shift_movement, optimizer.py:645-655), shifted warm start in the layouts the reference produces
  * (optimizer.py:602), next reference window incl. the frozen tail (desired_command_and_trajectory, :657-702).
- * nx = 5 only.  init_state [B,5] = (x, y, 0, v, psi) (optimizer.py:575); path [B,Lp,2], orient [B,Lp]: resampled path
+ * init_state [B,5] = (x, y, 0, v, psi) (optimizer.py:575); path [B,Lp,2], orient [B,Lp]: resampled path
  * points and orientation of every ego, Lp >= L = iter_length >= N; vdes [B].  Outputs: traj [B,L,5] (row i = state
  * before step i: what optimize() returns as its first array), ctrl [B,L,2] (second array), step_status [B,L] or NULL
  * (solver status of every step; the reference ignores it).  No noise (`noised: False`).                           */
 int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
                           const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status);
+/* The same loop with the reference's `noised: True` behaviour, reproducibly: N(0, sigma) samples from a counter-based generator
+ * (Philox4x32-10 + Box-Muller, keyed by seed and (instance, step, sample); csrc/mpc_closed_loop.h, mirrored by noise.py).
+ * noise_mode 0: none; 1: CasadiOptimizer (optimizer.py:611-617) -- noise on the whole predicted input sequence, the noised first
+ * column is applied and the noised sequence is shifted into the next warm start; 2: ForcesproOptimizer (optimizer.py:348-354) --
+ * noise on the applied input only.  sigma: 0.1 lane following, 0.05 collision avoidance (the reference's values).
+ * nx = 5 or 6 (the progress state of nx = 6 starts at 0 and is not reported: traj stays [B,L,5]).
+ * The device-pointer form enqueues the WHOLE loop without a host synchronisation per step when the solves run in the persistent
+ * pipeline launch; an abandoned launch or an instance that needs the second chance is noticed once, at the end, and the loop is
+ * then replayed step by step (mpc_last_loop_replayed tells).  Option "loop_async" = "0" forces the step-by-step form.          */
+int mpc_closed_loop_batch_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
+                             const double* orient, const double* vdes, int32_t noise_mode, double sigma, uint64_t seed,
+                             double* traj, double* ctrl, int32_t* step_status);
+int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
+                                 const double* d_orient, const double* d_vdes, int32_t noise_mode, double sigma, uint64_t seed,
+                                 double* d_traj, double* d_ctrl, int32_t* d_step_status, void* stream);
+int mpc_last_loop_replayed(const mpc_handle* h);
 /* FORCES-mode stage functions (scope row a11): what `FORCESNLPsolver_casadi2forces` evaluates per stage
  * (test/FORCESNLPsolver/FORCESNLPsolver_interface.c:41-198 -> casadi_f0..f9, FORCESNLPsolver_model.c:75-1756; the model
  * of ForcesproOptimizer, optimizer.py:91-245) for B independent (z, p) pairs.  z [B,7] = (deltaDot, aLong, x, y, delta, v,
@@ -184,7 +200,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
 
 /* Run-time switches of a handle.  They are read from the environment once, at mpc_create (MPCGPU_<NAME IN CAPITALS>), and
  * changed afterwards only through this call; value NULL restores the default.  Names: "pipeline" (0: one launch per kernel
- * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances),
+ * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances), "loop_async" (0: closed loop with a host round trip per step),
  * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing"
  * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);

@@ -1065,23 +1065,24 @@ __global__ void k_loop_setup(const LoopArgs A) {
 // after solve i: what loop_advance_instance (mpc_closed_loop.h, the form the CPU harness steps through) does for one
 // instance, laid out for coalesced rows -- one workgroup per instance, the threads run over the n_w columns of the three
 // row-major rows (solution in, warm start and parameter vector out); thread 0 records the step and integrates the plant.
-// Same values bit for bit (the columns are copies, the plant step is the same code).
+// Same values bit for bit (the columns are copies, the plant step and the noise samples are the same code).
 __global__ void __launch_bounds__(128) k_loop_advance(const Params P, const LoopArgs A, const int i) {
-    __shared__ double cur_s[5];
+    __shared__ double cur_s[6];
+    if (A.abort_flag != nullptr && *A.abort_flag != 0u) return;       // a solve of this loop was abandoned: the host replays the loop
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
-    const int N = A.N, nw = 2 * N + 5 * (N + 1);
+    const int N = A.N, nx = A.nx, nw = 2 * N + nx * (N + 1);
     const double* xo = A.x_out + (size_t)b * nw;
     if (t == 0) {
-        double cur[5], u[2], f[5], s, c, td;
-        for (int q = 0; q < 5; ++q) cur[q] = A.state[(size_t)b * 5 + q];
-        u[0] = xo[0];
-        u[1] = xo[1];
+        double cur[6], u[2], f[6], s, c, td;
+        for (int q = 0; q < nx; ++q) cur[q] = A.state[(size_t)b * nx + q];
+        u[0] = xo[0] + loop_noise(A, b, i, 0, 0);
+        u[1] = xo[1] + loop_noise(A, b, i, 1, 0);
         for (int q = 0; q < 5; ++q) A.traj[((size_t)b * A.L + i) * 5 + q] = cur[q];
         A.ctrl[((size_t)b * A.L + i) * 2 + 0] = u[0];
         A.ctrl[((size_t)b * A.L + i) * 2 + 1] = u[1];
         if (A.step_status) A.step_status[(size_t)b * A.L + i] = A.status ? A.status[b] : 0;
-        ode_eval<5>(P, cur, u, f, s, c, td);
-        for (int q = 0; q < 5; ++q) { cur[q] = cur[q] + P.dt * f[q]; A.state[(size_t)b * 5 + q] = cur[q]; cur_s[q] = cur[q]; }
+        if (nx == 5) ode_eval<5>(P, cur, u, f, s, c, td); else ode_eval<6>(P, cur, u, f, s, c, td);
+        for (int q = 0; q < nx; ++q) { cur[q] = cur[q] + P.dt * f[q]; A.state[(size_t)b * nx + q] = cur[q]; cur_s[q] = cur[q]; }
     }
     __syncthreads();
     double* x0 = A.x0 + (size_t)b * nw;
@@ -1091,23 +1092,28 @@ __global__ void __launch_bounds__(128) k_loop_advance(const Params P, const Loop
     for (int q = t; q < nw; q += (int)blockDim.x) {
         double v0, vp = 0.0;
         if (q < N) {
-            v0 = xo[2 * ((q + 1 < N) ? q + 1 : N - 1)];                          // all steering rates ...
+            const int src = (q + 1 < N) ? q + 1 : N - 1;
+            v0 = xo[2 * src] + (A.noise_mode == 1 ? loop_noise(A, b, i, 0, src) : 0.0);         // all steering rates ...
         } else if (q < 2 * N) {
-            const int k = q - N;
-            v0 = xo[2 * ((k + 1 < N) ? k + 1 : N - 1) + 1];                      // ... then all accelerations
+            const int src = (q - N + 1 < N) ? q - N + 1 : N - 1;
+            v0 = xo[2 * src + 1] + (A.noise_mode == 1 ? loop_noise(A, b, i, 1, src) : 0.0);     // ... then all accelerations
         } else {
-            const int r = q - 2 * N, k = r / 5, c = r - 5 * k;
-            v0 = xo[2 * N + 5 * ((k + 1 <= N) ? k + 1 : N) + c];
+            const int r = q - 2 * N, k = r / nx, c = r - nx * k;
+            v0 = xo[2 * N + nx * ((k + 1 <= N) ? k + 1 : N) + c];
             if (k == 0) vp = cur_s[c];
             else {
                 const int idx = i + k - shift;                                    // = i_done + (k - 1) + 1 - shift
                 vp = (c == 0) ? A.path[((size_t)b * A.Lp + idx) * 2] : (c == 1) ? A.path[((size_t)b * A.Lp + idx) * 2 + 1]
-                   : (c == 2) ? 0.0 : (c == 3) ? vd : A.orient[(size_t)b * A.Lp + idx];
+                   : (c == 3) ? vd : (c == 4) ? A.orient[(size_t)b * A.Lp + idx] : 0.0;
             }
         }
         x0[q] = v0;
         p[q] = vp;
     }
+}
+// sticky abort word of an asynchronous closed loop: set once any of its pipeline launches raised its own abort word
+__global__ void k_loop_sticky(const uint32_t* pipe_abort, uint32_t* loop_abort) {
+    if (*pipe_abort != 0u) *loop_abort = 1u;
 }
 
 // ---- second chance for stalled instances (see rescue_dev on the host side) ---------------------------------------------
@@ -1233,8 +1239,11 @@ struct mpc_handle {
     int n_cu = 256;
     uint32_t xcd_mask = 0xFFu;          // XCDs seen by k_xcd_census
     std::vector<hipEvent_t> ev_pool;
-    uint32_t* d_fail = nullptr;         // instances of the last solve that did not converge (counted by k_egest)
+    uint32_t* d_fail = nullptr;         // [0] instances of the last solve that did not converge (counted by k_egest); [1] sticky abort word of an asynchronous closed loop
+    bool async_loop = false;            // solves are being enqueued by the closed-loop driver without host synchronisation
+    bool async_ok = false;              // ... and the last one really went out that way
     uint32_t* h_fail = nullptr;         // pinned copy
+    int loop_replayed = 0;              // the last closed loop had to be replayed with host synchronisation per step
     int rescued_last = 0;               // instances the last solve handed to the second chance (rescue_dev)
     bool attr_set_fq = false;
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
@@ -1242,7 +1251,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1;
+        int rescue = 1, loop_async = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1268,12 +1277,13 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pipe_test_abort") k.pipe_test_abort = on != 0;
     else if (n == "pipe_timing") k.pipe_timing = on != 0;
     else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "pipe_xcd_mask"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "pipe_xcd_mask"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -1352,7 +1362,7 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT) != hipSuccess ||
         hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess ||
-        hipMalloc(&h->d_fail, sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&h->h_fail, sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc(&h->d_fail, 2 * sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&h->h_fail, 2 * sizeof(uint32_t)) != hipSuccess) {
         g_create_error = "HIP stream/counter allocation failed";
         delete h;
         return MPC_ERR_HIP;
@@ -1522,7 +1532,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
     const WsLayout w = ws_layout(d.N, d.nx, Bp);
     Prof prof{h, stream};
-    HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
+    if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));      // (an asynchronous loop accumulates over its steps)
+    h->async_ok = false;
     if (d_obst) {
         P.per_inst_obst = 1;
         hipLaunchKernelGGL(k_transpose_obst, dim3((B + 255) / 256), dim3(256), 0, stream, d_obst, h->d_ws + w.OBST * 64, B, (uint32_t)w.tile_elems);
@@ -1700,6 +1711,15 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.begin(2, stream);
             hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_fail);
             prof.end(stream);
+            if (h->async_loop) {
+                // closed-loop driver: nothing comes back to the host per step -- a launch that had to be abandoned leaves its mark
+                // in the loop's sticky abort word, the bookkeeping kernels behind it then do nothing and the host replays the loop
+                hipLaunchKernelGGL(k_loop_sticky, dim3(1), dim3(1), 0, stream, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_fail + 1);
+                HIP_TRY(h, hipGetLastError());
+                h->async_ok = true;
+                h->last_mode = 1;
+                return MPC_OK;
+            }
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, hipStreamSynchronize(stream));
@@ -2027,16 +2047,16 @@ int mpc_plant_step(mpc_handle* h, int32_t B, int32_t integrator, const double* x
     return MPC_OK;
 }
 
-int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
-                              const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl, int32_t* d_step_status,
-                              void* stream_) {
+int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
+                                 const double* d_orient, const double* d_vdes, int32_t noise_mode, double sigma, uint64_t seed,
+                                 double* d_traj, double* d_ctrl, int32_t* d_step_status, void* stream_) {
     if (!h) return MPC_ERR_INVALID;
     const mpc_problem_desc& d = h->hp.desc;
-    if (d.nx != 5) { h->err = "the closed loop of optimizer.py:562-643 is defined for the 5-state CasADi formulation (nx = 5)"; return MPC_ERR_INVALID; }
     if (B <= 0 || L <= 0 || Lp < L || L < d.N || !d_init_state || !d_path || !d_orient || !d_vdes || !d_traj || !d_ctrl) {
         h->err = "closed loop: B > 0, L >= N, Lp >= L and all of init_state, path, orient, vdes, traj, ctrl are required";
         return MPC_ERR_INVALID;
     }
+    if (noise_mode < 0 || noise_mode > 2 || (noise_mode != 0 && !(sigma >= 0.0))) { h->err = "closed loop: noise_mode in {0, 1, 2}, sigma >= 0"; return MPC_ERR_INVALID; }
     if (!h->hp.bounds_set) { h->err = "mpc_set_bounds has not been called"; return MPC_ERR_STATE; }
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = ensure_io(h, (size_t)B);
@@ -2044,30 +2064,70 @@ int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, c
     if (h->cap_state < (size_t)B) {
         if (h->d_state) (void)hipFree(h->d_state);
         h->d_state = nullptr;
-        HIP_TRY(h, hipMalloc(&h->d_state, (size_t)B * 5 * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_state, (size_t)B * 6 * sizeof(double)));
         h->cap_state = (size_t)B;
     }
     hipStream_t stream = (hipStream_t)stream_;
     LoopArgs A{};
-    A.B = B; A.N = d.N; A.L = L; A.Lp = Lp;
+    A.B = B; A.N = d.N; A.L = L; A.Lp = Lp; A.nx = d.nx;
     A.init_state = d_init_state; A.path = d_path; A.orient = d_orient; A.vdes = d_vdes;
     A.state = h->d_state; A.x0 = h->d_x0; A.p = h->d_p; A.x_out = h->d_xout; A.status = h->d_status;
     A.traj = d_traj; A.ctrl = d_ctrl; A.step_status = d_step_status;
+    A.noise_mode = noise_mode; A.sigma = sigma; A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
     Params P{};
-    P.dt = d.dt; P.wheelbase = d.wheelbase; P.nx = 5;
+    P.dt = d.dt; P.wheelbase = d.wheelbase; P.nx = d.nx;
     const dim3 grid((B + 127) / 128), block(128);
-    hipLaunchKernelGGL(k_loop_setup, grid, block, 0, stream, A);
-    for (int i = 0; i < L; ++i) {
-        rc = solve_dev(h, B, h->d_x0, h->d_p, nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, stream, nullptr, 0, nullptr);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_loop_advance, dim3(B), dim3(128), 0, stream, P, A, i);
+    // First attempt: the whole loop enqueued without a single host synchronisation (every solve in the persistent pipeline
+    // launch, which needs no convergence poll).  What could go wrong on the way -- a pipeline launch abandoned, an instance
+    // that needs the second chance -- is recorded on the device and looked at ONCE, at the end; then the loop is replayed
+    // step by step with the host in between (the per-kernel path polls for convergence, the second chance needs the count).
+    bool replay = true;
+    if (d.fixed_iters <= 0 && h->knobs.pipeline && !h->pipe_disabled && h->knobs.loop_async) {
+        HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 2 * sizeof(uint32_t), stream));
+        A.abort_flag = h->d_fail + 1;
+        hipLaunchKernelGGL(k_loop_setup, grid, block, 0, stream, A);
+        h->async_loop = true;
+        bool all_async = true;
+        for (int i = 0; i < L && all_async; ++i) {
+            rc = solve_dev_any(h, B, h->d_x0, h->d_p, nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, stream, nullptr, 0, nullptr);
+            if (rc) { h->async_loop = false; return rc; }
+            all_async = h->async_ok;             // (a batch shape the pipeline does not take: the solve has run synchronously -- start over)
+            if (all_async) hipLaunchKernelGGL(k_loop_advance, dim3(B), dim3(128), 0, stream, P, A, i);
+        }
+        h->async_loop = false;
+        if (all_async) {
+            HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(h, hipStreamSynchronize(stream));
+            replay = h->h_fail[0] != 0u || h->h_fail[1] != 0u;
+            if (h->h_fail[1] != 0u) {
+                h->pipe_disabled = true;
+                fprintf(stderr, "[mpcgpu] closed loop: a pipeline launch was abandoned (bounded wait expired); replaying the loop with one launch per kernel\n");
+            }
+        }
+    }
+    h->loop_replayed = replay ? 1 : 0;
+    if (replay) {
+        A.abort_flag = nullptr;
+        hipLaunchKernelGGL(k_loop_setup, grid, block, 0, stream, A);
+        for (int i = 0; i < L; ++i) {
+            rc = solve_dev(h, B, h->d_x0, h->d_p, nullptr, h->d_xout, h->d_status, h->d_iters, h->d_kkt, stream, nullptr, 0, nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_loop_advance, dim3(B), dim3(128), 0, stream, P, A, i);
+        }
     }
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
 }
 
-int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
-                          const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status) {
+int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
+                              const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl, int32_t* d_step_status,
+                              void* stream_) {
+    return mpc_closed_loop_batch_dev_ex(h, B, L, Lp, d_init_state, d_path, d_orient, d_vdes, 0, 0.0, 0, d_traj, d_ctrl, d_step_status, stream_);
+}
+
+int mpc_closed_loop_batch_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
+                             const double* orient, const double* vdes, int32_t noise_mode, double sigma, uint64_t seed, double* traj,
+                             double* ctrl, int32_t* step_status) {
     if (!h) return MPC_ERR_INVALID;
     if (B <= 0 || L <= 0 || Lp <= 0 || !init_state || !path || !orient || !vdes || !traj || !ctrl) { h->err = "closed loop: null or empty argument"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
@@ -2089,7 +2149,7 @@ int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const
         h->err = "closed loop: host to device copy failed";
         rc = MPC_ERR_HIP;
     }
-    if (!rc) rc = mpc_closed_loop_batch_dev(h, B, L, Lp, di, dp, dor, dv, dt_, dc, ds, (void*)s);
+    if (!rc) rc = mpc_closed_loop_batch_dev_ex(h, B, L, Lp, di, dp, dor, dv, noise_mode, sigma, seed, dt_, dc, ds, (void*)s);
     if (!rc) {
         if (hipMemcpyAsync(traj, dt_, nB * L * 5 * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(ctrl, dc, nB * L * 2 * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
             (step_status && hipMemcpyAsync(step_status, ds, nB * L * 4, hipMemcpyDeviceToHost, s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess) {
@@ -2100,6 +2160,12 @@ int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const
     cleanup();
     return rc;
 }
+
+int mpc_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* path,
+                          const double* orient, const double* vdes, double* traj, double* ctrl, int32_t* step_status) {
+    return mpc_closed_loop_batch_ex(h, B, L, Lp, init_state, path, orient, vdes, 0, 0.0, 0, traj, ctrl, step_status);
+}
+int mpc_last_loop_replayed(const mpc_handle* h) { return h ? h->loop_replayed : MPC_ERR_INVALID; }
 
 int mpc_metrics_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* d_traj, const double* d_ref_path, const double* d_origin_path,
                           double r_sum, int32_t all_pairs, double* d_deviation, double* d_rmsd, double* d_clearance, void* stream_) {

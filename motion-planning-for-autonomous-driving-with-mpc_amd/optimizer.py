@@ -26,6 +26,7 @@ import types
 
 import numpy as np
 
+from . import noise as _noise
 from .solver import BatchedMPCSolver, rescue_failed
 
 # ------------------------------------------------------------------------------------------------------------
@@ -249,13 +250,19 @@ class CasadiOptimizer(Optimizer):
         lbg, ubg, lbx, ubx = self.inequal_constraints()
         sol, _ = self.solver()
         backend = getattr(sol, "_backend", None)
-        if self.use_device_loop and not self.configuration.noised and hasattr(backend, "closed_loop"):
-            # the whole loop of optimizer.py:596-631 on the device (mpc_closed_loop_batch): no host round trip per step
+        noised = bool(self.configuration.noised)
+        sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05          # optimizer.py:612-615
+        # `noise_seed` (not in the reference, whose draws are unseeded and therefore not reproducible): with it the samples come
+        # from the counter-based generator of noise.py / csrc/mpc_closed_loop.h and the loop can run on the device
+        seed = getattr(self.configuration, "noise_seed", None)
+        if self.use_device_loop and hasattr(backend, "closed_loop") and (not noised or seed is not None):
+            # the whole loop of optimizer.py:596-631 on the device (mpc_closed_loop_batch_ex): no host round trip per step
             t_ = time.time()
             backend.set_bounds(lbx, ubx, lbg, ubg)
             init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation])
             traj, ctrl, st = backend.closed_loop(init_state, self.resampled_path_points, self.orientation, self.desired_velocity,
-                                                 self.iter_length)
+                                                 self.iter_length, noise_mode=1 if noised else 0, sigma=sigma if noised else 0.0,
+                                                 seed=0 if seed is None else int(seed))
             ok = bool(np.all(st == 1))
             sol._stats = dict(status=st[0].copy(), success=ok, return_status="Solve_Succeeded" if ok else "Not_Converged")
             return traj[0], ctrl[0], np.full(self.iter_length, (time.time() - t_) / self.iter_length)
@@ -277,10 +284,12 @@ class CasadiOptimizer(Optimizer):
             index_t.append(time.time() - t_)
             estimated_opt = res["x"].full()
             u0 = estimated_opt[:int(num_controls * N)].reshape(N, num_controls).T
-            if self.configuration.noised:
+            if noised:
                 # optimizer.py:611-615 draws 20 samples (N = 10); generalised to 2 N samples for other horizons
-                sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05
-                u0 = u0 + np.random.normal(0, sigma, 2 * N).reshape(num_controls, N)
+                if seed is None:
+                    u0 = u0 + np.random.normal(0, sigma, 2 * N).reshape(num_controls, N)
+                else:
+                    u0 = u0 + _noise.sequence_noise(int(seed), 0, i, N, sigma)
             x_m = estimated_opt[int(num_controls * N):].reshape(N + 1, num_states).T
             u_c.append(u0[:, 0])
             t0, current_state, u0, next_states = self.shift_movement(t0, current_state, u0, x_m, f)
@@ -465,7 +474,9 @@ class ForcesproOptimizer(Optimizer):
                 u[:, k] = pred_u[:, 0]
             else:
                 sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05
-                u[:, k] = pred_u[:, 0] + np.random.normal(np.array([0, 0]), np.array([sigma, sigma]), (2,))
+                seed = getattr(self.configuration, "noise_seed", None)
+                u[:, k] = pred_u[:, 0] + (np.random.normal(np.array([0, 0]), np.array([sigma, sigma]), (2,)) if seed is None
+                                          else _noise.applied_noise(int(seed), 0, k, sigma))
             x[:, k + 1] = np.transpose(model.eq(np.concatenate((u[:, k], x[:, k]))))
             solve_time[k] = info.solvetime
         x = np.delete(x, -1, axis=1)

@@ -173,10 +173,11 @@ class BatchedMPCSolver:
                                              _abi.as_dp(out)))
         return out[0] if single else out
 
-    def closed_loop(self, init_state, path, orient, vdes, steps):
-        """B egos through `steps` receding-horizon steps on the device (include/mpcgpu.h: mpc_closed_loop_batch; the loop
+    def closed_loop(self, init_state, path, orient, vdes, steps, noise_mode=0, sigma=0.0, seed=0):
+        """B egos through `steps` receding-horizon steps on the device (include/mpcgpu.h: mpc_closed_loop_batch_ex; the loop
         body of CasadiOptimizer.optimize, optimizer.py:596-631).  init_state [B,5], path [B,Lp,2], orient [B,Lp],
-        vdes [B] -> (traj [B,steps,5], ctrl [B,steps,2], step_status [B,steps])."""
+        vdes [B] -> (traj [B,steps,5], ctrl [B,steps,2], step_status [B,steps]).  noise_mode / sigma / seed: the reference's
+        `noised: True` with a counter-based generator (noise.py holds the Python mirror of the samples)."""
         init_state = _abi.f64(init_state)
         if init_state.ndim == 1:
             init_state = init_state[None]
@@ -189,9 +190,21 @@ class BatchedMPCSolver:
         traj = np.empty((B, steps, 5))
         ctrl = np.empty((B, steps, 2))
         st = np.empty((B, steps), np.int32)
-        self._check(self._lib.mpc_closed_loop_batch(self._h, B, steps, Lp, _abi.as_dp(init_state), _abi.as_dp(path), _abi.as_dp(orient),
-                                                    _abi.as_dp(vdes), _abi.as_dp(traj), _abi.as_dp(ctrl), _abi.as_ip(st)))
+        self._check(self._lib.mpc_closed_loop_batch_ex(self._h, B, steps, Lp, _abi.as_dp(init_state), _abi.as_dp(path), _abi.as_dp(orient),
+                                                       _abi.as_dp(vdes), int(noise_mode), float(sigma), int(seed) & (2 ** 64 - 1), _abi.as_dp(traj),
+                                                       _abi.as_dp(ctrl), _abi.as_ip(st)))
         return traj, ctrl, st
+
+    def closed_loop_device(self, B, d_init_state, d_path, d_orient, d_vdes, steps, Lp, d_traj, d_ctrl, d_step_status=0, noise_mode=0, sigma=0.0,
+                           seed=0, stream=0):
+        """device-pointer form (ints): the whole loop is enqueued on `stream`; see mpc_closed_loop_batch_dev_ex"""
+        vp = C.c_void_p
+        self._check(self._lib.mpc_closed_loop_batch_dev_ex(self._h, int(B), int(steps), int(Lp), vp(d_init_state), vp(d_path), vp(d_orient), vp(d_vdes),
+                                                           int(noise_mode), float(sigma), int(seed) & (2 ** 64 - 1), vp(d_traj), vp(d_ctrl),
+                                                           vp(d_step_status or None), vp(stream or None)))
+
+    def last_loop_replayed(self):
+        return bool(self._lib.mpc_last_loop_replayed(self._h))
 
     def metrics(self, traj, ref_path=None, origin_path=None, r_sum=None, all_pairs=False):
         """Post-hoc metrics of B planned trajectories [B,L,5] on the device (mpc_metrics_batch; mpc_planner.py:184-199,

@@ -147,13 +147,14 @@ extern "C" void emu_default_desc(mpc_problem_desc* d, int32_t N, int32_t nx) { d
 extern "C" int emu_closed_loop_piece(int32_t mode, int32_t i, double dt, double wheelbase, int32_t B, int32_t N, int32_t L, int32_t Lp,
                                      const double* init_state, const double* path, const double* orient, const double* vdes,
                                      double* state, double* x0, double* p, const double* x_out, const int32_t* status,
-                                     double* traj, double* ctrl, int32_t* step_status) {
+                                     double* traj, double* ctrl, int32_t* step_status, int32_t nx, int32_t noise_mode, double sigma, uint64_t seed) {
     LoopArgs A{};
     A.B = B; A.N = N; A.L = L; A.Lp = Lp;
+    A.nx = nx; A.noise_mode = noise_mode; A.sigma = sigma; A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
     A.init_state = init_state; A.path = path; A.orient = orient; A.vdes = vdes;
     A.state = state; A.x0 = x0; A.p = p; A.x_out = x_out; A.status = status; A.traj = traj; A.ctrl = ctrl; A.step_status = step_status;
     Params P{};
-    P.dt = dt; P.wheelbase = wheelbase; P.nx = 5;
+    P.dt = dt; P.wheelbase = wheelbase; P.nx = nx;
     for (int b = 0; b < B; ++b) {
         if (mode == 0) loop_setup_instance(A, b);
         else loop_advance_instance(P, A, b, i);
