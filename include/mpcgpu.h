@@ -27,6 +27,7 @@
  *                                     FORCES-mode stage cost / RK4 dynamics / inequalities with their derivatives.
  *   mpc_forces_solve_batch .......... `output, exitflag, info = solver.solve(problem)` of ForcesproOptimizer (optimizer.py:326).
  *   mpc_metrics_batch ............... deviation.txt / RMSD.txt of MPCPlanner (mpc_planner.py:184-199, 279-292), circle clearance.
+ *   mpc_validity_batch .............. the collision / road-boundary verdict of test/test_mpc_planner.py:37-47.
  *
  * Conventions (modelled on FORCESNLPsolver.h:117-203): caller-owned plain buffers, int return codes, no
  * exceptions, no callbacks, no globals; the library never keeps a host pointer past the call.
@@ -186,6 +187,19 @@ int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const dou
 int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const double* traj, const double* ref_path,
                       const double* origin_path, double r_sum, int32_t all_pairs, double* deviation, double* rmsd,
                       double* clearance);
+/* Collision / road verdict of B planned trajectories traj [B,L,5] (scope row f4): what the reference's test asks of
+ * commonroad_dc's collision checker (test/test_mpc_planner.py:37-47) -- does the ego rectangle (mpc_planner.py:99: length 4.3,
+ * width 1.8, centred on the planned position, heading psi) of some step overlap an obstacle rectangle of the same time step, or
+ * leave the drivable corridor?  obst [n_obst,L,5] = (x, y, length, width, orientation) per obstacle and time step (a static
+ * obstacle repeats its row; length <= 0 = absent at that step), or n_obst = 0.  left [n_left,2] / right [n_right,2]: boundary
+ * polylines of the corridor in driving direction (0 points = no road check).  Outputs [B]: index of the first offending step,
+ * -1 = none.                                                                                                              */
+int mpc_validity_batch(mpc_handle* h, int32_t B, int32_t L, const double* traj, double ego_length, double ego_width, int32_t n_obst,
+                       const double* obst, int32_t n_left, const double* left, int32_t n_right, const double* right,
+                       int32_t* first_collision, int32_t* first_off_road);
+int mpc_validity_batch_dev(mpc_handle* h, int32_t B, int32_t L, const double* d_traj, double ego_length, double ego_width, int32_t n_obst,
+                           const double* d_obst, int32_t n_left, const double* d_left, int32_t n_right, const double* d_right,
+                           int32_t* d_first_collision, int32_t* d_first_off_road, void* stream);
 int mpc_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_path,
                               const double* d_orient, const double* d_vdes, double* d_traj, double* d_ctrl,
                               int32_t* d_step_status, void* stream);

@@ -855,6 +855,71 @@ __global__ void __launch_bounds__(256) k_metrics(int L, int Lo, const double* tr
     }
 }
 
+// collision / road verdict of planned trajectories (row f4; what test/test_mpc_planner.py:37-47 asks of commonroad_dc's collision
+// checker): the ego rectangle (mpc_planner.py:99: 4.3 x 1.8 m, centred on the planned position, heading psi) of every step
+// against the obstacle rectangles of the same time step (separating-axis test of two oriented rectangles) and against the
+// drivable corridor (every corner right of the left boundary polyline and left of the right one, judged at the nearest
+// segment).  One workgroup per trajectory, threads over the steps; first offending step by atomicMin.
+__device__ __forceinline__ double seg_side(const double* poly, int n, double px, double py) {
+    // signed side of (px, py) w.r.t. the nearest segment of the polyline: > 0 left of it, < 0 right of it
+    double best = INFINITY, side = 0.0;
+    for (int q = 0; q + 1 < n; ++q) {
+        const double ax = poly[2 * q], ay = poly[2 * q + 1], bx = poly[2 * q + 2], by = poly[2 * q + 3];
+        const double ex = bx - ax, ey = by - ay, l2 = ex * ex + ey * ey;
+        double t = l2 > 0.0 ? ((px - ax) * ex + (py - ay) * ey) / l2 : 0.0;
+        t = fmin(1.0, fmax(0.0, t));
+        const double dx = px - (ax + t * ex), dy = py - (ay + t * ey), d2 = dx * dx + dy * dy;
+        if (d2 < best) { best = d2; side = ex * (py - ay) - ey * (px - ax); }
+    }
+    return side;
+}
+__global__ void __launch_bounds__(128) k_validity(int L, const double* traj, double ego_l, double ego_w, int n_obst, const double* obst, int n_left,
+                                                  const double* left, int n_right, const double* right, int32_t* first_collision,
+                                                  int32_t* first_off_road) {
+#pragma clang fp contract(off)
+    __shared__ int s_col, s_off;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t == 0) { s_col = 0x7fffffff; s_off = 0x7fffffff; }
+    __syncthreads();
+    const double* x = traj + (size_t)b * L * 5;
+    for (int i = t; i < L; i += 128) {
+        const double cx = x[i * 5], cy = x[i * 5 + 1], psi = x[i * 5 + 4];
+        double sn, cs;
+        sincos(psi, &sn, &cs);
+        const double hl = 0.5 * ego_l, hw = 0.5 * ego_w;
+        bool col = false, off = false;
+        for (int o = 0; o < n_obst && !col; ++o) {
+            const double* r = obst + ((size_t)o * L + i) * 5;
+            if (!(r[2] > 0.0) || !(r[3] > 0.0)) continue;                  // absent at this time step
+            double so, co;
+            sincos(r[4], &so, &co);
+            const double ol = 0.5 * r[2], ow = 0.5 * r[3], dx = r[0] - cx, dy = r[1] - cy;
+            // axes: ego (cs, sn), (-sn, cs); obstacle (co, so), (-so, co)
+            const double c00 = fabs(cs * co + sn * so), c01 = fabs(-cs * so + sn * co);       // |ego axis . obstacle axis|
+            bool sep = fabs(dx * cs + dy * sn) > hl + ol * c00 + ow * c01;
+            sep = sep || fabs(-dx * sn + dy * cs) > hw + ol * c01 + ow * c00;
+            sep = sep || fabs(dx * co + dy * so) > ol + hl * c00 + hw * c01;
+            sep = sep || fabs(-dx * so + dy * co) > ow + hl * c01 + hw * c00;
+            col = !sep;
+        }
+        if (n_left > 1 || n_right > 1) {
+            for (int q = 0; q < 4 && !off; ++q) {
+                const double sl = (q & 1) ? -hl : hl, sw = (q & 2) ? -hw : hw;
+                const double px = cx + sl * cs - sw * sn, py = cy + sl * sn + sw * cs;
+                if (n_left > 1 && seg_side(left, n_left, px, py) > 0.0) off = true;
+                if (n_right > 1 && seg_side(right, n_right, px, py) < 0.0) off = true;
+            }
+        }
+        if (col) atomicMin(&s_col, i);
+        if (off) atomicMin(&s_off, i);
+    }
+    __syncthreads();
+    if (t == 0) {
+        first_collision[b] = s_col == 0x7fffffff ? -1 : s_col;
+        first_off_road[b] = s_off == 0x7fffffff ? -1 : s_off;
+    }
+}
+
 // FORCES-mode stage functions (row a11; FORCESNLPsolver_interface.c:41-198 / FORCESNLPsolver_model.c:75-1756, the model of
 // optimizer.py:91-245): per instance  z = [deltaDot, aLong, x, y, delta, v, psi],  p = [x_ref, y_ref, v_des, psi_ref, 3 obstacle
 // circle centres]  ->  stage cost f and gradient (7), one RK4 step c (5) with Jacobian (5x7, forward sensitivities through
@@ -2206,6 +2271,49 @@ int mpc_metrics_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lo, const dou
     if (deviation) HIP_TRY(h, hipMemcpyAsync(deviation, ddev, nB * L * 8, hipMemcpyDeviceToHost, s));
     if (rmsd) HIP_TRY(h, hipMemcpyAsync(rmsd, drm, nB * 2 * 8, hipMemcpyDeviceToHost, s));
     if (clearance) HIP_TRY(h, hipMemcpyAsync(clearance, dcl, nB * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MPC_OK;
+}
+
+int mpc_validity_batch_dev(mpc_handle* h, int32_t B, int32_t L, const double* d_traj, double ego_length, double ego_width, int32_t n_obst,
+                           const double* d_obst, int32_t n_left, const double* d_left, int32_t n_right, const double* d_right,
+                           int32_t* d_first_collision, int32_t* d_first_off_road, void* stream_) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L <= 0 || !d_traj || !d_first_collision || !d_first_off_road || n_obst < 0 || (n_obst > 0 && !d_obst) ||
+        (n_left > 0 && !d_left) || (n_right > 0 && !d_right) || !(ego_length > 0.0) || !(ego_width > 0.0)) {
+        h->err = "validity: B, L > 0, traj, both outputs and consistent obstacle / boundary arguments are required";
+        return MPC_ERR_INVALID;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_validity, dim3(B), dim3(128), 0, (hipStream_t)stream_, L, d_traj, ego_length, ego_width, n_obst, d_obst, n_left, d_left, n_right,
+                       d_right, d_first_collision, d_first_off_road);
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_validity_batch(mpc_handle* h, int32_t B, int32_t L, const double* traj, double ego_length, double ego_width, int32_t n_obst,
+                       const double* obst, int32_t n_left, const double* left, int32_t n_right, const double* right,
+                       int32_t* first_collision, int32_t* first_off_road) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L <= 0 || !traj || !first_collision || !first_off_road) { h->err = "validity: B, L > 0, traj and both outputs are required"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = h->own_stream;
+    const size_t nB = (size_t)B;
+    double* dt_ = static_cast<double*>(scratch_get(h, 4, nB * L * 5 * 8));
+    double* dob = n_obst > 0 ? static_cast<double*>(scratch_get(h, 5, (size_t)n_obst * L * 5 * 8)) : nullptr;
+    double* dl = n_left > 0 ? static_cast<double*>(scratch_get(h, 6, (size_t)n_left * 2 * 8)) : nullptr;
+    double* dr = n_right > 0 ? static_cast<double*>(scratch_get(h, 7, (size_t)n_right * 2 * 8)) : nullptr;
+    int32_t* dc = static_cast<int32_t*>(scratch_get(h, 11, nB * 4));
+    int32_t* dor = static_cast<int32_t*>(scratch_get(h, 12, nB * 4));
+    if (!dt_ || (n_obst > 0 && !dob) || (n_left > 0 && !dl) || (n_right > 0 && !dr) || !dc || !dor) { h->err = "validity: out of device memory"; return MPC_ERR_HIP; }
+    HIP_TRY(h, hipMemcpyAsync(dt_, traj, nB * L * 5 * 8, hipMemcpyHostToDevice, s));
+    if (n_obst > 0) HIP_TRY(h, hipMemcpyAsync(dob, obst, (size_t)n_obst * L * 5 * 8, hipMemcpyHostToDevice, s));
+    if (n_left > 0) HIP_TRY(h, hipMemcpyAsync(dl, left, (size_t)n_left * 2 * 8, hipMemcpyHostToDevice, s));
+    if (n_right > 0) HIP_TRY(h, hipMemcpyAsync(dr, right, (size_t)n_right * 2 * 8, hipMemcpyHostToDevice, s));
+    const int rc = mpc_validity_batch_dev(h, B, L, dt_, ego_length, ego_width, n_obst, dob, n_left, dl, n_right, dr, dc, dor, (void*)s);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(first_collision, dc, nB * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(first_off_road, dor, nB * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return MPC_OK;
 }

@@ -32,4 +32,17 @@ def min_clearance(solver: BatchedMPCSolver, x, r_sum, all_pairs=False):
     return out[0] if x.ndim == 2 else out
 
 
-__all__ = ["deviation_euclidean_dis", "compute_rmsd", "min_clearance"]
+def collision_verdict(solver: BatchedMPCSolver, x, obstacles=None, left_boundary=None, right_boundary=None, ego_length=4.3, ego_width=1.8):
+    """what test/test_mpc_planner.py:37-47 prints -- does the ego vehicle (mpc_planner.py:99: a 4.3 x 1.8 m rectangle on the planned
+    states) collide with an obstacle of the scenario or with the road boundary? -- for one trajectory (L,5) or a batch (B,L,5).
+    Returns (collides, first_collision_step, leaves_road, first_off_road_step); scenario.obstacle_rectangles / road_corridor build
+    the obstacle rows and boundary polylines from a scenario."""
+    x = np.asarray(x, dtype=np.float64)
+    r = solver.validity(x, obstacles=obstacles, left=left_boundary, right=right_boundary, ego_length=ego_length, ego_width=ego_width)
+    fc, fo = r["first_collision"], r["first_off_road"]
+    if x.ndim == 2:
+        return bool(fc[0] >= 0), int(fc[0]), bool(fo[0] >= 0), int(fo[0])
+    return fc >= 0, fc, fo >= 0, fo
+
+
+__all__ = ["deviation_euclidean_dis", "compute_rmsd", "min_clearance", "collision_verdict"]

@@ -19,13 +19,20 @@ What is restated from where (file:line of /root/reference, or the third-party fu
   * `chaikins_corner_cutting`, `resample_polyline`, `compute_polyline_length`, `compute_orientation_from_polyline`:
     commonroad_dc.geometry.util -- source not in the tree; restated from the library's documented behaviour
   * route: commonroad_route_planner `RoutePlanner(...).plan_routes().retrieve_first_route().reference_path` -- source not
-    in the tree; restated as the centre line through the lanelet sequence start -> goal (breadth-first over successors)
+    in the tree; restated from the library's published behaviour (plan_route below): lanelet sequence start -> first goal
+    lanelet over successor AND same-direction adjacent lanelets (lane changes), reference path from portions of the centre
+    lines (a run of lane changes shares its stretch equally), a few vertices dropped around every hand-over, 2 m
+    resampling, one Chaikin refinement
   * `parameters_vehicle2` (commonroad-vehicle-models): only the fields optimizer.py:34-46 reads
 
 PARITY: unpinned against the third-party pieces (versions unknown).  What can be checked is checked in
-tests/test_scenario.py: for ZAM_Over-1_1 the pipeline reproduces the recorded run's length (30 steps) and the recorded
-RMSD.txt from the recorded `planned states.txt` to 0.2 % (the residual is the route planner's own smoothing of the
-centre line, which is not recorded anywhere in the reference).
+tests/test_scenario.py against the reference's recorded runs: for ZAM_Over-1_1 (one lanelet) the pipeline reproduces the run
+length (30 steps) and the recorded RMSD.txt from the recorded `planned states.txt` to 0.2 %; for USA_Lanker-2_18_T-1 (route
+3672 -> 3452 -> lane changes over 3454 to 3456) the run length (70 steps), the first state and the recorded RMSD to +12 % / +5 %
+(x / y) -- that figure moves by 50 ... 200 % when the lane-change construction is altered (portions, dropped vertices,
+resampling step), so the recorded run does discriminate; the residual is the noise of the recorded run and whatever the
+library version of 2021 did differently in detail.  ZAM_Tutorial-1_2_T-1 carries a planning problem WITHOUT a goal: the
+reference's Configuration cannot plan it either (configuration.py:529 reads goal.state_list[0]); it raises here.
 """
 from __future__ import annotations
 
@@ -121,13 +128,35 @@ def read_scenario(path):
     """lanelets, static obstacles and planning problems of a CommonRoad XML file (commonroad.common.file_reader subset)."""
     root = ET.parse(path).getroot()
     sc = SimpleNamespace(scenario_id=root.attrib.get("benchmarkID", ""), dt=float(root.attrib.get("timeStepSize", 0.1)),
-                         lanelets={}, obstacles=[], planning_problems={})
+                         lanelets={}, obstacles=[], dynamic_obstacles=[], planning_problems={})
     for l in root.findall("lanelet"):
         left, right = _points(l.find("leftBound")), _points(l.find("rightBound"))
         sc.lanelets[int(l.attrib["id"])] = SimpleNamespace(
             lanelet_id=int(l.attrib["id"]), left_vertices=left, right_vertices=right, center_vertices=0.5 * (left + right),
             successor=[int(s.attrib["ref"]) for s in l.findall("successor")],
-            predecessor=[int(s.attrib["ref"]) for s in l.findall("predecessor")])
+            predecessor=[int(s.attrib["ref"]) for s in l.findall("predecessor")],
+            adj_same=[int(a.attrib["ref"]) for a in (l.find("adjacentLeft"), l.find("adjacentRight"))
+                      if a is not None and a.attrib.get("drivingDir") == "same"],
+            adj_left=(int(l.find("adjacentLeft").attrib["ref"]) if l.find("adjacentLeft") is not None
+                      and l.find("adjacentLeft").attrib.get("drivingDir") == "same" else None),
+            adj_right=(int(l.find("adjacentRight").attrib["ref"]) if l.find("adjacentRight") is not None
+                       and l.find("adjacentRight").attrib.get("drivingDir") == "same" else None),
+            adj_left_opposite=(int(l.find("adjacentLeft").attrib["ref"]) if l.find("adjacentLeft") is not None
+                               and l.find("adjacentLeft").attrib.get("drivingDir") == "opposite" else None))
+    for tag in ("obstacle", "dynamicObstacle"):
+        for o in root.findall(tag):                     # moving obstacles: rectangle + one (x, y, orientation) per time step
+            role = o.find("role")
+            if tag == "obstacle" and (role is None or role.text != "dynamic"):
+                continue
+            rect, ini, trj = o.find("shape/rectangle"), o.find("initialState"), o.find("trajectory")
+            if rect is None or ini is None:
+                continue
+            states = {}
+            for st in [ini] + (list(trj.findall("state")) if trj is not None else []):
+                tt = int(round(_value(st.find("time"))))
+                states[tt] = (float(st.find("position/point/x").text), float(st.find("position/point/y").text), _value(st.find("orientation")))
+            sc.dynamic_obstacles.append(SimpleNamespace(obstacle_id=int(o.attrib["id"]), length=float(rect.find("length").text),
+                                                        width=float(rect.find("width").text), states=states))
     for tag in ("obstacle", "staticObstacle"):
         for o in root.findall(tag):
             role = o.find("role")
@@ -144,7 +173,7 @@ def read_scenario(path):
     for pp in root.findall("planningProblem"):
         ini = pp.find("initialState")
         goal = pp.find("goalState")
-        gpos = goal.find("position")
+        gpos = goal.find("position") if goal is not None else None
         center, goal_lanelets = None, []
         if gpos is not None:
             for shape in ("rectangle", "circle"):
@@ -152,9 +181,11 @@ def read_scenario(path):
                 if c is not None:
                     center = np.array([float(c.find("x").text), float(c.find("y").text)])
             goal_lanelets = [int(g.attrib["ref"]) for g in gpos.findall("lanelet")]
-        t = goal.find("time")
-        t_exact = t.find("exact")
-        time_end = int(float(t_exact.text)) if t_exact is not None else int(float(t.find("intervalEnd").text))
+        time_end = None
+        if goal is not None:
+            t = goal.find("time")
+            t_exact = t.find("exact")
+            time_end = int(float(t_exact.text)) if t_exact is not None else int(float(t.find("intervalEnd").text))
         sc.planning_problems[int(pp.attrib["id"])] = SimpleNamespace(
             planning_problem_id=int(pp.attrib["id"]),
             initial_position=np.array([float(ini.find("position/point/x").text), float(ini.find("position/point/y").text)]),
@@ -176,12 +207,19 @@ def _lanelet_of_point(lanelets, pt):
     return best
 
 
-def plan_route(scenario, planning_problem):
-    """returns (reference_path ndarray(n,2), list of lanelet ids)"""
+def plan_route(scenario, planning_problem, step_resample=1.0, num_vertices_lane_change_max=6, percentage_vertices_lane_change_max=0.1):
+    """returns (reference_path ndarray(n,2), list of lanelet ids).
+
+    Lanelet sequence: breadth-first from the lanelet of the initial position to the FIRST goal lanelet of the planning problem
+    (the reference takes `retrieve_first_route()`), moving to successors and to adjacent lanelets of the same driving direction
+    (a lane change).  Reference path, as the route planner builds it: every lanelet contributes the portion [a, b] of its centre
+    line (resampled to `step_resample`) -- [0, 1] normally, while the m lanelets of a run of lane changes share the stretch,
+    [q/m, (q+1)/m] -- minus a few vertices on either side of every hand-over, so that the change of lane becomes a diagonal
+    instead of a jump; then 2 m resampling and one Chaikin refinement."""
     lan = scenario.lanelets
     start = _lanelet_of_point(lan, planning_problem.initial_position)
     if planning_problem.goal_lanelets:
-        goals = set(planning_problem.goal_lanelets)
+        goals = {planning_problem.goal_lanelets[0]}
     elif planning_problem.goal_center is not None:
         goals = {_lanelet_of_point(lan, planning_problem.goal_center)}
     else:
@@ -191,25 +229,50 @@ def plan_route(scenario, planning_problem):
     hit = start if (start in goals or not goals) else None
     while queue and hit is None:
         cur = queue.popleft()
-        for s in lan[cur].successor:
+        for s in list(lan[cur].successor) + list(getattr(lan[cur], "adj_same", [])):
             if s in lan and s not in prev:
                 prev[s] = cur
                 if s in goals:
                     hit = s
                     break
                 queue.append(s)
-    if hit is None:                       # goal not reachable through successors: stay on the start lanelet
+    if hit is None:                       # goal not reachable: stay on the start lanelet
         hit = start
     ids = []
     while hit is not None:
         ids.append(hit)
         hit = prev[hit]
     ids.reverse()
-    pts = [lan[ids[0]].center_vertices]
-    for lid in ids[1:]:
-        c = lan[lid].center_vertices
-        pts.append(c[1:] if np.allclose(c[0], pts[-1][-1]) else c)
-    return np.concatenate(pts, axis=0), ids
+    n = len(ids)
+    change = [1 if (i + 1 < n and ids[i + 1] in getattr(lan[ids[i]], "adj_same", [])) else 0 for i in range(n)]
+    portions, i = [], 0
+    while i < n:
+        if not change[i]:
+            portions.append((0.0, 1.0))
+            i += 1
+            continue
+        j = i
+        while j < n and change[j]:
+            j += 1
+        m = j - i + 1                     # lanelets of this run of lane changes
+        portions += [(q / m, (q + 1) / m) for q in range(m)]
+        i = j + 1
+    path = None
+    for k, lid in enumerate(ids):
+        v = resample_polyline(lan[lid].center_vertices, step_resample)
+        nv = len(v)
+        n_lc = min(int(nv * percentage_vertices_lane_change_max) + 1, num_vertices_lane_change_max)
+        i0 = int(portions[k][0] * nv)
+        i1 = int(portions[k][1] * nv)
+        if path is None:
+            i1 = max(i1, 1)
+        else:
+            i0 = min(i0 + n_lc, nv - 1)
+        if k != n - 1:
+            i1 = max(i1 - n_lc, 1)
+        part = v[i0:i1]
+        path = part if path is None else np.concatenate((path, part), axis=0)
+    return chaikins_corner_cutting(resample_polyline(path, 2.0)), ids
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -254,6 +317,9 @@ class Configuration(object):
         """configuration.py:500-552"""
         pp = self.planning_problem
         vehicle_settings = self.settings["vehicle_settings"][pp.planning_problem_id]
+        if pp.goal_time_end is None:
+            raise ValueError("planning problem {} has no goal state: the desired velocity is defined by the goal's time limit "
+                             "(configuration.py:529-538), the reference cannot plan it either".format(pp.planning_problem_id))
         origin_reference_path, lanelets_leading_to_goal = plan_route(self.scenario, pp)
         goal_position = pp.goal_center if pp.goal_center is not None else origin_reference_path[-1]
         clipped = clip_reference_path(origin_reference_path, pp.initial_position, goal_position)
@@ -307,6 +373,51 @@ class Configuration(object):
         return c
 
 
+def obstacle_rectangles(scenario, steps):
+    """[n, steps, 5] rows (x, y, length, width, orientation) of every obstacle of the scenario at time steps 0 .. steps-1 -- the
+    input of mpc_validity_batch / metrics.collision_verdict.  Static obstacles repeat their row; a moving obstacle that does not
+    exist at a time step gets length = width = 0 there."""
+    rows = []
+    for o in scenario.obstacles:
+        rows.append(np.tile([o.position[0], o.position[1], o.length, o.width, o.orientation], (steps, 1)))
+    for o in scenario.dynamic_obstacles:
+        r = np.zeros((steps, 5))
+        for i in range(steps):
+            if i in o.states:
+                r[i] = [o.states[i][0], o.states[i][1], o.length, o.width, o.states[i][2]]
+        rows.append(r)
+    return np.array(rows) if rows else np.zeros((0, steps, 5))
+
+
+def road_corridor(scenario, lanelet_ids, include_oncoming=True):
+    """(left, right) boundary polylines, in driving direction, of the road along a lanelet sequence (a route): for every lanelet
+    of the sequence the RIGHT bound of its rightmost neighbour of the same driving direction and, on the other side, the LEFT
+    bound of its leftmost one -- or, with include_oncoming (what commonroad_dc's road boundary of the whole network amounts to
+    on a two-way road, and what configuration.py:432-433 picks for ZAM_Over-1_1), the far bound of the oncoming lanes next to
+    it.  Consecutive lanelets of one lane-change run share a cross-section and contribute it once."""
+    lan = scenario.lanelets
+    left, right, seen = [], [], set()
+    for lid in lanelet_ids:
+        lm = lid
+        while getattr(lan[lm], "adj_left", None) in lan:
+            lm = lan[lm].adj_left
+        rm = lid
+        while getattr(lan[rm], "adj_right", None) in lan:
+            rm = lan[rm].adj_right
+        if (lm, rm) in seen:
+            continue
+        seen.add((lm, rm))
+        left_pts = lan[lm].left_vertices
+        opp = getattr(lan[lm], "adj_left_opposite", None)
+        if include_oncoming and opp in lan:
+            while getattr(lan[opp], "adj_right", None) in lan:          # rightmost lane of the oncoming direction
+                opp = lan[opp].adj_right
+            left_pts = lan[opp].right_vertices[::-1]
+        for acc, pts in ((left, left_pts), (right, lan[rm].right_vertices)):
+            acc.append(pts if not acc or not np.allclose(acc[-1][-1], pts[0]) else pts[1:])
+    return np.concatenate(left, axis=0), np.concatenate(right, axis=0)
+
+
 def init_values(scenario, planning_problem_id=None):
     """(position, velocity, acceleration, orientation) as MPCPlanner hands them to the optimizers (mpc_planner.py:30-59)"""
     if planning_problem_id is None:
@@ -315,6 +426,6 @@ def init_values(scenario, planning_problem_id=None):
     return pp.initial_position, pp.initial_velocity, pp.initial_acceleration, pp.initial_orientation
 
 
-__all__ = ["read_scenario", "Configuration", "init_values", "plan_route", "clip_reference_path", "find_closest_point",
+__all__ = ["read_scenario", "Configuration", "init_values", "plan_route", "obstacle_rectangles", "road_corridor", "clip_reference_path", "find_closest_point",
            "chaikins_corner_cutting", "resample_polyline", "compute_polyline_length", "compute_orientation_from_polyline",
            "parameters_vehicle2"]

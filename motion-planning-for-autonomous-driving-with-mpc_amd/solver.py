@@ -229,6 +229,30 @@ class BatchedMPCSolver:
                                                 _abi.as_dp(cl)))
         return dict(deviation=dev, rmsd=rm, clearance=cl)
 
+    def validity(self, traj, obstacles=None, left=None, right=None, ego_length=4.3, ego_width=1.8):
+        """collision / road verdict of B planned trajectories [B,L,5] on the device (mpc_validity_batch; the check of the
+        reference's test, test/test_mpc_planner.py:37-47).  obstacles: [n,5] static rectangles (x, y, length, width, orientation)
+        or [n,L,5] per time step; left / right: boundary polylines [m,2] of the drivable corridor in driving direction.
+        Returns dict(first_collision [B], first_off_road [B]) -- step index or -1."""
+        traj = _abi.f64(traj)
+        if traj.ndim == 2:
+            traj = traj[None]
+        B, L = traj.shape[0], traj.shape[1]
+        n_obst, ob = 0, None
+        if obstacles is not None and len(obstacles):
+            ob = np.asarray(obstacles, dtype=np.float64)
+            if ob.ndim == 2:
+                ob = np.repeat(ob[:, None, :], L, axis=1)
+            ob = _abi.f64(ob[:, :L])
+            n_obst = ob.shape[0]
+        lf = None if left is None else _abi.f64(left).reshape(-1, 2)
+        rt = None if right is None else _abi.f64(right).reshape(-1, 2)
+        fc, fo = np.empty(B, np.int32), np.empty(B, np.int32)
+        self._check(self._lib.mpc_validity_batch(self._h, B, L, _abi.as_dp(traj), float(ego_length), float(ego_width), n_obst, _abi.as_dp(ob),
+                                                 0 if lf is None else lf.shape[0], _abi.as_dp(lf), 0 if rt is None else rt.shape[0], _abi.as_dp(rt),
+                                                 _abi.as_ip(fc), _abi.as_ip(fo)))
+        return dict(first_collision=fc, first_off_road=fo)
+
     def forces_stage_eval(self, z, p, terminal=False):
         """FORCES-mode stage functions of B (z, p) pairs on the device (mpc_forces_stage_eval; the generated
         FORCESNLPsolver_model.c of the reference): dict(f, grad_f, c, jac_c, h, jac_h); c / jac_c are None at the last stage."""
