@@ -1316,7 +1316,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1343,12 +1343,13 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pipe_timing") k.pipe_timing = on != 0;
     else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "pipe_xcd_mask"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "pipe_xcd_mask"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -1577,6 +1578,18 @@ struct Prof {
 };
 }  // namespace
 
+// the one synchronisation of a pipelined solve: polling the stream keeps the host thread on the core for the ~1 ms the launch lasts
+// and saves the wake-up latency of a blocking wait (tens of microseconds per solve); option "sync_spin" = 0 blocks instead
+static hipError_t wait_stream(mpc_handle* h, hipStream_t stream) {
+    if (h->knobs.sync_spin) {
+        for (int spins = 0; spins < 2000000; ++spins) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e != hipErrorNotReady) return e;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
 template <int NX>
 static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst,
                           double* d_x_out, int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream,
@@ -1597,7 +1610,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
     const WsLayout w = ws_layout(d.N, d.nx, Bp);
     Prof prof{h, stream};
-    if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));      // (an asynchronous loop accumulates over its steps)
     h->async_ok = false;
     if (d_obst) {
         P.per_inst_obst = 1;
@@ -1613,6 +1625,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const size_t lds_max = 160 * 1024 - 1024;          // the kernels also hold a few hundred bytes of static LDS
     const int stash_rows = small_wg && MPC_STAGE_STASH ? std::max(Stash<NX>::rows(has_ou), 2 * NX) : 2 * NX;
     const size_t lds_bytes = ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * threads) * sizeof(double);
+    // the start-iterate kernel parks nothing in LDS (no line search): with the small footprint several of its workgroups share a CU
+    // and the 512 of a 4096-instance batch run at once instead of in two rounds
+    const size_t lds_init = ((size_t)nw * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)2 * NX * threads) * sizeof(double);
     const int rblk = (int)(Bp / 64);
     const size_t ric_lds = std::max(RIC_DEPTH * (size_t)((MPC_EV(Dim<NX>::NBLK) * 512 + 1023) / 1024) * 1024,
                                     RIC_DEPTH_F * (size_t)((Dim<NX>::NKK * 512 + 1023) / 1024 + 6) * 1024) + 64;   // ring + flag
@@ -1661,10 +1676,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Pg.tile0 = q.tile0;
         if (!init && stage_timing && P.DBG) Pg.DBG = P.DBG;
         if (small_wg) {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_init, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
-            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_init, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
@@ -1711,14 +1726,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     P.tile_mask = h->d_tile_mask;
     const bool polled = d.fixed_iters <= 0 && !trace;
-    if (polled) {
-        if (cap > mpc_handle::MAX_POLL_IT) { h->err = "max_iter exceeds the poll table (1024)"; return MPC_ERR_INVALID; }
-        HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT, stream));
-        if (G > 1) {     // the sub-streams were forked before this memset was enqueued
-            HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
-            for (int g = 0; g < G; ++g) HIP_TRY(h, hipStreamWaitEvent(h->sub_stream[g], h->ev_fork, 0));
-        }
-    }
+    if (polled && cap > mpc_handle::MAX_POLL_IT) { h->err = "max_iter exceeds the poll table (1024)"; return MPC_ERR_INVALID; }
     int it = 0, chunk_id = 0;
     // ---- single-launch pipeline (k_pipeline): all iterations in one persistent grid, tiles cycling independently.
     // Pays while the Riccati chain is latency bound (few tiles per CU); larger batches keep one launch per kernel.
@@ -1774,7 +1782,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
             // synchronisation of the call is the last thing that happens
             prof.begin(2, stream);
-            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_fail);
+            // (instances that did not converge are counted into word 14 of the control block, which travels back with the abort word;
+            //  an asynchronous closed loop accumulates them over its steps in d_fail instead)
+            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT),
+                               h->async_loop ? h->d_fail : h->d_pipe + PIPE_ABORT + 14);
             prof.end(stream);
             if (h->async_loop) {
                 // closed-loop driver: nothing comes back to the host per step -- a launch that had to be abandoned leaves its mark
@@ -1786,8 +1797,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 return MPC_OK;
             }
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(h, hipStreamSynchronize(stream));
+            HIP_TRY(h, wait_stream(h, stream));
+            h->h_fail[0] = h->h_pipe[14];
             if (h->h_pipe[0] != 0u) {
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
                 // through an iteration, so start over with one launch per kernel -- and stay there for this handle
@@ -1827,6 +1838,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             h->pipe_prof[1] = 1; h->pipe_prof[2] = it;
             h->pipe_prof[3] = (double)st64[0] * 1e-5; h->pipe_prof[4] = (double)st64[1] * 1e-5; h->pipe_prof[5] = (double)st64[2] * 1e-5;   // 100 MHz ticks -> ms
             h->pipe_prof[6] = (double)st64[3]; h->pipe_prof[7] = (double)h->h_pipe[12] + 1e-3 * (double)h->h_pipe[13];
+        }
+    }
+    if (!piped) {
+        // one launch per kernel: the poll table of this solve and (unless an asynchronous closed loop accumulates over its steps) the
+        // count of instances that do not converge start from zero -- the pipeline path keeps both in its control block
+        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
+        if (polled) HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT, stream));
+        if (G > 1) {     // the sub-streams were forked before these memsets were enqueued
+            HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
+            for (int g = 0; g < G; ++g) HIP_TRY(h, hipStreamWaitEvent(h->sub_stream[g], h->ev_fork, 0));
         }
     }
     while (!piped && it < cap) {
