@@ -759,8 +759,8 @@ __global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* s
             if (P.iters_out) P.iters_out[b] = P.ISC[tl * P.itile_elems + mpc_prow((uint32_t)IS_ITERS) + 2u * lane];
             if (P.kkt_out) P.kkt_out[b] = P.SC[(size_t)tl * P.tile_elems + mpc_prow((uint32_t)SC_E0) + 2u * lane];
         }
-        // how many instances of the batch did not converge (the host decides from this whether a second chance is due)
-        const int nbad = __popcll(__ballot(st != 1 ? 1 : 0));
+        // how many instances of the batch ran out of iterations or stalled (the host decides from this whether a second chance is due)
+        const int nbad = __popcll(__ballot((st == 0 || st == -7) ? 1 : 0));      // (NaN inputs stay NaN: not counted)
         if (fail_count != nullptr && lane == 0 && nbad) atomicAdd(fail_count, (uint32_t)nbad);
     }
 }
@@ -1191,7 +1191,7 @@ __global__ void __launch_bounds__(1024) k_rescue_select(const int32_t* status, i
     __syncthreads();
     for (int b0 = 0; b0 < B; b0 += 1024) {
         const int b = b0 + t;
-        const int bad = (b < B && status[b] != 1) ? 1 : 0;
+        const int bad = (b < B && (status[b] == 0 || status[b] == -7)) ? 1 : 0;          // iteration limit / no progress; a NaN (-6) would stay one
         const unsigned long long m = __ballot(bad);
         if (lane == 0) wsum[w] = __popcll(m);
         __syncthreads();

@@ -406,6 +406,10 @@ def test_bad_inputs_are_contained_and_reported():
     assert L.mpc_solve_batch(h, 0, abi.as_dp(x0), abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
     assert L.mpc_solve_batch(h, 4, None, abi.as_dp(p), None, abi.as_dp(np.empty_like(x0)), None, None, None) == abi.MPC_ERR_INVALID
     assert b"required" in L.mpc_last_error(h)
+    assert s.last_rescued() == 0                       # NaN instances are not handed to the second chance
+    with pytest.raises(pkg.MpcError):
+        s.set_option("no_such_switch", "1")
+    s.set_option("pipeline", None)
 
 
 def test_mixed_sweep_shard_matches_oracle():
