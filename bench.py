@@ -477,6 +477,19 @@ def side_paths(torch, mpc_amd, fam, B, local_rank):
                                                             frac=B * float(it_.mean()) * b_it / tf / 1e9 / HBM_PEAK_GBS, traffic=None,
                                                             algorithmic_bytes_per_instance_iteration=b_it),
                                               note="mpc_forces_solve_batch_dev, device-resident buffers, HIP events (row f3)")
+        Lf = 30
+        kf = np.arange(Lf)
+        pathf = np.stack([29.9948 + kf * 2.0 * np.cos(0.03495), -1.1501 + kf * 2.0 * np.sin(0.03495)], 1)
+        initf = np.tile([29.9948, -1.1501, 0.0, 20.0, 0.03495], (B, 1))
+        initf[:, 1] += np.random.default_rng(2).uniform(-0.3, 0.3, B)
+        argsf = (np.tile(pathf, (B, 1, 1)), np.full((B, Lf), 0.03495), np.full(B, 20.0), Lf, lbf, ubf, hlf, huf)
+        sf.forces_closed_loop(initf[:64], argsf[0][:64], argsf[1][:64], argsf[2][:64], *argsf[3:])
+        t0 = time.perf_counter()
+        _, _, flf = sf.forces_closed_loop(initf, *argsf)
+        tfl = time.perf_counter() - t0
+        other_paths["forces_closed_loop"] = dict(ego_steps_per_s=B * Lf / tfl, ms_per_step_of_batch=tfl / Lf * 1e3, batch=B, steps=Lf, horizon=10,
+                                                 solved_frac=float((flf == 1).mean()),
+                                                 note="mpc_forces_closed_loop_batch, host buffers in/out once per call (rows f1 + f3)")
     except Exception as e:      # never let the side measurements take the bench line down
         other_paths["error"] = repr(e)
     return other_paths

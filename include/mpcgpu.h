@@ -26,6 +26,7 @@
  *   mpc_forces_stage_eval ........... `FORCESNLPsolver_casadi2forces` (test/FORCESNLPsolver/FORCESNLPsolver_interface.c:41-198):
  *                                     FORCES-mode stage cost / RK4 dynamics / inequalities with their derivatives.
  *   mpc_forces_solve_batch .......... `output, exitflag, info = solver.solve(problem)` of ForcesproOptimizer (optimizer.py:326).
+ *   mpc_forces_closed_loop_batch .... the loop of ForcesproOptimizer.optimize around it (optimizer.py:246-366).
  *   mpc_metrics_batch ............... deviation.txt / RMSD.txt of MPCPlanner (mpc_planner.py:184-199, 279-292), circle clearance.
  *   mpc_validity_batch .............. the collision / road-boundary verdict of test/test_mpc_planner.py:37-47.
  *
@@ -176,6 +177,23 @@ int mpc_forces_stage_eval(mpc_handle* h, int32_t B, int32_t terminal, const doub
 int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const double* xinit, const double* all_parameters,
                            const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
                            double* x_out, int32_t* exitflag, int32_t* it, double* res);
+
+/* The FORCES-mode closed loop around that solve (ForcesproOptimizer.optimize, optimizer.py:246-366) for B egos, on the device with
+ * nothing coming back to the host between the steps: the never-refreshed guess problem["x0"] = tiled initial point (:264-274), the
+ * run-time parameters of every step (next N path points / orientations replenished with the last one, desired velocity ramping to 0
+ * over the last N steps of the run, obstacle circle centres of the descriptor; :292-323), one SQP step, first input (+ N(0, sigma)
+ * on it alone with noise_mode 2, :348-354; 0 = none; seeded counter-based samples as in mpc_closed_loop_batch_ex), one RK4 plant step
+ * (:356).  init_state [B,5], init_acc [B] or NULL (0), path [B,Lp,2], orient [B,Lp] (the reference has Lp = L = iter_length), vdes [B];
+ * lb/ub/hl/hu as in mpc_forces_solve_batch (host arrays).  Outputs traj [B,L,5], ctrl [B,L,2], step_flag [B,L] or NULL (the exitflag of
+ * every step; the reference asserts it is 1, optimizer.py:330).                                                                  */
+int mpc_forces_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* init_acc,
+                                 const double* path, const double* orient, const double* vdes, const double* lb, const double* ub,
+                                 const double* hl, const double* hu, int32_t hessian_mode, int32_t noise_mode, double sigma, uint64_t seed,
+                                 double* traj, double* ctrl, int32_t* step_flag);
+int mpc_forces_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_init_acc,
+                                     const double* d_path, const double* d_orient, const double* d_vdes, const double* lb, const double* ub,
+                                     const double* hl, const double* hu, int32_t hessian_mode, int32_t noise_mode, double sigma, uint64_t seed,
+                                     double* d_traj, double* d_ctrl, int32_t* d_step_flag, void* stream);
 
 /* Post-hoc trajectory metrics (scope row f4) for B planned trajectories traj [B,L,5] (host buffers, any output may be NULL):
  *   deviation [B,L]  distance to the nearest point of origin_path [B,Lo,2]   (plot_deviation_euclidean_dis,

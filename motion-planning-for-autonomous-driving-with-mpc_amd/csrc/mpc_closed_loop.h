@@ -134,4 +134,90 @@ MPC_HD void loop_advance_instance(const Params& P, const LoopArgs& A, int b, int
     loop_write_reference(A, b, i, cur);
 }
 
+// =========================================================================================================================
+// The FORCES-mode loop (ForcesproOptimizer.optimize, MPC_Planner/optimizer.py:246-366) around `solver.solve(problem)`:
+//   * the guess problem["x0"] is the tiled initial point and is NEVER refreshed                              :264-274
+//   * run-time parameters of step k: the next N path points / orientations (replenished with the last one), the desired
+//     velocity ramping linearly to 0 over the last N steps of the run, the obstacle circle centres          :292-323
+//   * the first input of the solution (+ noise on it alone when `noised`, :348-354) goes to the plant: one RK4 step   :356
+// One instance per thread; buffers row-major.
+// =========================================================================================================================
+struct ForcesLoopArgs {
+    int32_t B, N, L, Lp;             // instances, horizon, steps (iter_length = path rows the reference has), path rows per instance given
+    const double* init_state;        // [B,5]
+    const double* init_acc;          // [B]   initial acceleration (second entry of the guess, optimizer.py:265)
+    const double* path;              // [B,Lp,2]
+    const double* orient;            // [B,Lp]
+    const double* vdes;              // [B]
+    double obstacle[6];              // circle centres of the obstacle (problem template)
+    double* state;                   // [B,5]   plant state (work buffer) = problem["xinit"] of the next solve
+    double* zbar;                    // [B,N,7] problem["x0"]
+    double* params;                  // [B,N,10] problem["all_parameters"]
+    const double* z_out;             // [B,N,7] solution of the solve just finished
+    const int32_t* exitflag;         // [B]
+    double* traj;                    // [B,L,5]
+    double* ctrl;                    // [B,L,2]
+    int32_t* step_flag;              // [B,L] exitflag of every step (the reference asserts == 1), or null
+    double dt, wheelbase;
+    int32_t noise_mode;              // 0 or 2 (applied input only)
+    double sigma;
+    uint32_t seed_lo, seed_hi;
+};
+
+MPC_HD void forces_loop_setup_instance(const ForcesLoopArgs& A, int b) {
+    double z0[7] = {0.0, A.init_acc ? A.init_acc[b] : 0.0, A.init_state[(size_t)b * 5 + 0], A.init_state[(size_t)b * 5 + 1], 0.0,
+                    A.init_state[(size_t)b * 5 + 3], A.init_state[(size_t)b * 5 + 4]};
+    for (int q = 0; q < 5; ++q) A.state[(size_t)b * 5 + q] = (q == 2) ? 0.0 : A.init_state[(size_t)b * 5 + q];
+    for (int j = 0; j < A.N; ++j)
+        for (int i = 0; i < 7; ++i) A.zbar[((size_t)b * A.N + j) * 7 + i] = z0[i];
+}
+// all_parameters of step k (optimizer.py:292-323)
+MPC_HD void forces_loop_params_instance(const ForcesLoopArgs& A, int b, int k) {
+    const int N = A.N, L = A.L;
+    const double vd = A.vdes[b];
+    for (int j = 0; j < N; ++j) {
+        const int idx = k + 1 + j;
+        const int ip = idx < A.Lp ? idx : A.Lp - 1;                                  // replenished with the last point / orientation
+        // desired velocity: vdes for the first L - N steps, then linspace(vdes, 0, N); beyond the run: its last entry
+        const int iv = idx < L ? idx : L - 1;
+        double v = vd;
+        if (iv >= L - N) {
+            const int r = iv - (L - N);
+            v = (N > 1) ? vd + (double)r * ((0.0 - vd) / (double)(N - 1)) : vd;      // numpy.linspace: start + i * step
+            if (r == N - 1 && N > 1) v = 0.0;                                         // ... with the end point exact
+        }
+        double* p = A.params + ((size_t)b * N + j) * 10;
+        p[0] = A.path[((size_t)b * A.Lp + ip) * 2];
+        p[1] = A.path[((size_t)b * A.Lp + ip) * 2 + 1];
+        p[2] = v;
+        p[3] = A.orient[(size_t)b * A.Lp + ip];
+        for (int q = 0; q < 6; ++q) p[4 + q] = A.obstacle[q];
+    }
+}
+// after solve k: applied input (+ noise), record, one RK4 step of the plant
+MPC_HD void forces_loop_advance_instance(const ForcesLoopArgs& A, int b, int k) {
+    Params P{};
+    P.dt = A.dt; P.wheelbase = A.wheelbase; P.nx = 5;
+    LoopArgs nz{};
+    nz.noise_mode = A.noise_mode; nz.sigma = A.sigma; nz.seed_lo = A.seed_lo; nz.seed_hi = A.seed_hi; nz.N = A.N;
+    double x[5], u[2];
+    for (int q = 0; q < 5; ++q) x[q] = A.state[(size_t)b * 5 + q];
+    u[0] = A.z_out[((size_t)b * A.N) * 7 + 0] + loop_noise(nz, b, k, 0, 0);
+    u[1] = A.z_out[((size_t)b * A.N) * 7 + 1] + loop_noise(nz, b, k, 1, 0);
+    for (int q = 0; q < 5; ++q) A.traj[((size_t)b * A.L + k) * 5 + q] = x[q];
+    A.ctrl[((size_t)b * A.L + k) * 2] = u[0];
+    A.ctrl[((size_t)b * A.L + k) * 2 + 1] = u[1];
+    if (A.step_flag) A.step_flag[(size_t)b * A.L + k] = A.exitflag ? A.exitflag[b] : 0;
+    double k1[5], k2[5], k3[5], k4[5], tmp[5], s, c, td;
+    const double h = A.dt;
+    ode_eval<5>(P, x, u, k1, s, c, td);
+    for (int i = 0; i < 5; ++i) tmp[i] = x[i] + 0.5 * h * k1[i];
+    ode_eval<5>(P, tmp, u, k2, s, c, td);
+    for (int i = 0; i < 5; ++i) tmp[i] = x[i] + 0.5 * h * k2[i];
+    ode_eval<5>(P, tmp, u, k3, s, c, td);
+    for (int i = 0; i < 5; ++i) tmp[i] = x[i] + h * k3[i];
+    ode_eval<5>(P, tmp, u, k4, s, c, td);
+    for (int i = 0; i < 5; ++i) A.state[(size_t)b * 5 + i] = x[i] + h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+}
+
 }  // namespace mpc

@@ -1181,6 +1181,20 @@ __global__ void k_loop_sticky(const uint32_t* pipe_abort, uint32_t* loop_abort) 
     if (*pipe_abort != 0u) *loop_abort = 1u;
 }
 
+// FORCES-mode closed loop (mpc_closed_loop.h: ForcesLoopArgs), one instance per thread
+__global__ void k_floop_setup(const ForcesLoopArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) forces_loop_setup_instance(A, b);
+}
+__global__ void k_floop_params(const ForcesLoopArgs A, const int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) forces_loop_params_instance(A, b, k);
+}
+__global__ void k_floop_advance(const ForcesLoopArgs A, const int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < A.B) forces_loop_advance_instance(A, b, k);
+}
+
 // ---- second chance for stalled instances (see rescue_dev on the host side) ---------------------------------------------
 // ordered list of the instances whose status is not "converged": one workgroup, ballot-based compaction
 __global__ void __launch_bounds__(1024) k_rescue_select(const int32_t* status, int B, int32_t* idx, int32_t* count) {
@@ -1320,7 +1334,7 @@ struct mpc_handle {
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
-    static constexpr int N_SCRATCH = 16;
+    static constexpr int N_SCRATCH = 32;
     void* scratch[N_SCRATCH] = {};
     size_t scratch_cap[N_SCRATCH] = {};
 };
@@ -2434,6 +2448,79 @@ int mpc_forces_solve_batch(mpc_handle* h, int32_t B, const double* x0, const dou
     if (exitflag) HIP_TRY(h, hipMemcpyAsync(exitflag, dflag, nB * 4, hipMemcpyDeviceToHost, s));
     if (it) HIP_TRY(h, hipMemcpyAsync(it, dit, nB * 4, hipMemcpyDeviceToHost, s));
     if (res) HIP_TRY(h, hipMemcpyAsync(res, dres, nB * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MPC_OK;
+}
+
+int mpc_forces_closed_loop_batch_dev(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* d_init_state, const double* d_init_acc,
+                                     const double* d_path, const double* d_orient, const double* d_vdes, const double* lb, const double* ub,
+                                     const double* hl, const double* hu, int32_t hessian_mode, int32_t noise_mode, double sigma, uint64_t seed,
+                                     double* d_traj, double* d_ctrl, int32_t* d_step_flag, void* stream_) {
+    if (!h) return MPC_ERR_INVALID;
+    const mpc_problem_desc& d = h->hp.desc;
+    if (B <= 0 || L <= 0 || Lp <= 0 || L < d.N || !d_init_state || !d_path || !d_orient || !d_vdes || !d_traj || !d_ctrl || !lb || !ub || !hl || !hu) {
+        h->err = "forces closed loop: B, L, Lp > 0, L >= N and init_state, path, orient, vdes, traj, ctrl, lb, ub, hl, hu are required";
+        return MPC_ERR_INVALID;
+    }
+    if (!(noise_mode == 0 || noise_mode == 2) || (noise_mode && !(sigma >= 0.0))) { h->err = "forces closed loop: noise_mode 0 or 2, sigma >= 0"; return MPC_ERR_INVALID; }
+    if (d.nx != 5) { h->err = "the FORCES formulation has 5 states"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nB = (size_t)B, N = (size_t)d.N;
+    double* st = static_cast<double*>(scratch_get(h, 16, nB * 5 * 8));
+    double* zb = static_cast<double*>(scratch_get(h, 17, nB * N * 7 * 8));
+    double* par = static_cast<double*>(scratch_get(h, 18, nB * N * 10 * 8));
+    double* zo = static_cast<double*>(scratch_get(h, 19, nB * N * 7 * 8));
+    int32_t* fl = static_cast<int32_t*>(scratch_get(h, 20, nB * 4));
+    if (!st || !zb || !par || !zo || !fl) { h->err = "forces closed loop: out of device memory"; return MPC_ERR_HIP; }
+    hipStream_t s = (hipStream_t)stream_;
+    ForcesLoopArgs A{};
+    A.B = B; A.N = d.N; A.L = L; A.Lp = Lp;
+    A.init_state = d_init_state; A.init_acc = d_init_acc; A.path = d_path; A.orient = d_orient; A.vdes = d_vdes;
+    for (int i = 0; i < 6; ++i) A.obstacle[i] = d.obstacle[i];
+    A.state = st; A.zbar = zb; A.params = par; A.z_out = zo; A.exitflag = fl;
+    A.traj = d_traj; A.ctrl = d_ctrl; A.step_flag = d_step_flag;
+    A.dt = d.dt; A.wheelbase = d.wheelbase;
+    A.noise_mode = noise_mode; A.sigma = sigma; A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
+    const dim3 grid((B + 127) / 128), block(128);
+    hipLaunchKernelGGL(k_floop_setup, grid, block, 0, s, A);
+    for (int k = 0; k < L; ++k) {                       // nothing comes back to the host between the steps
+        hipLaunchKernelGGL(k_floop_params, grid, block, 0, s, A, k);
+        const int rc = mpc_forces_solve_batch_dev(h, B, zb, st, par, lb, ub, hl, hu, hessian_mode, zo, fl, nullptr, nullptr, (void*)s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_floop_advance, grid, block, 0, s, A, k);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_forces_closed_loop_batch(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, const double* init_state, const double* init_acc, const double* path,
+                                 const double* orient, const double* vdes, const double* lb, const double* ub, const double* hl, const double* hu,
+                                 int32_t hessian_mode, int32_t noise_mode, double sigma, uint64_t seed, double* traj, double* ctrl, int32_t* step_flag) {
+    if (!h) return MPC_ERR_INVALID;
+    if (B <= 0 || L <= 0 || Lp <= 0 || !init_state || !path || !orient || !vdes || !traj || !ctrl) { h->err = "forces closed loop: null or empty argument"; return MPC_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nB = (size_t)B;
+    hipStream_t s = h->own_stream;
+    double* di = static_cast<double*>(scratch_get(h, 21, nB * 5 * 8));
+    double* da = static_cast<double*>(scratch_get(h, 22, nB * 8));
+    double* dp = static_cast<double*>(scratch_get(h, 23, nB * Lp * 2 * 8));
+    double* dor = static_cast<double*>(scratch_get(h, 24, nB * Lp * 8));
+    double* dv = static_cast<double*>(scratch_get(h, 25, nB * 8));
+    double* dt_ = static_cast<double*>(scratch_get(h, 26, nB * L * 5 * 8));
+    double* dc = static_cast<double*>(scratch_get(h, 27, nB * L * 2 * 8));
+    int32_t* df = static_cast<int32_t*>(scratch_get(h, 28, nB * L * 4));
+    if (!di || !da || !dp || !dor || !dv || !dt_ || !dc || !df) { h->err = "forces closed loop: out of device memory"; return MPC_ERR_HIP; }
+    HIP_TRY(h, hipMemcpyAsync(di, init_state, nB * 5 * 8, hipMemcpyHostToDevice, s));
+    if (init_acc) HIP_TRY(h, hipMemcpyAsync(da, init_acc, nB * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dp, path, nB * Lp * 2 * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dor, orient, nB * Lp * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dv, vdes, nB * 8, hipMemcpyHostToDevice, s));
+    const int rc = mpc_forces_closed_loop_batch_dev(h, B, L, Lp, di, init_acc ? da : nullptr, dp, dor, dv, lb, ub, hl, hu, hessian_mode, noise_mode, sigma, seed,
+                                                    dt_, dc, step_flag ? df : nullptr, (void*)s);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(traj, dt_, nB * L * 5 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(ctrl, dc, nB * L * 2 * 8, hipMemcpyDeviceToHost, s));
+    if (step_flag) HIP_TRY(h, hipMemcpyAsync(step_flag, df, nB * L * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return MPC_OK;
 }

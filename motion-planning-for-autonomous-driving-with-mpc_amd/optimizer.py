@@ -446,10 +446,25 @@ class ForcesproOptimizer(Optimizer):
         oc = np.array(self.obstacle_circles_centers_tuple, dtype=np.float64).reshape(6, 1)
         return np.vstack((pts, v, ori, np.tile(oc, (1, N))))
 
+    use_device_loop = True      # the whole loop on the device (mpc_forces_closed_loop_batch); False: the step-by-step host loop below
+
     def optimize(self):
         """optimizer.py:246-366"""
         model, solver = self.solver()
         L = self.iter_length
+        noised = bool(self.configuration.noised)
+        seed = getattr(self.configuration, "noise_seed", None)
+        backend = getattr(solver, "_backend", None)
+        if self.use_device_loop and hasattr(backend, "forces_closed_loop") and (not noised or seed is not None):
+            t_ = time.time()
+            sigma = 0.1 if self.configuration.use_case == "lane_following" else 0.05
+            init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation])
+            traj, ctrl, flag = backend.forces_closed_loop(init_state, self.resampled_path_points, self.orientation, self.desired_velocity, L,
+                                                          model.lb, model.ub, model.hl, model.hu, init_acc=self.init_acceleration,
+                                                          hessian_mode=self.hessian_mode, noise_mode=2 if noised else 0,
+                                                          sigma=sigma if noised else 0.0, seed=0 if seed is None else int(seed))
+            assert np.all(flag == 1), "bad exitflag"                               # optimizer.py:330
+            return traj[0], ctrl[0], np.full(L, (time.time() - t_) / L)
         x = np.zeros((5, L + 1))
         u = np.zeros((2, L))
         solve_time = np.zeros(L)

@@ -296,6 +296,30 @@ class BatchedMPCSolver:
                                                          _abi.as_dp(big(hl, 10)), _abi.as_dp(big(hu, 10)), int(hessian_mode), vp(d_x_out), vp(d_flag or None),
                                                          vp(d_it or None), vp(d_res or None), vp(stream or None)))
 
+    def forces_closed_loop(self, init_state, path, orient, vdes, steps, lb, ub, hl, hu, init_acc=None, hessian_mode=0, noise_mode=0, sigma=0.0, seed=0):
+        """B egos through `steps` steps of ForcesproOptimizer.optimize (optimizer.py:246-366) on the device
+        (mpc_forces_closed_loop_batch): init_state [B,5], path [B,Lp,2], orient [B,Lp], vdes [B] -> (traj [B,steps,5],
+        ctrl [B,steps,2], exitflag [B,steps])."""
+        def big(a, n):
+            a = np.asarray(a, dtype=np.float64).reshape(n)
+            return _abi.f64(np.where(np.isfinite(a), a, np.sign(a) * 1e308))
+        init_state = _abi.f64(init_state)
+        if init_state.ndim == 1:
+            init_state = init_state[None]
+        B = init_state.shape[0]
+        path = _abi.f64(path).reshape(B, -1, 2)
+        Lp = path.shape[1]
+        orient = _abi.f64(orient).reshape(B, Lp)
+        vdes = _abi.f64(np.broadcast_to(np.asarray(vdes, dtype=np.float64), (B,)))
+        acc = None if init_acc is None else _abi.f64(np.broadcast_to(np.asarray(init_acc, dtype=np.float64), (B,)))
+        steps = int(steps)
+        traj, ctrl, fl = np.empty((B, steps, 5)), np.empty((B, steps, 2)), np.empty((B, steps), np.int32)
+        self._check(self._lib.mpc_forces_closed_loop_batch(self._h, B, steps, Lp, _abi.as_dp(init_state), _abi.as_dp(acc), _abi.as_dp(path), _abi.as_dp(orient),
+                                                           _abi.as_dp(vdes), _abi.as_dp(big(lb, 7)), _abi.as_dp(big(ub, 7)), _abi.as_dp(big(hl, 10)),
+                                                           _abi.as_dp(big(hu, 10)), int(hessian_mode), int(noise_mode), float(sigma), int(seed) & (2 ** 64 - 1),
+                                                           _abi.as_dp(traj), _abi.as_dp(ctrl), _abi.as_ip(fl)))
+        return traj, ctrl, fl
+
     def set_option(self, name, value=None):
         """run-time switch of the handle (include/mpcgpu.h: mpc_set_option); value None restores the default.  The
         environment (MPCGPU_<NAME>) is only read when the handle is created."""

@@ -162,6 +162,25 @@ extern "C" int emu_closed_loop_piece(int32_t mode, int32_t i, double dt, double 
     return 0;
 }
 
+// pieces of the FORCES-mode closed loop (mpc_closed_loop.h): mode 0 setup, 1 parameters of step k, 2 advance after solve k
+extern "C" int emu_forces_loop_piece(int32_t mode, int32_t k, double dt, double wheelbase, int32_t B, int32_t N, int32_t L, int32_t Lp,
+                                     const double* init_state, const double* init_acc, const double* path, const double* orient, const double* vdes,
+                                     const double* obstacle, double* state, double* zbar, double* params, const double* z_out, const int32_t* exitflag,
+                                     double* traj, double* ctrl, int32_t* step_flag, int32_t noise_mode, double sigma, uint64_t seed) {
+    ForcesLoopArgs A{};
+    A.B = B; A.N = N; A.L = L; A.Lp = Lp;
+    A.init_state = init_state; A.init_acc = init_acc; A.path = path; A.orient = orient; A.vdes = vdes;
+    for (int i = 0; i < 6; ++i) A.obstacle[i] = obstacle[i];
+    A.state = state; A.zbar = zbar; A.params = params; A.z_out = z_out; A.exitflag = exitflag; A.traj = traj; A.ctrl = ctrl; A.step_flag = step_flag;
+    A.dt = dt; A.wheelbase = wheelbase; A.noise_mode = noise_mode; A.sigma = sigma; A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
+    for (int b = 0; b < B; ++b) {
+        if (mode == 0) forces_loop_setup_instance(A, b);
+        else if (mode == 1) forces_loop_params_instance(A, b, k);
+        else forces_loop_advance_instance(A, b, k);
+    }
+    return 0;
+}
+
 // FORCES-mode SQP step (mpc_forces_qp.h), one instance after the other on host arrays
 extern "C" int emu_forces_solve(int32_t B, int32_t N, double dt, double l, double wb, double rho, const double* Q, const double* R,
                                 const double* Pt, const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,

@@ -78,6 +78,9 @@ def emu_lib():
         L.emu_closed_loop_piece.restype = C.c_int
         L.emu_forces_solve.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double] + [dp] * 7 + [C.c_int32] + [dp] * 3 + [dp, ip, ip, dp]
         L.emu_forces_solve.restype = C.c_int
+        L.emu_forces_loop_piece.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [dp] * 6 + \
+                                           [dp, dp, dp, dp, ip, dp, dp, ip, C.c_int32, C.c_double, C.c_uint64]
+        L.emu_forces_loop_piece.restype = C.c_int
         _emu = L
     return _emu
 

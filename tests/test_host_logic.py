@@ -270,3 +270,48 @@ def test_rescue_by_radius_homotopy_with_standin_backend():
     assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6)
     # and the bounds of the backend are the original ones again
     assert be._o.desc.obst_lo == float(lbg[-1])
+
+
+@pytest.mark.parametrize("seed", [None, 11])
+def test_forces_loop_pieces_match_the_python_loop(seed):
+    """mpc_closed_loop.h's FORCES-mode driver (setup / run-time parameters / advance), stepped on the CPU with the emulated SQP
+    step in between, against ForcesproOptimizer.optimize's host loop (optimizer.py:246-366): the never-refreshed guess, the
+    parameter block with its replenished tail and velocity ramp, the applied-input noise convention, the RK4 plant step"""
+    import ctypes as C
+    from helpers import emu_lib
+    N, L = 10, 30
+    o = make_forces_optimizer(N, L)
+    o.use_device_loop = False
+    if seed is not None:
+        o.configuration.noised = True
+        o.configuration.noise_seed = seed
+    states, controls, _ = o.optimize()
+    model, solver = o.solver()
+    be = solver._backend
+    lib = emu_lib()
+    B = 1
+    init = np.array([[29.9948, -1.1501, 0.0, 20.0, 0.03495]])
+    acc = np.zeros(1)
+    path, orient, vdes = o.resampled_path_points[None].copy(), np.asarray(o.orientation)[None].copy(), np.array([20.0])
+    obst = np.array(o.obstacle_circles_centers_tuple, dtype=np.float64).ravel()
+    state, zbar, par, zo = np.zeros((B, 5)), np.zeros((B, N, 7)), np.zeros((B, N, 10)), np.zeros((B, N, 7))
+    fl = np.ones(B, np.int32)
+    traj, ctrl, sfl = np.zeros((B, L, 5)), np.zeros((B, L, 2)), np.zeros((B, L), np.int32)
+
+    def piece(mode, k):
+        rc = lib.emu_forces_loop_piece(mode, k, C.c_double(0.1), C.c_double(2.5789128), B, N, L, L, abi.as_dp(init), abi.as_dp(acc), abi.as_dp(path),
+                                       abi.as_dp(orient), abi.as_dp(vdes), abi.as_dp(obst), abi.as_dp(state), abi.as_dp(zbar), abi.as_dp(par), abi.as_dp(zo),
+                                       abi.as_ip(fl), abi.as_dp(traj), abi.as_dp(ctrl), abi.as_ip(sfl), 0 if seed is None else 2, C.c_double(0.1),
+                                       C.c_uint64(seed or 0))
+        assert rc == 0
+    piece(0, 0)
+    assert np.array_equal(zbar[0], np.tile([0.0, 0.0, 29.9948, -1.1501, 0.0, 20.0, 0.03495], (N, 1)))
+    for k in range(L):
+        piece(1, k)
+        assert np.allclose(par[0], o.runtime_parameters(k, N).T, rtol=0, atol=1e-12), k
+        x, flag, it, res = be.forces_solve(zbar, state, par, model.lb, model.ub, model.hl, model.hu)
+        zo[:] = x
+        fl[:] = flag
+        piece(2, k)
+    assert np.all(sfl == 1)
+    assert np.allclose(traj[0], states, rtol=0, atol=1e-9) and np.allclose(ctrl[0], controls, rtol=0, atol=1e-9)
