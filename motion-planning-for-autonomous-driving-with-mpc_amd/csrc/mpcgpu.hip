@@ -1330,7 +1330,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1358,12 +1358,13 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "pipe_xcd_mask"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2045,6 +2046,27 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
     if (rescue && !d_status) {
         d_status = static_cast<int32_t*>(scratch_get(h, 11, (size_t)B * 4));
         if (!d_status) { h->err = "out of device memory"; return MPC_ERR_HIP; }
+    }
+    // The workspace is addressed with 32-bit buffer offsets (< 4 GiB): a batch beyond that is solved in chunks of whole tiles, one after
+    // the other on the same stream (instances are independent; the rows of a chunk are a contiguous slice of every caller buffer).
+    {
+        const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64);
+        size_t max_b = (((size_t)1 << 32) - 1) / (w1.tile_elems * sizeof(double)) * 64;
+        if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
+        if ((size_t)B > max_b && !trace && !h->async_loop) {
+            const size_t nw = h->hp.n_w();
+            int rescued = 0;
+            for (size_t off = 0; off < (size_t)B; off += max_b) {
+                const int32_t n = (int32_t)std::min(max_b, (size_t)B - off);
+                const int rcc = solve_dev(h, n, d_x0 + off * nw, d_p + off * nw, d_obst ? d_obst + off * 6 : nullptr, d_x_out + off * nw,
+                                          d_status ? d_status + off : nullptr, d_iters ? d_iters + off : nullptr, d_kkt ? d_kkt + off : nullptr, stream,
+                                          nullptr, 0, nullptr);
+                if (rcc) return rcc;
+                rescued += h->rescued_last;
+            }
+            h->rescued_last = rescued;
+            return MPC_OK;
+        }
     }
     const int rc = solve_dev_any(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
     if (rc != MPC_OK || !rescue || h->h_fail[0] == 0u) return rc;       // (converged mode: the solve has synchronised the stream)

@@ -65,6 +65,26 @@ def test_ragged_batch_sizes(B):
     assert np.array_equal(part.x, full.x[:B]) and np.array_equal(part.iters, full.iters[:B])
 
 
+def test_batches_beyond_the_workspace_limit_are_solved_in_chunks():
+    """the workspace is addressed with 32-bit offsets (< 4 GiB, ~100 k instances at N = 30); a larger batch is cut into chunks of
+    whole tiles behind the C-ABI.  Option "max_batch" lowers the limit so that the path can be exercised: same bits as one solve."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 300, **kw)
+    s = make_solver(cfg)
+    full = s.solve(x0, p)
+    s.set_option("max_batch", "128")                      # 128 + 128 + 44
+    part = s.solve(x0, p)
+    assert _same(part, full)
+    x0c, pc = ca_batch(CA_CFG, 200)
+    sc = make_solver(CA_CFG)
+    set_cfg_bounds(sc, CA_CFG)
+    fullc = sc.solve(x0c, pc)
+    n = sc.last_rescued()
+    sc.set_option("max_batch", "64")
+    partc = sc.solve(x0c, pc)
+    assert _same(partc, fullc) and sc.last_rescued() == n and np.all(partc.status == 1)
+
+
 @pytest.mark.parametrize("env", ["MPCGPU_BIG_WG", "MPCGPU_GROUPS"])
 def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
     """The opt-in variants (512-thread stage workgroups -- the kernel long horizons use --, sub-batch streams) run the
