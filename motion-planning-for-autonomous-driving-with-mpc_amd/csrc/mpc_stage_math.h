@@ -1454,8 +1454,9 @@ struct RicGain {
 // NE < NX (NE = 5 with NX = 6): the progress state s (index 5: s' = v, zero weight, unbounded) is decoupled -- its row and
 // column of the cost-to-go are identically zero as long as no inertia correction is added -- so the recursion runs on NE
 // states and writes explicit zeros where the six-state layout has entries of s.
-template <int NX, int NE = NX>
-MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g) {
+template <int NX, int NE = NX, bool SYM = true>
+MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g,
+                            bool sym_gk = false) {
     using D = Dim<NX>;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
@@ -1508,7 +1509,8 @@ MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, doubl
             }
             double t = Ps[D::sidx(i, j)];
             if (D::hrow(i, j) >= 0) t += s.H[D::sidx(i, j)];
-            t += g.G0[i] * K0[j] + g.G1[i] * K1[j];
+            const double gk = g.G0[i] * K0[j] + g.G1[i] * K1[j];
+            t += gk;
             if (j >= 2 && j <= 4) t += W[i][j - 2];
             if (i >= 2 && i <= 4) t += W[j][i - 2];
             if (i >= 2 && i <= 4 && j >= 2 && j <= 4) {          // ((dtF)'W)[i][j], rows/cols (delta, v, psi)
@@ -1518,6 +1520,15 @@ MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, doubl
                 if (i == 4) t += a04 * W[0][cj] + a14 * W[1][cj];
             }
             if (i == j) t += delta;
+            // Nonconvex instances (any that ever needed an inertia correction): the term G'K = -G' Lam^-1 G cancels most of A'P+A once
+            // active circle rows put weights of 1/mu into the cost-to-go, and the rounding of K makes G'K slightly unsymmetric -- taking
+            // (i, j) from one triangle only then feeds an error of 1e-16 x 1e9 back into every later stage, spurious "indefinite" verdicts
+            // and steps that do not reduce the KKT error follow (collision avoidance: up to 95 iterations where the dense-KKT solver
+            // needs 26).  The mean of the two triangles -- what symmetrising P_k amounts to -- removes that; 3 more instructions per entry,
+            // so only for the instances that need it (lane following never does: same bits as before).  SYM = false is the
+            // instantiation without the term, for a wavefront none of whose instances asks for it (adding the 0.0 of the select
+            // changes no bits, so which of the two a wavefront runs does not show in the results).
+            if (SYM && i != j) t += sym_gk ? 0.5 * ((g.G0[j] * K0[i] + g.G1[j] * K1[i]) - gk) : 0.0;
             Ps[D::sidx(i, j)] = t;
         }
     }
@@ -1575,15 +1586,15 @@ MPC_HD void ric_store_stage(const Params& P, uint32_t bb, int k, const double* P
 }
 
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
-template <int NX, int NE = NX>
+template <int NX, int NE = NX, bool SYM = true>
 MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
-                                  double hux1, double* Ps, double* pv) {
+                                  double hux1, double* Ps, double* pv, bool sym_gk = false) {
     constexpr int NS = Dim<NX>::NS;
     double Pn[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Pn[i] = Ps[i];
     RicGain<NX> g;
-    if (!ric_matrix_step<NX, NE>(P, k, s, delta, hux0, hux1, Ps, g)) return false;
+    if (!ric_matrix_step<NX, NE, SYM>(P, k, s, delta, hux0, hux1, Ps, g, sym_gk)) return false;
     ric_vector_step<NX, NE>(P, s, Pn, g, pv);
     ric_store_stage<NX>(P, bb, k, Ps, pv, g);
     return true;
@@ -1593,12 +1604,12 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
 // this sweep (delta_w would put a nonzero entry on the diagonal of the decoupled state)
 template <int NX>
 MPC_HD bool ric_bwd_any(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
-                        double* Ps, double* pv) {
+                        double* Ps, double* pv, bool sym_gk = false) {
     // (measured on MI355X: the five-state recursion -- 301 instead of 402 instructions per stage -- does not shorten the
     //  stage, 40.4 vs 39.8 us per launch, so the GPU kernel runs the general step; the emulation harness keeps exercising
     //  the NE = 5 instantiation through this function so that it stays correct)
-    if (NX == 6 && P.dec_s && delta == 0.0) return riccati_backward_step<NX, (NX == 6 ? 5 : NX)>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
-    return riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+    if (NX == 6 && P.dec_s && delta == 0.0) return riccati_backward_step<NX, (NX == 6 ? 5 : NX)>(P, bb, k, s, delta, hux0, hux1, Ps, pv, sym_gk);
+    return riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv, sym_gk);
 }
 
 // stage data of the forward sweep
@@ -1684,12 +1695,12 @@ MPC_HD void riccati_instance(const Params& P, int b) {
         int k = N - 1;
         for (; k >= 1; k -= 2) {
             ric_load<NX>(P, b, k - 1, nxt);
-            if (!ric_bwd_any<NX>(P, bb, k, cur, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+            if (!ric_bwd_any<NX>(P, bb, k, cur, delta, hux0, hux1, Ps, pv, delta != 0.0 || delta_last != 0.0)) { ok = false; break; }
             if (k >= 2) ric_load<NX>(P, b, k - 2, cur);
-            if (!ric_bwd_any<NX>(P, bb, k - 1, nxt, delta, hux0, hux1, Ps, pv)) { ok = false; break; }
+            if (!ric_bwd_any<NX>(P, bb, k - 1, nxt, delta, hux0, hux1, Ps, pv, delta != 0.0 || delta_last != 0.0)) { ok = false; break; }
         }
         if (ok && k == 0) {
-            if (!ric_bwd_any<NX>(P, bb, 0, cur, delta, hux0, hux1, Ps, pv)) ok = false;
+            if (!ric_bwd_any<NX>(P, bb, 0, cur, delta, hux0, hux1, Ps, pv, delta != 0.0 || delta_last != 0.0)) ok = false;
         }
         if (ok) break;
         if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);

@@ -21,6 +21,7 @@
 //   k_ingest / k_egest LDS-tiled transposes between the caller's row-major buffers and the tile-major workspace.
 // HBM layout: tile-major structure-of-arrays with interleaved row pairs (mpc_prow in mpc_stage_math.h).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cctype>
@@ -347,32 +348,40 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
         } else {
             // ---------------- compute
             bool ok = need;
-            double Ps[NS], pv[NX];
-            for (int t = 0; t <= N; ++t) {
-                const int k = N - t;
-                if (t == 15) RIC_STAMP(3);
-                lds_barrier();
-                if (t == 15) RIC_STAMP(4);
-                RicStage<NX> s;
-                read_stage((uint32_t)(t % RIC_DEPTH) * SLOT, s);
-                if (t == 0) {
+            // symmetrised G'K for the instances that ever needed an inertia correction (mpc_stage_math.h, ric_matrix_step); a
+            // wavefront without any runs the sweep instantiated without the term (decided per sweep, so that the loop of the
+            // common case is the loop it always was)
+            const bool sym = delta != 0.0 || delta_last != 0.0;
+            auto sweep = [&](auto sym_tag) {
+                constexpr bool SYM = decltype(sym_tag)::value;
+                double Ps[NS], pv[NX];
+                for (int t = 0; t <= N; ++t) {
+                    const int k = N - t;
+                    if (t == 15) RIC_STAMP(3);
+                    lds_barrier();
+                    if (t == 15) RIC_STAMP(4);
+                    RicStage<NX> s;
+                    read_stage((uint32_t)(t % RIC_DEPTH) * SLOT, s);
+                    if (t == 0) {
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
+                        for (int i = 0; i < NS; ++i) Ps[i] = s.H[i];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
-                    if (ok) {
-                        double pk[D::NPK];
+                        for (int i = 0; i < NX; ++i) { Ps[D::sidx(i, i)] += delta; pv[i] = s.gx[i]; }
+                        if (ok) {
+                            double pk[D::NPK];
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) pk[i] = Ps[i];
+                            for (int i = 0; i < NS; ++i) pk[i] = Ps[i];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) pk[NS + i] = pv[i];
-                        ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, N, e)), pk);
+                            for (int i = 0; i < NX; ++i) pk[NS + i] = pv[i];
+                            ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, N, e)), pk);
+                        }
+                    } else if (ok) {
+                        ok = riccati_backward_step<NX, NX, SYM>(P, bb, k, s, delta, hux0, hux1, Ps, pv, SYM && sym);
                     }
-                } else if (ok) {
-                    ok = riccati_backward_step<NX>(P, bb, k, s, delta, hux0, hux1, Ps, pv);
+                    if (t == 15) RIC_STAMP(5);
                 }
-                if (t == 15) RIC_STAMP(5);
-            }
+            };
+            if (__any(sym ? 1 : 0)) sweep(std::true_type{}); else sweep(std::false_type{});
             if (need && ok) need = false;
             else if (need) {
                 if (delta == 0.0) delta = (delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * delta_last);

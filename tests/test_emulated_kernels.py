@@ -66,6 +66,17 @@ def test_collision_avoidance_family():
         assert min(nlp.obstacle_rows(x)[0].min() for x in X) >= CA_CFG.r_sum - 1e-6
 
 
+def test_nonconvex_instances_stay_within_the_oracles_iteration_budget():
+    """the kernels' sparse cost-to-go update symmetrises G'K for instances that needed an inertia correction (ric_matrix_step): without
+    it the collision-avoidance family wanders at mu = 1e-9 (96 instances: 2730+ iterations, slowest 72-78) where the oracle's dense,
+    symmetrised recursion needs 2478 / 55"""
+    x0, p = ca_batch(CA_CFG, 96)
+    re = emu_solve(CA_CFG, x0, p)
+    ro = OracleSolver(CA_CFG).solve_batch(x0, p, nthreads=8)
+    assert (re["status"] == 1).sum() >= (ro["status"] == 1).sum()
+    assert re["iters"].sum() <= 1.03 * ro["iters"].sum() and re["iters"].max() <= ro["iters"].max() + 5
+
+
 def test_per_instance_obstacles_equal_shared():
     x0, p = ca_batch(CA_CFG, 8)
     shared = emu_solve(CA_CFG, x0, p)
