@@ -235,7 +235,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances), "loop_async" (0: closed loop with a host round trip per step),
  * "sync_spin" (0: block in the one synchronisation of a solve instead of polling the stream), "max_batch" (instances per chunk: a batch
  * whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway; this lowers the limit),
- * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing"
+ * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing",
+ * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage)
  * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);
 

@@ -388,7 +388,6 @@ struct Ctx {
     double so[3], dso[3];
     double sf, dsf;                  // friction slack (k == 0)
     double zt[NZ], sot[3], sft;      // current / accepted trial point
-    double tr_sps, tr_cps, tr_td;    // sin(psi), cos(psi), tan(delta) at zt (the assembly phase evaluates the model at the accepted zt again)
     double obst[6];
     // --- per-instance scalars (every thread of the instance holds the same values)
     double mu, tau, df, theta, phi, thmax, thmin;
@@ -427,16 +426,6 @@ MPC_HD void ode_eval(const Params& P, const double* x, const double* u, double* 
     sps = sin(x[4]); cps = cos(x[4]);
 #endif
     td = tan(x[2]);
-    f[0] = x[3] * cps;
-    f[1] = x[3] * sps;
-    f[2] = u[0];
-    f[3] = u[1];
-    f[4] = x[3] / P.wheelbase * td;
-    if (NX == 6) f[5] = x[3];
-}
-// the same with sin(psi), cos(psi), tan(delta) already known (the values ode_eval returned for this very x)
-template <int NX>
-MPC_HD void ode_eval_trig(const Params& P, const double* x, const double* u, double* f, double sps, double cps, double td) {
     f[0] = x[3] * cps;
     f[1] = x[3] * sps;
     f[2] = u[0];
@@ -989,7 +978,6 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     }
     double f[NX], sps, cps, td;
     ode_eval<NX>(P, c.zt + 2, c.zt, f, sps, cps, td);
-    c.tr_sps = sps; c.tr_cps = cps; c.tr_td = td;
     if (k < N) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1196,10 +1184,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         lamn[i] = (k < N) ? c.lamn[i] : 0.0;
         if (k >= N) c.xn[i] = 0.0;
     }
-    // REUSE: an active instance got here through an accepted trial point, x is that point (phase_apply_update copied zt) and
-    // phase_trial_eval left its sin / cos / tan in the context -- the same values ode_eval would compute again
-    if (REUSE) { sps = c.tr_sps; cps = c.tr_cps; td = c.tr_td; ode_eval_trig<NX>(P, x, u, f, sps, cps, td); }
-    else ode_eval<NX>(P, x, u, f, sps, cps, td);
+    ode_eval<NX>(P, x, u, f, sps, cps, td);
     const double secd2 = 1.0 + td * td, v = x[3], il = 1.0 / P.wheelbase;      // sec^2 = 1 + tan^2 (td from ode_eval)
     // A = I + dt * df/dx : six off-identity entries
     const double a03 = dt * cps, a04 = -dt * v * sps, a13 = dt * sps, a14 = dt * v * cps;

@@ -693,6 +693,123 @@ __global__ void __launch_bounds__(128) k_prestart(const Params P) {
     if (wave == 0 && b < P.B) prestart_decide<NX>(P, b, frow, a0lb, a0ub, th_guess[lane], th);
 }
 
+// The same start-point safeguard with one thread per (instance, stage), the layout of the stage kernel (bx instance columns per
+// workgroup).  The two 30-stage chains of k_prestart are chains of sin / cos / tan only because of how they are written: the defect of
+// the caller's state guess needs no recursion at all, and in the rollout (delta, v) depend on the controls alone, psi on (delta, v)
+// and (x, y, s) on (v, psi) -- so every transcendental is evaluated by the thread of its stage, and what is left sequential are
+// three short scans x_{k+1} = push_in(x_k + dt f_k) per state, run by the first two stage-threads of every instance from increments
+// parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
+template <int NX>
+__global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NZ = NX + 2;
+    const int N = P.N, S = N + 1, bx = P.bx, t = threadIdx.x, bl = t & (bx - 1);
+    const int nb = S * NZ, SB = S * bx;
+    double* LBt = sm;                       // [S][NZ]
+    double* UBt = LBt + nb;
+    double* XR = UBt + nb;                  // [NX][S][bx]  rollout states
+    double* DR = XR + NX * SB;              // [NX][S][bx]  rollout: clipping defect of state i at stage k
+    double* DG = DR + NX * SB;              // [NX][S][bx]  guess: dynamics defect of state i at stage k
+    double* IN = DG + NX * SB;              // [2][S][bx]   increments f_i of the two states being scanned
+    double* A0 = IN + 2 * SB;               // [3][bx]      a0lb, a0ub, defect of the guess
+    struct { int b, k; } c;
+    c.k = t / bx;
+    c.b = (int)((blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + bl;
+    const bool valid = c.k <= N && c.b < P.B;
+    const uint32_t bb = (uint32_t)c.b;
+    for (int q = t; q < nb; q += (int)blockDim.x) { LBt[q] = MPC_GP(P.LB, q); UBt[q] = MPC_GP(P.UB, q); }
+    double a0lb = 0.0, a0ub = 0.0;
+    int frow = 1;
+    if (valid && c.k == 0) {
+        frow = prestart_a0<NX>(P, c.b, a0lb, a0ub);
+        A0[bl] = a0lb;
+        A0[bx + bl] = a0ub;
+    }
+    __syncthreads();
+    const double dt = P.dt;
+#define PP_AT(arr, i, k) (arr)[((i) * S + (k)) * bx + bl]
+    if (valid) {
+        const int k = c.k;
+        double g[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) g[i] = push_in((double)MPC_K(P.Z, NZ, 0, 2 + i), LBt[k * NZ + 2 + i], UBt[k * NZ + 2 + i]);
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double r0 = MPC_K(P.REF, NX, 0, i);
+                const double x0 = push_in(r0, LBt[2 + i], UBt[2 + i]);
+                PP_AT(XR, i, 0) = x0;
+                PP_AT(DR, i, 0) = fabs(x0 - r0);
+                PP_AT(DG, i, 0) = fabs(g[i] - r0);
+            }
+        }
+        if (k < N) {
+            double u[2], f[NX], sp, cp, td;
+            u[0] = push_in((double)MPC_K(P.Z, NZ, 0, 0), LBt[k * NZ], UBt[k * NZ]);
+            u[1] = push_in((double)MPC_K(P.Z, NZ, 0, 1), (k == 0) ? A0[bl] : LBt[k * NZ + 1], (k == 0) ? A0[bx + bl] : UBt[k * NZ + 1]);
+            PP_AT(IN, 0, k) = u[0];
+            PP_AT(IN, 1, k) = u[1];
+            ode_eval<NX>(P, g, u, f, sp, cp, td);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double raw = f[i] * dt + g[i];
+                const double gn = push_in((double)MPC_K(P.Z, NZ, 1, 2 + i), LBt[(k + 1) * NZ + 2 + i], UBt[(k + 1) * NZ + 2 + i]);
+                PP_AT(DG, i, k + 1) = fabs(gn - raw);
+            }
+        }
+    }
+    __syncthreads();
+    // one scan: lanes of stage-thread `which` (0 or 1) carry state s0 / s1 through the stages from the increments IN[which]
+    auto scan = [&](int s0, int s1, int nwhich) {
+        if (valid && c.k < nwhich) {
+            const int si = (c.k == 0) ? s0 : s1;
+            const double* in = IN + c.k * SB;
+            double x = PP_AT(XR, si, 0);
+            for (int k = 0; k < N; ++k) {
+                const double raw = in[k * bx + bl] * dt + x;
+                const double rn = push_in(raw, LBt[(k + 1) * NZ + 2 + si], UBt[(k + 1) * NZ + 2 + si]);
+                PP_AT(DR, si, k + 1) = fabs(rn - raw);
+                PP_AT(XR, si, k + 1) = rn;
+                x = rn;
+            }
+        }
+        __syncthreads();
+    };
+    scan(2, 3, 2);                                            // delta, v from the controls
+    if (valid && c.k < N) {
+        const double dl = PP_AT(XR, 2, c.k), v = PP_AT(XR, 3, c.k);
+        PP_AT(IN, 0, c.k) = v / P.wheelbase * tan(dl);
+        PP_AT(IN, 1, c.k) = v;
+    }
+    __syncthreads();
+    scan(4, 5, NX == 6 ? 2 : 1);                              // psi (and the progress state)
+    if (valid && c.k < N) {
+        double sp, cp;
+        sincos(PP_AT(XR, 4, c.k), &sp, &cp);
+        const double v = PP_AT(XR, 3, c.k);
+        PP_AT(IN, 0, c.k) = v * cp;
+        PP_AT(IN, 1, c.k) = v * sp;
+    }
+    __syncthreads();
+    scan(0, 1, 2);                                            // x, y
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) MPC_K(P.ROLL, NX, 0, i) = PP_AT(XR, i, c.k);
+    }
+    double th = 0.0;
+    if (valid && c.k < 2) {                                   // stage-thread 0 sums the rollout's defects, stage-thread 1 the guess's
+        const double* D = (c.k == 0) ? DR : DG;
+        for (int k = 0; k <= N; ++k) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) th += PP_AT(D, i, k);
+        }
+        if (c.k == 1) A0[2 * bx + bl] = th;
+    }
+    __syncthreads();
+    if (valid && c.k == 0) prestart_decide<NX>(P, c.b, frow, a0lb, a0ub, A0[2 * bx + bl], th);
+#undef PP_AT
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_ingest / k_egest: LDS-tiled transposes between the caller's row-major [B][n_w] buffers (optimizer.py:550 order)
 // and the tile-major workspace.  One workgroup per tile of 64 instances; both the global reads and the global
@@ -1339,7 +1456,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1368,12 +1485,13 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
+    else if (n == "prestart_chains") k.prestart_chains = on != 0;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -1715,7 +1833,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         prof.begin(2, q.st);
         const int n_w = 2 * d.N + NX * (d.N + 1);
         hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
-        hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
+        // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
+        // stage-threads the scans need (otherwise the two-chain kernel)
+        const size_t lds_pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx) * sizeof(double);
+        if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
+            hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
+        else
+            hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
         launch_stage(q, true);
         prof.end(q.st);
     }

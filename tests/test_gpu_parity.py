@@ -100,6 +100,34 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
         assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+@pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5", "ca", "transposed"])
+def test_stage_parallel_start_point_safeguard_equals_the_two_chain_kernel(fam):
+    """k_prestart_par (one thread per instance and stage, three short scans) against k_prestart (two sequential 30-stage chains per
+    instance): same rollout, same decisions, hence the same solve bit for bit -- lane following, the long horizon, collision-avoidance
+    cold starts, and the reference's transposed step-0 state guess, for which the safeguard takes the rollout"""
+    if fam == "ca":
+        cfg, (x0, p) = CA_CFG, ca_batch(CA_CFG, 300)
+    elif fam == "transposed":
+        cfg, kw = FAMILIES["zamlf_n30_nx5"]
+        x0, p = synthetic_batch(cfg, 200, **kw)
+        N, nx = cfg.N, cfg.nx
+        X = x0[:, 2 * N:].reshape(-1, N + 1, nx)
+        x0 = x0.copy()
+        x0[:, 2 * N:] = X.transpose(0, 2, 1).reshape(-1, (N + 1) * nx)       # state guess handed over in the (nx, N+1) order
+    else:
+        cfg, kw = FAMILIES[fam]
+        x0, p = synthetic_batch(cfg, 600, **kw)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    s.set_option("rescue", "0")
+    new = s.solve(x0, p)
+    s.set_option("prestart_chains", "1")
+    old = s.solve(x0, p)
+    assert _same(new, old)
+    if fam == "transposed":
+        assert np.all(new.status == 1)
+
+
 def _same(a, b):
     return np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters) and np.array_equal(a.status, b.status) and np.array_equal(a.kkt, b.kkt)
 
