@@ -236,7 +236,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * "sync_spin" (0: block in the one synchronisation of a solve instead of polling the stream), "max_batch" (instances per chunk: a batch
  * whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway; this lowers the limit),
  * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing",
- * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage)
+ * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage),
+ * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve)
  * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);
 
@@ -254,6 +255,12 @@ int mpc_get_profile(const mpc_handle* h, double out[6]);
  * summed over workers, out[5] = ms the stage workers spent on work items, out[6] = work items processed,
  * out[7] = stage workers + Riccati workers / 1000.                                                          */
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]);
+/* When the last call ran as ONE resident launch (k_resident: a workgroup owns up to 8 instances for all iterations, iterate in registers,
+ * stage blocks / cost-to-go / step in LDS, lane-parallel Riccati sweep; the default for horizons up to 63, option "resident" = 0 turns it
+ * off) both sets of figures above are zero and this reports: out[0] = ms of that launch (profiling enabled only), out[1] = 1 if the
+ * resident path ran, out[2] = rounds (iterations) of the slowest workgroup, out[3] = workgroups of the launch, out[4] = rounds summed
+ * over the workgroups, out[5] = backward Riccati sweeps summed over the workgroups (> out[4] when inertia corrections repeat a sweep). */
+int mpc_get_resident_profile(const mpc_handle* h, double out[8]);
 
 /* debugging: per-iteration per-instance scalars of a host solve.  trace: [max_iter+1, 8, B] doubles
  * rows {mu, theta, phi, alpha, alpha_dual, delta_w, E0, n_trials}; returns iterations launched in *n_it. */

@@ -335,6 +335,13 @@ class BatchedMPCSolver:
         return dict(riccati_ms=out[0], riccati_launches=int(out[1]), stage_ms=out[2], stage_launches=int(out[3]),
                     other_ms=out[4], iterations=int(out[5]))
 
+    def get_resident_profile(self):
+        """Figures of the resident solve (k_resident: one workgroup owns up to 8 instances for all iterations) for the last solve;
+        `ran` is False when the solve used a streaming path (horizons above 63, trace mode, option "resident" = 0)."""
+        out = np.zeros(8)
+        self._check(self._lib.mpc_get_resident_profile(self._h, _abi.as_dp(out)))
+        return dict(ms=out[0], ran=bool(out[1]), rounds=int(out[2]), workgroups=int(out[3]), workgroup_rounds=int(out[4]), sweeps=int(out[5]))
+
     def get_pipeline_profile(self):
         """Figures of the single-launch pipeline (k_pipeline) for the last solve; `ran` is False when the solve used one
         launch per kernel instead (small or very large batches, MPCGPU_PIPELINE=0)."""
