@@ -1,0 +1,445 @@
+// mpc_riccati_mfma.h -- the Riccati factor / solve of ONE instance by ONE wavefront on the fp64 matrix pipe (v_mfma_f64_4x4x4_f64), the
+// KKT solve of the workgroup-resident solve path (k_solve_wg in mpcgpu.hip).  Product code, device only.
+//
+// Why a second formulation.  riccati_tile runs one instance per LANE: 64 instances per wavefront, but a 31-stage chain of ~2 200 ticks
+// per stage whatever the number of live lanes -- 31 us of latency per interior-point iteration.  Here the augmented cost-to-go
+//     M_k = [ P_k  p_k ; p_k'  * ]   (8 x 8: states 0..NX-1, zero rows up to 6, the affine coordinate at index 7)
+// lies ACROSS the 64 lanes of a wavefront and one backward stage is five matrix instructions,
+//     Y = M+ At          T = At' Y + Ht          M = T + Gt' Kt (+ delta_w I)          with  Gt = B'Y + [Hux | gu],  Kt = -Lam^-1 Gt
+// (At = [A -c; 0 1], Ht = [H gx; gx' 0]: the affine terms ride along as row / column 7, so p_k and k_ff need no recursion of their
+// own), ~210 ticks of dependent latency per stage instead of ~2 200.  The forward sweep is two matrix instructions per stage:
+// x_{k+1} = (At + Bt Kt) x_k in block column 0 and du_k = Kt x_k in block column 1 of the same products.
+//
+// Lane map of v_mfma_f64_4x4x4_f64 (4 blocks of 4x4x4, one double per lane and operand; measured with tools/ubench/mfma_probe.hip, the
+// guide documents the 16x16x4 form only): lane L = 16 x + 4 blk + y,
+//     A operand: A_blk[i = y][k = x]      B operand: B_blk[k = x][j = y]      C / D: D_blk[i = x][j = y].
+// An 8 x 8 matrix is 2 x 2 blocks, blk = 2 I + J: "natural" (= D) layout M[4 I + x][4 J + y], i.e. row R = 4 * bit3(L) + (L >> 4),
+// column C = L & 7.  A product X Y takes two instructions (k-steps K = 0, 1) whose operands are natural-layout registers with their
+// 4-lane banks moved inside each 16-lane row -- DPP row shifts with a bank mask, no LDS:
+//     B operand of k-step K = banks of Y  [b0 b1 b0 b1] (K = 0) / [b2 b3 b2 b3] (K = 1)
+//     A operand of k-step K = banks of X' [b0 b0 b1 b1] (K = 0) / [b2 b2 b3 b3] (K = 1)      (X' = the TRANSPOSE of X in natural layout:
+//                                                                                            a D register used as A operand is read transposed)
+// M+ is symmetric, so its own register serves as X' of the first product; At and Ht are read from the LDS record of the stage with
+// per-lane offsets (every lane knows which entry of the sparse At it needs).  The two rows of Gt come down from rows 2, 3 of Y with
+// v_permlane32_swap, their partner rows for Kt = -Lam^-1 Gt with a ds_swizzle (swap of 16-lane rows), Lam^-1 is computed by every lane
+// from three v_readlane of M+.
+//
+// Reference: the linear solve inside IPOPT's step computation for the NLP of MPC_Planner/optimizer.py:373-558 (the reference hands it
+// to MUMPS); recursion and inertia-correction schedule as riccati_instance (mpc_stage_math.h).  The rounding differs from the
+// one-instance-per-lane recursion (dense 8 x 8 products instead of the sparse update): results agree to ~1e-13 relative.
+#pragma once
+#include <type_traits>
+#include "mpc_stage_math.h"
+
+namespace mpc {
+
+// LDS record of one (instance, stage), in doubles: the stage block as phase_finish stores it (BLK rows; the defect negated), three
+// constants for the "no entry" / identity / dt offsets, and the gain rows the backward sweep leaves for the forward sweep
+template <int NX>
+struct Rec {
+    using D = Dim<NX>;
+    static constexpr int A = D::B_A, RUU = D::B_RUU, GU = D::B_GU, NCN = D::B_CN, GX = D::B_GX, H = D::B_H;
+    static constexpr int ZERO = D::NBLK, ONE = ZERO + 1, DT = ZERO + 2;
+    static constexpr int K0 = (DT + 2) & ~1, K1 = K0 + 8;        // Kt rows: [K0 (NX) | 0.. | kff0], [K1 | .. | kff1]
+    static constexpr int HX = K1 + 8;                            // 2: Hux of stage 0 (zero in every other stage)
+    static constexpr int DUMMY = HX + 2;                         // target of the lanes that have no gain entry to write
+    static constexpr int SIZE = DUMMY + 2;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+
+// ---- cross-lane primitives on doubles ---------------------------------------------------------------------------------------------
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double wv_dpp(double old, double src) {
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANKS, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_SHL4 = 0x104, DPP_SHL8 = 0x108, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118;     // row_shl: lane <- lane + n, row_shr: lane <- lane - n
+// B operand of k-step K from a natural-layout register
+template <int K>
+__device__ __forceinline__ double wv_opB(double v) {
+    if (K == 0) return wv_dpp<DPP_SHR8, 0xC>(v, v);           // [b0 b1 b0 b1]
+    return wv_dpp<DPP_SHL8, 0x3>(v, v);                       // [b2 b3 b2 b3]
+}
+// A operand of k-step K from the natural-layout register of the TRANSPOSED left factor
+template <int K>
+__device__ __forceinline__ double wv_opA(double v) {
+    if (K == 0) {
+        const double t = wv_dpp<DPP_SHR4, 0x6>(v, v);         // [b0 b0 b1 b3]
+        return wv_dpp<DPP_SHR8, 0x8>(t, v);                   // [b0 b0 b1 b1]
+    }
+    const double t = wv_dpp<DPP_SHL4, 0x6>(v, v);             // [b0 b2 b3 b3]
+    return wv_dpp<DPP_SHL8, 0x1>(t, v);                       // [b2 b2 b3 b3]
+}
+// every bank <- bank 2K (block column 0 of block row K): the B operand of the forward sweep
+template <int K>
+__device__ __forceinline__ double wv_bcast(double v) {
+    if (K == 0) {
+        const double t = wv_dpp<DPP_SHR4, 0x2>(v, v);         // [b0 b0 b2 b3]
+        return wv_dpp<DPP_SHR8, 0xC>(t, t);                   // [b0 b0 b0 b0]
+    }
+    double t = wv_dpp<DPP_SHL8, 0x1>(v, v);                   // [b2 b1 b2 b3]
+    t = wv_dpp<DPP_SHR4, 0x8>(t, v);                          // [b2 b1 b2 b2]
+    return wv_dpp<DPP_SHL4, 0x2>(t, v);                       // [b2 b2 b2 b2]
+}
+// lanes 0..31 <- lanes 32..63 of v, lanes 32..63 <- 0
+__device__ __forceinline__ double wv_upper_to_lower(double v) {
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), 0u, false, false);
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), 0u, false, false);
+    return __hiloint2double((int)h[1], (int)l[1]);
+}
+// 16-lane rows swapped inside each half of the wavefront
+__device__ __forceinline__ double wv_swap16(double v) {
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F));
+}
+__device__ __forceinline__ double wv_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wv_bpermute(double v, int byte_addr) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+}
+__device__ __forceinline__ double wv_mfma(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// ---- per-lane constants: which entries of the stage record this lane feeds into which operand ------------------------------------------
+// lane L = 16 x + 8 hi + 4 lo + y  (hardware block (hi, lo))
+template <int NX>
+struct MfmaLane {
+    int oB[2], oAA[2], oHC, oHA;        // backward: At as B operand of Y (per block column J) / as transposed A operand of T (per k-step), Ht, [Hux | gu]
+    int oF1, oF2;                       // forward: A operand = rec[oF1] + fscale * rec[oF2]
+    double fscale, dmask;               // dmask: 1 on the diagonal of the state block (delta_w goes there)
+    int pk_row;                         // row of the PK array this lane stores (P_k upper triangle, p_k), or -1
+    int tr_addr;                        // byte address of the transposed lane (ds_bpermute), for the symmetrisation
+    int k_off;                          // backward: where this lane writes its entry of Kt (or the dummy slot)
+    int dz_row;                         // forward: row of the DZ array this lane stores (du: 0, 1; dx: 2 + R), or -1
+    bool dz_next;                       // ... of stage k + 1 (the dx lanes)
+    int fix;                            // forward: 0 = keep the product, 1 = coordinate forced to 0 (spare row), 2 = forced to 1 (affine coordinate)
+    int R, C, Rb;                       // natural row / column; row of x~ this lane carries as B operand of the forward sweep
+};
+
+template <int NX>
+__device__ __forceinline__ int rec_aoff(int r, int c) {
+    using RC = Rec<NX>;
+    if (r < NX && c < NX) {
+        if (r == c) return RC::ONE;
+        if (r == 0 && c == 3) return RC::A + 0;
+        if (r == 0 && c == 4) return RC::A + 1;
+        if (r == 1 && c == 3) return RC::A + 2;
+        if (r == 1 && c == 4) return RC::A + 3;
+        if (r == 4 && c == 2) return RC::A + 4;
+        if (r == 4 && c == 3) return RC::A + 5;
+        if (NX == 6 && r == 5 && c == 3) return RC::DT;
+        return RC::ZERO;
+    }
+    if (r < NX && c == 7) return RC::NCN + r;
+    if (r == 7 && c == 7) return RC::ONE;
+    return RC::ZERO;
+}
+template <int NX>
+__device__ __forceinline__ int rec_hoff(int r, int c) {
+    using RC = Rec<NX>;
+    if (r < NX && c < NX) {
+        const int i = r < c ? r : c, j = r < c ? c : r;
+        const int hr = i == j ? i : (i == 0 && j == 1) ? NX : (i == 0 && j == 4) ? NX + 1 : (i == 1 && j == 4) ? NX + 2 : (i == 2 && j == 3) ? NX + 3
+                     : (i == 3 && j == 4) ? NX + 4 : -1;                                          // (Dim::hrow with run-time arguments)
+        return hr >= 0 ? RC::H + hr : RC::ZERO;
+    }
+    if (r < NX && c == 7) return RC::GX + r;
+    if (r == 7 && c < NX) return RC::GX + c;
+    return RC::ZERO;
+}
+
+template <int NX>
+__device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, int lane, double dt) {
+    using RC = Rec<NX>;
+    using D = Dim<NX>;
+    const int x = lane >> 4, hi = (lane >> 3) & 1, lo = (lane >> 2) & 1, y = lane & 3;
+    m.R = 4 * hi + x;
+    m.C = lane & 7;
+    m.Rb = 4 * hi + x;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        m.oB[q] = rec_aoff<NX>(4 * hi + x, 4 * q + y);        // block (hi, lo) of the B operand of column block q: At_{hi, q}
+        m.oAA[q] = rec_aoff<NX>(4 * q + x, 4 * hi + y);       // k-step q: (At')_{hi, q} read transposed
+    }
+    m.oHC = rec_hoff<NX>(m.R, m.C);
+    // rows x = 0, 1 of Gt live in both halves (hi) of the 16-lane rows: [Hux | gu] is added there
+    m.oHA = (x < 2 && m.C == 7) ? RC::GU + x : (x == 1 && m.C == 2) ? RC::HX : (x == 1 && m.C == 3) ? RC::HX + 1 : RC::ZERO;
+    m.dmask = (m.R == m.C && m.R < NX) ? 1.0 : 0.0;
+    m.pk_row = -1;
+    if (m.R < NX && m.C < NX && m.R <= m.C) m.pk_row = D::sidx(m.R, m.C);
+    if (m.R < NX && m.C == 7) m.pk_row = D::NS + m.R;
+    m.tr_addr = (16 * y + 8 * lo + 4 * hi + x) * 4;
+    m.k_off = (x < 2 && hi == 0) ? ((x == 0 ? RC::K0 : RC::K1) + m.C) : RC::DUMMY;
+    // forward sweep: hardware block (hi = K, lo = I) holds Acl'_{I K}, read transposed: A_blk[i = y][k = x] = Acl'[4 lo + y][4 hi + x]
+    {
+        const int r = 4 * lo + y, c = 4 * hi + x;
+        if (r < NX) { m.oF1 = rec_aoff<NX>(r, c); m.oF2 = (r == 2) ? RC::K0 + c : (r == 3) ? RC::K1 + c : RC::ZERO; m.fscale = dt; }
+        else { m.oF1 = RC::ZERO; m.oF2 = (r == 6) ? RC::K0 + c : (r == 7) ? RC::K1 + c : RC::ZERO; m.fscale = 1.0; }
+    }
+    // the product of the forward sweep, summed over hi: lane (x, *, lo, y = 0) carries row 4 lo + x: states, du_0 (row 6), du_1 (row 7)
+    {
+        const int r = 4 * lo + x;
+        m.dz_row = -1;
+        m.dz_next = false;
+        m.fix = 0;
+        if (y == 0 && hi == 0) {
+            if (r < NX) { m.dz_row = 2 + r; m.dz_next = true; }
+            else if (r >= 6) m.dz_row = r - 6;
+        }
+        if (r == 7) m.fix = 2; else if (r >= NX) m.fix = 1;
+        if (y != 0) m.fix = 1;
+    }
+}
+
+// What the sweeps need to know about the instance (wave-uniform)
+struct MfmaInst {
+    uint32_t ws_lane_off;      // byte offset of the instance inside its tile-major rows: tile * tile_elems * 8 + (b & 63) * 16
+    double delta_last;
+};
+
+// 1 / d for the 2 x 2 determinant: v_rcp_f64 + two Newton steps (the IEEE division sequence is twice as long and sits on the
+// critical path of every stage; the quotient only scales Lam^-1, whose rounding the recursion does not depend on)
+__device__ __forceinline__ double wv_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+// x + (x with the two halves of every 16-lane row exchanged): the sum over the block index hi, left in both halves
+__device__ __forceinline__ double wv_sum_hi(double v) {
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x128, 0xF, 0xF, false);       // row_ror:8
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x128, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+
+// ---- backward sweeps of NI instances of one wavefront, interleaved (independent dependency chains in one instruction stream: the
+// wavefront issues in order, so a second instance fills the latencies of the first).  ok[q] = false: no admissible delta_w (status -7).
+// rec[q]: LDS records of instance q, stage k at rec[q] + k * Rec::SIZE; one more record in FRONT of every instance's records must be
+// readable (the operand prefetch of stage 0 reads "stage -1").  dump: 64 doubles of LDS the lanes without a gain entry may write.  Writes the Kt rows into the records and P_k / p_k into the PK rows of the workspace (lanes
+// without an entry write row 0 of the KK array, which this path does not use: no divergent store).
+//
+// One stage, with M = M+ in natural layout (symmetric: as A operand its block (hi, lo) is read as M_{lo, hi}):
+//   column block J of Y = M+ At:  D = mfma(M, At_{hi, J}) gives M_{lo, hi} At_{hi, J} in block (hi, lo); the sum over hi (one DPP row
+//                                 rotation + add) leaves Y_{lo, J} in both halves -- S_J, two independent instructions instead of a chain
+//   B operands of T = At' Y + Ht: k-step K needs Y_{K, lo}: banks of S_0 / S_1 merged by one DPP each
+//   Gt rows come down from rows 2, 3 of the first of them (v_permlane32_swap) already replicated over hi, so Kt = -Lam^-1 Gt is the B
+//   operand of the rank-2 update as it stands and Gt' needs ONE bank move
+template <int NX, int NI>
+__device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
+                                              int lane, mpc_lds_ptr dump, double (&delta)[NI], bool (&ok)[NI], uint32_t& sweeps) {
+    using RC = Rec<NX>;
+    using D = Dim<NX>;
+    const int N = P.N;
+    const double dt = P.dt, dt2 = dt * dt;
+    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    constexpr uint32_t PKS = MPC_EV(D::NPK) * 512u;                       // bytes per stage of the PK rows
+    const uint32_t pk_arr = (uint32_t)(uintptr_t)P.PK - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
+    const uint32_t pk_lane = m.pk_row >= 0 ? pk_arr + mpc_prow((uint32_t)m.pk_row) * 8u + (uint32_t)N * PKS : kk_arr, pk_inc = m.pk_row >= 0 ? PKS : 0u;
+    const int x = lane >> 4;
+    // where a lane writes its entry of Kt, as an offset from the records of the instance: the writers walk down the stages, the others
+    // stay on their own double of the dump area (a shared dummy address would serialise 48 lanes on one LDS bank)
+    const bool writer = m.k_off != RC::DUMMY;
+    const int w_inc = writer ? RC::SIZE : 0;
+    int w_first[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) w_first[q] = writer ? N * RC::SIZE + m.k_off : (int)(dump - rec[q]) + lane;
+    bool need[NI], sym[NI];
+    int pkb[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        delta[q] = 0.0;
+        need[q] = true;
+        ok[q] = false;
+        sym[q] = in[q].delta_last != 0.0;
+        pkb[q] = mpc_uni(in[q].ws_lane_off);
+    }
+    for (;;) {
+        ++sweeps;
+        bool symm = false;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) symm = symm || sym[q] || delta[q] != 0.0;
+        double M[NI], b0[NI], b1[NI], aa0[NI], aa1[NI], hc[NI], ha[NI], ruu0[NI], ruu1[NI];
+        bool good[NI];
+        uint32_t voff = pk_lane;
+        int wdec = 0;
+        // terminal stage: M_N = Ht_N + delta_w I
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            mpc_lds_ptr r = rec[q] + N * RC::SIZE;
+            M[q] = r[m.oHC] + delta[q] * m.dmask;
+            good[q] = true;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff, pkb[q], 0);
+            r = rec[q] + (N - 1) * RC::SIZE;
+            b0[q] = r[m.oB[0]]; b1[q] = r[m.oB[1]]; aa0[q] = r[m.oAA[0]]; aa1[q] = r[m.oAA[1]]; hc[q] = r[m.oHC]; ha[q] = r[m.oHA];
+            ruu0[q] = r[RC::RUU]; ruu1[q] = r[RC::RUU + 1];
+        }
+        auto stage = [&](auto sym_tag, int k) {
+            constexpr bool SYM = decltype(sym_tag)::value;
+            voff -= pk_inc;
+            wdec += w_inc;
+            double nb0[NI], nb1[NI], naa0[NI], naa1[NI], nhc[NI], nha[NI], nruu0[NI], nruu1[NI];
+            double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], i00[NI], i01[NI], i11[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
+            // The wavefront issues in order: the scalar chain Lam -> det -> 1 / det (ten dependent instructions) is cut into pieces that
+            // are laid between the steps of the matrix chain, and the scheduling fences keep the compiler from clumping them again.
+#define MPC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {        // operands of the next stage (software pipeline; stage -1 reads the pad record)
+                mpc_lds_ptr rn = rec[q] + (k - 1) * RC::SIZE;
+                nb0[q] = rn[m.oB[0]]; nb1[q] = rn[m.oB[1]]; naa0[q] = rn[m.oAA[0]]; naa1[q] = rn[m.oAA[1]]; nhc[q] = rn[m.oHC]; nha[q] = rn[m.oHA];
+                nruu0[q] = rn[RC::RUU]; nruu1[q] = rn[RC::RUU + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {        // Y = M+ At, one instruction per column block; Lam = Ruu + B'P+B (+ delta_w)
+                const double P22 = wv_readlane(M[q], 34), P23 = wv_readlane(M[q], 35), P33 = wv_readlane(M[q], 51);
+                S0[q] = wv_mfma(M[q], b0[q], 0.0);
+                S1[q] = wv_mfma(M[q], b1[q], 0.0);
+                L00[q] = ruu0[q] + dt2 * P22 + delta[q]; L01[q] = dt2 * P23; L11[q] = ruu1[q] + dt2 * P33 + delta[q];
+            }
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) det[q] = fma(L00[q], L11[q], -(L01[q] * L01[q]));
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { rc[q] = __builtin_amdgcn_rcp(det[q]); S0[q] = wv_sum_hi(S0[q]); }       // S0: lane (x, *, lo, y) = Y[4 lo + x][y]
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { er[q] = fma(-det[q], rc[q], 1.0); S1[q] = wv_sum_hi(S1[q]); }           // S1:                    = Y[4 lo + x][4 + y]
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { rc[q] = fma(er[q], rc[q], rc[q]); B0[q] = wv_dpp<DPP_SHR4, 0xA>(S0[q], S1[q]); }   // k-step 0: block (hi, lo) = Y_{0, lo}
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                er[q] = fma(-det[q], rc[q], 1.0);
+                B1[q] = wv_dpp<DPP_SHL4, 0x5>(S1[q], S0[q]);                       // k-step 1: block (hi, lo) = Y_{1, lo}
+                T[q] = wv_mfma(aa0[q], B0[q], hc[q]);                              // T = At' Y + Ht
+            }
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                rc[q] = fma(er[q], rc[q], rc[q]);
+                // Gt = dt * rows (2, 3) of Y + [Hux | gu] in rows x = 0, 1 (both halves)
+                G[q] = dt * wv_upper_to_lower(B0[q]) + ha[q];
+                T[q] = wv_mfma(aa1[q], B1[q], T[q]);
+            }
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                Gs[q] = wv_swap16(G[q]);
+                good[q] = good[q] && (L00[q] > 0.0) && (det[q] > 0.0);
+                i00[q] = L11[q] * rc[q]; i01[q] = -L01[q] * rc[q]; i11[q] = L00[q] * rc[q];
+            }
+            MPC_FENCE();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const double ca = (x == 0) ? -i00[q] : -i11[q];
+                const double GA = wv_dpp<DPP_SHL4, 0x6>(G[q], G[q]);               // block (hi, lo) = column block hi of Gt (read transposed)
+                Kt[q] = ca * G[q] - i01[q] * Gs[q];                                // Kt = -Lam^-1 Gt
+                M[q] = wv_mfma(GA, Kt[q], T[q]) + delta[q] * m.dmask;              // M = T + Gt' Kt + delta_w I
+                if (SYM) M[q] = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr));
+                rec[q][w_first[q] - wdec] = Kt[q];                                              // gains for the forward sweep (lanes without an entry: the dump area)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff, pkb[q], 0);   // cost-to-go for the stage threads
+                b0[q] = nb0[q]; b1[q] = nb1[q]; aa0[q] = naa0[q]; aa1[q] = naa1[q]; hc[q] = nhc[q]; ha[q] = nha[q]; ruu0[q] = nruu0[q]; ruu1[q] = nruu1[q];
+            }
+#undef MPC_FENCE
+        };
+        auto alive = [&]() {
+            bool a = false;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) a = a || (need[q] && good[q]);
+            return __builtin_amdgcn_ballot_w64(a) != 0ull;
+        };
+        // (a sweep whose every instance has met an indefinite Lam is abandoned: it is repeated with a larger delta_w anyway)
+        // (two stages per trip: the operand registers of the software pipeline swap roles without copies)
+        if (__builtin_amdgcn_ballot_w64(symm) != 0ull) {
+            int k = N - 1;
+            for (; k >= 1 && alive(); k -= 2) { stage(std::true_type{}, k); stage(std::true_type{}, k - 1); }
+            if (k == 0 && alive()) stage(std::true_type{}, 0);
+        } else {
+            int k = N - 1;
+            for (; k >= 1 && alive(); k -= 2) { stage(std::false_type{}, k); stage(std::false_type{}, k - 1); }
+            if (k == 0 && alive()) stage(std::false_type{}, 0);
+        }
+        bool again = false;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            if (!need[q]) continue;
+            if (good[q]) { need[q] = false; ok[q] = true; continue; }
+            // IPOPT's inertia-correction schedule (Waechter & Biegler section 3.1), as riccati_instance
+            if (delta[q] == 0.0) delta[q] = (in[q].delta_last == 0.0) ? DW_0 : fmax(DW_MIN, KW_MINUS * in[q].delta_last);
+            else delta[q] *= (in[q].delta_last == 0.0) ? KW_PLUS_BAR : KW_PLUS;
+            if (delta[q] > DW_MAX) need[q] = false; else again = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(again) == 0ull) return;
+    }
+}
+
+// ---- forward sweeps of NI instances: dz_k = (du_k, dx_k) into the DZ rows of the workspace ----------------------------------------------
+// One matrix instruction per stage: x~' = Acl' x~ with Acl' = At + Bt Kt in the state rows and the two rows of Kt in rows 6, 7 (the
+// affine coordinate is put back by hand), the k index spread over the hardware blocks (block (hi, lo) = Acl'_{lo, hi} x~_hi) and summed over
+// hi by a DPP row rotation.  x0[q]: B-operand register, lane (x, hi, *, 0) = x~_0[4 hi + x] (the affine coordinate 7 holds 1), zero for y != 0.
+// Lanes without an entry to store write row 0 of the unused KK array (no divergent store).
+template <int NX, int NI>
+__device__ __forceinline__ void mfma_forward(const Params& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
+                                             const double (&x0)[NI], const bool (&ok)[NI]) {
+    using D = Dim<NX>;
+    using RC = Rec<NX>;
+    const int N = P.N;
+    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    constexpr uint32_t DZS = MPC_EV(D::NZ) * 512u;
+    const bool st = m.dz_row >= 0;
+    const uint32_t dz_arr = (uint32_t)(uintptr_t)P.DZ - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
+    // per-lane running offset: storing lanes walk the DZ rows (the dx lanes one stage ahead), the others stay on the dump row
+    uint32_t voff = st ? dz_arr + mpc_prow((uint32_t)m.dz_row) * 8u + (m.dz_next ? DZS : 0u) : kk_arr;
+    const uint32_t inc = st ? DZS : 0u;
+    const double fixval = (m.fix == 2) ? 1.0 : 0.0;
+    const bool fix = m.fix != 0;
+    double X[NI], f1[NI], f2[NI];
+    int base[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        X[q] = x0[q];
+        base[q] = mpc_uni(in[q].ws_lane_off);
+        // dx_0: the storing lanes (x, hi = 0, lo, 0) want row 4 lo + x, the operand layout carries row 4 hi + x: one bank move
+        if (ok[q]) {
+            const double xs = wv_dpp<DPP_SHR4, 0x2>(X[q], wv_dpp<DPP_SHL8, 0x1>(X[q], X[q]));      // bank (0, 1) <- bank (1, *)
+            if (m.dz_next) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, xs), rsrc, (int)(voff - DZS), base[q], 0);
+        }
+        mpc_lds_cptr r = rec[q];
+        f1[q] = r[m.oF1]; f2[q] = r[m.oF2];
+    }
+    auto fstage = [&](int k) {
+        double n1[NI], n2[NI], S[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            mpc_lds_cptr rn = rec[q] + (k + 1) * RC::SIZE;                                  // (stage N: the terminal record, read and not used)
+            n1[q] = rn[m.oF1]; n2[q] = rn[m.oF2];
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) S[q] = wv_mfma(f1[q] + m.fscale * f2[q], X[q], 0.0);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            S[q] = wv_sum_hi(S[q]);                                              // lane (x, *, lo, 0) = x~'[4 lo + x]: dx_{k+1}, du_k in rows 6, 7
+            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, S[q]), rsrc, (int)voff, base[q], 0);
+            S[q] = fix ? fixval : S[q];
+            X[q] = wv_dpp<DPP_SHL4, 0x6>(S[q], S[q]);                            // block (hi, lo) <- x~_hi
+            f1[q] = n1[q]; f2[q] = n2[q];
+        }
+        voff += inc;
+    };
+    {
+        int k = 0;
+        for (; k + 1 < N; k += 2) { fstage(k); fstage(k + 1); }
+        if (k < N) fstage(k);
+    }
+    if (st && !m.dz_next) {                                                  // du_N = 0
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, 0.0), rsrc, (int)voff, base[q], 0);
+    }
+}
+
+#endif   // __HIP_DEVICE_COMPILE__
+
+}  // namespace mpc

@@ -36,6 +36,7 @@
 #include "mpc_closed_loop.h"
 #include "mpc_forces_qp.h"
 #include "mpc_riccati_lanes.h"
+#include "mpc_riccati_mfma.h"
 
 using namespace mpc;
 
@@ -275,7 +276,7 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
 // instance of the tile is iterating, nothing was touched)
 template <int NX>
-__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem, const bool stamp = true) {
+__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem, const bool stamp = true, const int handover_live = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
@@ -296,6 +297,9 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
     const bool active = (b < P.B) && ((int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING);
     const unsigned long long act_mask = __ballot(active ? 1 : 0);
     if (act_mask == 0ull) return 0ull;                              // all waves see the same 64 instances
+    // hybrid solve: a tile with this few instances left is no longer worth a 31-stage pass of a whole wavefront -- it leaves the
+    // pipeline untouched, k_solve_wg (one wavefront per instance, MFMA Riccati) finishes its instances behind this launch
+    if (__popcll(act_mask) <= handover_live) return 0ull;
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
@@ -501,6 +505,7 @@ struct PipeArgs {
     uint32_t n_ric;         // Riccati workers per XCD (the first arrivals)
     uint32_t cap;           // ready-queue slots per XCD, a power of two >= 2 * items of one XCD
     uint32_t items;         // stage work items per tile = 64 / bx
+    uint32_t handover;      // a tile with at most this many instances still iterating leaves the pipeline (0: tiles run to the end)
     uint32_t flags;         // bit 0: producers also issue an agent-scope release (MPCGPU_PIPE_RELEASE: the protocol that does not
                             // rely on a tile staying inside one L2; same results, 10-17 % slower); bit 1: raise the abort word at
                             // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path)
@@ -582,7 +587,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                 lds_barrier();
                 if (sh_word[1] == 0u) return;
                 PIPE_STAMP(12);
-                const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds), n_pass == 5u);
+                const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds), n_pass == 5u, (int)A.handover);
                 if (mask == 0ull) {
                     fin |= 1u << j;
                     if (t == 0) {
@@ -855,6 +860,151 @@ __global__ void __launch_bounds__(256) k_resident(const Params P, const int n_mu
     }
 #undef RES_STAMP
     res_store<NX>(P, c);
+    if (stats != nullptr && t == 0) {
+        atomicMax(stats + 0, rounds);
+        atomicAdd(stats + 1, rounds);
+        atomicAdd(stats + 2, sweeps);
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_solve_wg: ALL iterations of `bx` instances by ONE workgroup that never lets go of them -- the workgroup-resident solve path.
+// k_pipeline chains two latencies per interior-point iteration (a 31-stage one-instance-per-lane Riccati pass of a 64-instance tile,
+// 42 us whatever the number of live lanes, and a stage work item, 24 us) plus two hand-offs between workgroups, and a launch lasts
+// as many such rounds as its SLOWEST instance needs while most tiles idle through the tail.  Here every workgroup cycles on its own:
+//     stage blocks (workspace rows written by phase_finish) -> LDS records
+//     wave-per-instance MFMA Riccati (mpc_riccati_mfma.h): backward sweep, forward sweep; P_k / p_k and the step go to the workspace
+//     stage_block: the SAME stage phases as every other path (line search, update, derivatives, KKT error, condensed blocks)
+// No queue, no hand-off between workgroups, no Riccati role: a workgroup leaves when its last instance is done and the hardware
+// dispatcher hands the CU to the next workgroup of the grid.  The rows stay in the tile-major workspace (they are this CU's own
+// and come back from the L2), so the stage phases are bit-for-bit those of the other paths; only the KKT solve rounds differently.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NX>
+__global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int or_slots[2][8];
+    __shared__ uint32_t sh_mask;
+    if (skip_if != nullptr && *skip_if != 0u) return;          // the pipeline launch in front of this one was abandoned: the host starts over
+    using D = Dim<NX>;
+    using RC = Rec<NX>;
+    const int bx = P.bx, t = threadIdx.x, N = P.N;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nw = (int)(blockDim.x >> 6);
+    const uint32_t b0 = (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
+    struct { int b, k; } c;                      // (the workspace accessors are written in terms of c.b / c.k)
+    c.k = t / bx;
+    c.b = (int)b0 + (t & (bx - 1));
+    const bool valid = (c.k <= N) && (c.b < P.B);
+    // LDS of the sweeps (aliases the stage phases' region): [dump area of the sweeps, 64 doubles per wavefront | one pad record | records]
+    const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * nw + RC::SIZE;
+    const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * wave;
+#define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    uint32_t rounds = 0, sweeps = 0;
+    for (;;) {
+        // ---- which of my instances are iterating (status rows of the workspace; written by phase_finish / the sweeps below)
+        if (t < 64) {
+            const int bb = (int)b0 + t;
+            const bool run = t < bx && bb < P.B && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb) == ST_RUNNING;
+            const unsigned long long mk = __ballot(run ? 1 : 0);
+            if (t == 0) sh_mask = (uint32_t)mk;
+        }
+        lds_barrier();
+        const uint32_t mask = sh_mask;
+        if (mask == 0u) break;
+        ++rounds;
+        WG_STAMP(12);
+        // ---- stage blocks -> LDS records, instance-major (every stage thread its own; defect negated, three constants, Hux of stage 0)
+        if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
+            double blk[MPC_EV(D::NBLK)];
+            ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
+            double hx0 = 0.0, hx1 = 0.0;
+            if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
+            const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
+#pragma unroll
+            for (int i = 0; i < D::NBLK; ++i) r[i] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
+            r[RC::ZERO] = 0.0;
+            r[RC::ONE] = 1.0;
+            r[RC::DT] = P.dt;
+            r[RC::HX] = hx0;
+            r[RC::HX + 1] = hx1;
+        }
+        lds_barrier();
+        WG_STAMP(13);
+        // (per-lane operand offsets of the sweeps: rebuilt every round from a lane id the compiler cannot see through, so that they are
+        //  not hoisted out of the loop and kept in registers across stage_block)
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        MfmaLane<NX> m;
+        mfma_lane_setup<NX>(m, lane_v, P.dt);
+        // ---- KKT solves: wave w takes instances w and w + nw of the block (interleaved in one instruction stream), then w + 2 nw, ...
+        {
+            auto inst_of = [&](int g, MfmaInst& in, double& x0) {
+                const int bb = (int)b0 + g;
+                in.ws_lane_off = ((uint32_t)bb >> 6) * P.tile_elems * 8u + ((uint32_t)bb & 63u) * 16u;
+                in.delta_last = MPC_UB(P.SC, (uint32_t)SC_DLAST, bb);
+                // x~_0 = (-c_0, 0.., 1) as B operand of the forward sweep (requested now, needed after the backward sweep)
+                x0 = 0.0;
+                if ((lane & 3) == 0) {
+                    if (m.Rb < NX) x0 = -(double)ws_ref3(P, P.SC, 0u, (uint32_t)bb, mpc_prow((uint32_t)(SC_C0 + m.Rb)));
+                    else if (m.Rb == 7) x0 = 1.0;
+                }
+            };
+            auto finish = [&](int g, bool ok, double delta) {
+                const int bb = (int)b0 + g;
+                if (lane != 0) return;
+                if (ok) {
+                    if (delta > 0.0) MPC_UB(P.SC, (uint32_t)SC_DLAST, bb) = delta;
+                    MPC_UB(P.SC, (uint32_t)SC_DELTA, bb) = delta;
+                } else {
+                    MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb) = -7;
+                }
+            };
+            // the live instances of this wave, in pairs
+            uint32_t mine = 0u;
+            for (int g = wave; g < bx; g += nw) mine |= mask & (1u << g);
+            while (mine) {
+                const int g0 = __builtin_ctz(mine);
+                mine &= mine - 1u;
+                if (mine) {
+                    const int g1 = __builtin_ctz(mine);
+                    mine &= mine - 1u;
+                    MfmaInst in[2];
+                    double x0[2], delta[2];
+                    bool ok[2];
+                    inst_of(g0, in[0], x0[0]);
+                    inst_of(g1, in[1], x0[1]);
+                    const mpc_lds_ptr rec[2] = {recs + g0 * (N + 1) * RC::SIZE, recs + g1 * (N + 1) * RC::SIZE};
+                    mfma_backward<NX, 2>(P, m, in, rec, lane, dump, delta, ok, sweeps);
+                    mfma_forward<NX, 2>(P, m, in, rec, x0, ok);
+                    finish(g0, ok[0], delta[0]);
+                    finish(g1, ok[1], delta[1]);
+                } else {
+                    MfmaInst in[1];
+                    double x0[1], delta[1];
+                    bool ok[1];
+                    inst_of(g0, in[0], x0[0]);
+                    const mpc_lds_ptr rec[1] = {recs + g0 * (N + 1) * RC::SIZE};
+                    mfma_backward<NX, 1>(P, m, in, rec, lane, dump, delta, ok, sweeps);
+                    mfma_forward<NX, 1>(P, m, in, rec, x0, ok);
+                    finish(g0, ok[0], delta[0]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // cost-to-go and step are in the L2
+        lds_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // (this CU's vector L1 may hold the rows of the last round)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG_STAMP(14);
+        // ---- the stage work of the round
+        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
+        lds_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG_STAMP(15);
+    }
+#undef WG_STAMP
     if (stats != nullptr && t == 0) {
         atomicMax(stats + 0, rounds);
         atomicAdd(stats + 1, rounds);
@@ -1650,7 +1800,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 1, res_timing = 0;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 0, hybrid_bx = 1, hybrid_live = -1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1680,14 +1830,17 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
     else if (n == "prestart_chains") k.prestart_chains = on != 0;
-    else if (n == "resident") k.resident = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "resident") k.resident = value == nullptr ? 0 : (int)iv;
     else if (n == "res_timing") k.res_timing = on != 0;
+    else if (n == "hybrid") k.hybrid = value == nullptr ? 0 : (int)iv;
+    else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 1 : (int)iv;
+    else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -1951,7 +2104,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
     int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     // resident solve (k_resident): a workgroup owns up to 8 instances (one lane group of the Riccati wavefront each) for all iterations
-    bool use_res = kn.resident && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
+    // workgroup-resident solve (k_solve_wg, option resident = 2): the stage phases of the streaming paths + a wave-per-instance MFMA Riccati
+    const bool use_wg = kn.resident == 2 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
+    bool use_res = kn.resident == 1 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
     if (use_res) {
         const int bxr = std::min(bx, 8), thr = ((((int)d.N + 1) * bxr + 63) / 64) * 64;
         const int srows = MPC_STAGE_STASH ? std::max(Stash<NX>::rows(h->hp.has_ou != 0), 2 * NX) : 2 * NX;
@@ -1992,6 +2147,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resident<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
         }
     }
@@ -2092,19 +2248,41 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     h->last_mode = 0;
     for (int i = 0; i < 8; ++i) { h->pipe_prof[i] = 0; h->res_prof[i] = 0; }
     bool piped = false;
-    if (use_res) {
-        // ---- resident solve: start iterate + ALL iterations of every instance in one launch, one workgroup per bx instances
+    // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
+    auto wg_lds = [&](int bxw) {
+        const int thr = ((S * bxw + 63) / 64) * 64;
+        return std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
+                        ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double));
+    };
+    auto launch_wg = [&](int bxw, const uint32_t* skip_if) {
+        Params Pw = P;
+        Pw.bx = bxw;
+        const int thr = ((S * bxw + 63) / 64) * 64;
+        hipLaunchKernelGGL((k_solve_wg<NX>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, h->d_fail + 2, skip_if);
+    };
+    // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
+    // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
+    int hyb_bx = (kn.hybrid_bx == 2 && S * 2 <= 64) ? 2 : 1;
+    const bool hyb_ok = kn.hybrid && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
+    int hand = 0;
+    if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
+    const size_t lds_wg = wg_lds(bx);
+    const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
+    if (use_res || (use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
+        // ---- resident solves: ALL iterations of every instance in one launch, one workgroup per bx instances
         if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
         HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 3 * sizeof(uint32_t), stream));
         const size_t lds_res = resident_lds_doubles<NX>(S, bx, threads, stash_rows) * sizeof(double);
+        const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
-            HIP_TRY(h, hipMalloc(&t_rdbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk));
-            HIP_TRY(h, hipMemsetAsync(t_rdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)nblk, stream));
+            HIP_TRY(h, hipMalloc(&t_rdbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg));
+            HIP_TRY(h, hipMemsetAsync(t_rdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg, stream));
             P.DBG = t_rdbg.as<unsigned long long>();
         }
         prof.begin(5, stream);
-        hipLaunchKernelGGL((k_resident<NX>), dim3(nblk), dim3(threads), lds_res, stream, P, h->hp.n_mult, h->hp.n_z, stash_rows, h->d_fail + 2);
+        if (use_res) hipLaunchKernelGGL((k_resident<NX>), dim3(nblk), dim3(threads), lds_res, stream, P, h->hp.n_mult, h->hp.n_z, stash_rows, h->d_fail + 2);
+        else launch_wg(wg_only ? hyb_bx : bx, nullptr);
         prof.end(stream);
         prof.begin(2, stream);
         hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail);
@@ -2118,25 +2296,39 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, wait_stream(h, stream));
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
-            std::vector<unsigned long long> hd((size_t)16 * nblk);
+            std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
             HIP_TRY(h, hipMemcpy(hd.data(), P.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            double acc[10] = {0};
+            double acc[16] = {0};
             int cnt = 0;
-            for (int bq = 0; bq < nblk; ++bq) {
-                const unsigned long long* r = hd.data() + (size_t)bq * 16;
-                if (!r[10]) continue;
-                for (int q = 0; q < 10; ++q) acc[q] += (double)(long long)(r[q + 1] - r[q]);
-                ++cnt;
+            if (use_res) {
+                for (int bq = 0; bq < nblk; ++bq) {
+                    const unsigned long long* r = hd.data() + (size_t)bq * 16;
+                    if (!r[10]) continue;
+                    for (int q = 0; q < 10; ++q) acc[q] += (double)(long long)(r[q + 1] - r[q]);
+                    ++cnt;
+                }
+                static const char* names[10] = {"backward", "gains", "forward", "round-begin", "P1+reduce1", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3+P5"};
+                fprintf(stderr, "[mpcgpu resident timing, shader-clock ticks, third round of %d workgroups]", cnt);
+                for (int q = 0; q < 10; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
+            } else {
+                // k_solve_wg: 12 round start, 13 records in LDS, 14 sweeps done, [0..10 stage_block's own stamps], 15 round end
+                const int order[16] = {12, 13, 14, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 15};
+                for (int bq = 0; bq < nblk_dbg; ++bq) {
+                    const unsigned long long* r = hd.data() + (size_t)bq * 16;
+                    if (!r[15] || !r[10]) continue;
+                    for (int q = 0; q < 14; ++q) acc[q] += (double)(long long)(r[order[q + 1]] - r[order[q]]);
+                    ++cnt;
+                }
+                static const char* names[14] = {"records", "sweeps", "enter", "load+premath", "or", "P1", "reduce1+ls-begin", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3", "P5", "drain"};
+                fprintf(stderr, "[mpcgpu k_solve_wg timing, shader-clock ticks, third round of %d workgroups]", cnt);
+                for (int q = 0; q < 14; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
             }
-            static const char* names[10] = {"backward", "gains", "forward", "round-begin", "P1+reduce1", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3+P5"};
-            fprintf(stderr, "[mpcgpu resident timing, shader-clock ticks, third round of %d workgroups]", cnt);
-            for (int q = 0; q < 10; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
             fprintf(stderr, "\n");
             P.DBG = nullptr;
         }
         piped = true;
         it = (int)h->h_fail[2];
-        h->res_prof[1] = 1; h->res_prof[2] = it; h->res_prof[3] = nblk; h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4];
+        h->res_prof[1] = 1; h->res_prof[2] = it; h->res_prof[3] = nblk_dbg; h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4];
     } else {
         uint32_t xcd_mask = h->xcd_mask;
         if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
@@ -2163,6 +2355,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.cap = 1;
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
             A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u);
+            A.handover = (uint32_t)hand;
             const size_t words = pipe_ctl_words(A.ntiles, A.cap);
             if (h->pipe_words < words) {
                 if (h->d_pipe) (void)hipFree(h->d_pipe);
@@ -2183,6 +2376,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.begin(3, stream);
             hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
+            if (hand > 0) {
+                HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 3 * sizeof(uint32_t), stream));
+                prof.begin(5, stream);
+                launch_wg(hyb_bx, (const uint32_t*)(h->d_pipe + PIPE_ABORT));
+                prof.end(stream);
+            }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
             // synchronisation of the call is the last thing that happens
             prof.begin(2, stream);

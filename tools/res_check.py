@@ -22,7 +22,7 @@ for fixed in (0, 20):
         set_cfg_bounds(s, cfg)
         s.set_option("rescue", "0")
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "2"):
         s.set_option("resident", mode)
         r = s.solve(x0, p)
         rp = s.get_resident_profile()
@@ -38,7 +38,7 @@ for fixed in (0, 20):
         res[mode] = r
         print(f"{fam} B={B} fixed={fixed} resident={mode} ran={rp['ran']} {ms:.3f} ms/batch = {B / ms * 1e3 / 1e6:.3f} M steps/s  conv={np.mean(r.status == 1):.4f} "
               f"iters mean {r.iters.mean():.2f} max {r.iters.max()}  launch_ms res={rp2['ms']:.3f} pipe={pp2['ms']:.3f} rounds={rp['rounds']} wg_rounds={rp['workgroup_rounds']} sweeps={rp['sweeps']}", flush=True)
-    a, b = res["0"], res["1"]
+    a, b = res["0"], res["2"]
     both = (a.status == 1) & (b.status == 1)
     print("   streaming vs resident: iters equal", float(np.mean(a.iters == b.iters)), " status equal", float(np.mean(a.status == b.status)),
           " max |dx| (both converged) =", float(np.abs(a.x[both] - b.x[both]).max()), " kkt max", float(b.kkt[b.status == 1].max()), flush=True)
