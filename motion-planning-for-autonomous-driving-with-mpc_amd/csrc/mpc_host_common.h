@@ -116,6 +116,7 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
 // element(row, b) = (b >> 6) * tile_elems + mpc_prow(row) + 2 * (b & 63).
 struct WsLayout {
     size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, ROLL, SC, FILT, OBST;
+    size_t MBLK, MPK, MDZ;       // ELEMENT offsets of the instance-major mailbox arrays ([instance][stage][rows], behind the tiles)
     size_t rows, irows;          // rows per tile (double / int32 workspace)
     size_t tile_elems, itile_elems, ntiles;
     size_t total, itotal;        // elements to allocate
@@ -141,6 +142,9 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     w.itile_elems = w.irows * 64;
     w.ntiles = Bp / 64;
     w.total = w.ntiles * w.tile_elems;
+    w.MBLK = w.total; w.total += Bp * S * NBLK;
+    w.MPK = w.total; w.total += Bp * S * NPK;
+    w.MDZ = w.total; w.total += Bp * S * NZ;
     w.itotal = w.ntiles * w.itile_elems;
     return w;
 }
@@ -181,6 +185,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.LAM = base + w.LAM * 64; P.REF = base + w.REF * 64; P.DZ = base + w.DZ * 64; P.PK = base + w.PK * 64; P.KK = base + w.KK * 64;
     P.BLK = base + w.BLK * 64; P.ROLL = base + w.ROLL * 64; P.SC = base + w.SC * 64;
     P.FILT = base + w.FILT * 64; P.OBST = base + w.OBST * 64;
+    P.MBLK = base + w.MBLK; P.MPK = base + w.MPK; P.MDZ = base + w.MDZ;
     P.tile_elems = (uint32_t)w.tile_elems; P.itile_elems = (uint32_t)w.itile_elems;
     P.ISC = ibase;
     P.WS = base; P.IWS = ibase;

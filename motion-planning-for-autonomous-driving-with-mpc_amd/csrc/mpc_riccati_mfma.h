@@ -194,7 +194,7 @@ __device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, int lane, doubl
 
 // What the sweeps need to know about the instance (wave-uniform)
 struct MfmaInst {
-    uint32_t ws_lane_off;      // byte offset of the instance inside its tile-major rows: tile * tile_elems * 8 + (b & 63) * 16
+    uint32_t inst;             // instance (its cost-to-go and step go to the instance-major mailbox arrays MPK / MDZ of the workspace)
     double delta_last;
 };
 
@@ -233,9 +233,9 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
     const int N = P.N;
     const double dt = P.dt, dt2 = dt * dt;
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
-    constexpr uint32_t PKS = MPC_EV(D::NPK) * 512u;                       // bytes per stage of the PK rows
-    const uint32_t pk_arr = (uint32_t)(uintptr_t)P.PK - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
-    const uint32_t pk_lane = m.pk_row >= 0 ? pk_arr + mpc_prow((uint32_t)m.pk_row) * 8u + (uint32_t)N * PKS : kk_arr, pk_inc = m.pk_row >= 0 ? PKS : 0u;
+    constexpr uint32_t PKS = MPC_EV(D::NPK) * 8u;                         // bytes per stage of the mailbox PK rows
+    const uint32_t pk_arr = (uint32_t)(uintptr_t)P.MPK - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
+    const uint32_t pk_lane = m.pk_row >= 0 ? (uint32_t)m.pk_row * 8u + (uint32_t)N * PKS : 0u, pk_inc = m.pk_row >= 0 ? PKS : 0u;
     const int x = lane >> 4;
     // where a lane writes its entry of Kt, as an offset from the records of the instance: the writers walk down the stages, the others
     // stay on their own double of the dump area (a shared dummy address would serialise 48 lanes on one LDS bank)
@@ -252,7 +252,7 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
         need[q] = true;
         ok[q] = false;
         sym[q] = in[q].delta_last != 0.0;
-        pkb[q] = mpc_uni(in[q].ws_lane_off);
+        pkb[q] = mpc_uni(pk_arr + in[q].inst * (uint32_t)(N + 1) * PKS);
     }
     for (;;) {
         ++sweeps;
@@ -261,7 +261,11 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
         for (int q = 0; q < NI; ++q) symm = symm || sym[q] || delta[q] != 0.0;
         double M[NI], b0[NI], b1[NI], aa0[NI], aa1[NI], hc[NI], ha[NI], ruu0[NI], ruu1[NI];
         bool good[NI];
-        uint32_t voff = pk_lane;
+        // (per-lane store offsets: the lanes with an entry walk down the stages of their instance's mailbox rows, the others stay on
+        //  row 0 of the KK array -- the scalar offset is the instance's, so theirs is taken relative to it)
+        uint32_t voff[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) voff[q] = m.pk_row >= 0 ? pk_lane : kk_arr - (uint32_t)pkb[q];
         int wdec = 0;
         // terminal stage: M_N = Ht_N + delta_w I
 #pragma unroll
@@ -269,14 +273,15 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
             mpc_lds_ptr r = rec[q] + N * RC::SIZE;
             M[q] = r[m.oHC] + delta[q] * m.dmask;
             good[q] = true;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff, pkb[q], 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff[q], pkb[q], 0);
             r = rec[q] + (N - 1) * RC::SIZE;
             b0[q] = r[m.oB[0]]; b1[q] = r[m.oB[1]]; aa0[q] = r[m.oAA[0]]; aa1[q] = r[m.oAA[1]]; hc[q] = r[m.oHC]; ha[q] = r[m.oHA];
             ruu0[q] = r[RC::RUU]; ruu1[q] = r[RC::RUU + 1];
         }
         auto stage = [&](auto sym_tag, int k) {
             constexpr bool SYM = decltype(sym_tag)::value;
-            voff -= pk_inc;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) voff[q] -= pk_inc;
             wdec += w_inc;
             double nb0[NI], nb1[NI], naa0[NI], naa1[NI], nhc[NI], nha[NI], nruu0[NI], nruu1[NI];
             double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], i00[NI], i01[NI], i11[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
@@ -339,7 +344,7 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
                 M[q] = wv_mfma(GA, Kt[q], T[q]) + delta[q] * m.dmask;              // M = T + Gt' Kt + delta_w I
                 if (SYM) M[q] = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr));
                 rec[q][w_first[q] - wdec] = Kt[q];                                              // gains for the forward sweep (lanes without an entry: the dump area)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff, pkb[q], 0);   // cost-to-go for the stage threads
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff[q], pkb[q], 0);   // cost-to-go for the stage threads
                 b0[q] = nb0[q]; b1[q] = nb1[q]; aa0[q] = naa0[q]; aa1[q] = naa1[q]; hc[q] = nhc[q]; ha[q] = nha[q]; ruu0[q] = nruu0[q]; ruu1[q] = nruu1[q];
             }
 #undef MPC_FENCE
@@ -387,24 +392,25 @@ __device__ __forceinline__ void mfma_forward(const Params& P, const MfmaLane<NX>
     using RC = Rec<NX>;
     const int N = P.N;
     const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
-    constexpr uint32_t DZS = MPC_EV(D::NZ) * 512u;
+    constexpr uint32_t DZS = MPC_EV(D::NZ) * 8u;                           // bytes per stage of the mailbox DZ rows
     const bool st = m.dz_row >= 0;
-    const uint32_t dz_arr = (uint32_t)(uintptr_t)P.DZ - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
-    // per-lane running offset: storing lanes walk the DZ rows (the dx lanes one stage ahead), the others stay on the dump row
-    uint32_t voff = st ? dz_arr + mpc_prow((uint32_t)m.dz_row) * 8u + (m.dz_next ? DZS : 0u) : kk_arr;
+    const uint32_t dz_arr = (uint32_t)(uintptr_t)P.MDZ - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
+    // per-lane running offset: storing lanes walk the DZ rows of their instance (the dx lanes one stage ahead), the others stay on the dump row
     const uint32_t inc = st ? DZS : 0u;
     const double fixval = (m.fix == 2) ? 1.0 : 0.0;
     const bool fix = m.fix != 0;
     double X[NI], f1[NI], f2[NI];
     int base[NI];
+    uint32_t voff[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         X[q] = x0[q];
-        base[q] = mpc_uni(in[q].ws_lane_off);
+        base[q] = mpc_uni(dz_arr + in[q].inst * (uint32_t)(N + 1) * DZS);
+        voff[q] = st ? (uint32_t)m.dz_row * 8u + (m.dz_next ? DZS : 0u) : kk_arr - (uint32_t)base[q];
         // dx_0: the storing lanes (x, hi = 0, lo, 0) want row 4 lo + x, the operand layout carries row 4 hi + x: one bank move
         if (ok[q]) {
             const double xs = wv_dpp<DPP_SHR4, 0x2>(X[q], wv_dpp<DPP_SHL8, 0x1>(X[q], X[q]));      // bank (0, 1) <- bank (1, *)
-            if (m.dz_next) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, xs), rsrc, (int)(voff - DZS), base[q], 0);
+            if (m.dz_next) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, xs), rsrc, (int)(voff[q] - DZS), base[q], 0);
         }
         mpc_lds_cptr r = rec[q];
         f1[q] = r[m.oF1]; f2[q] = r[m.oF2];
@@ -421,12 +427,12 @@ __device__ __forceinline__ void mfma_forward(const Params& P, const MfmaLane<NX>
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             S[q] = wv_sum_hi(S[q]);                                              // lane (x, *, lo, 0) = x~'[4 lo + x]: dx_{k+1}, du_k in rows 6, 7
-            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, S[q]), rsrc, (int)voff, base[q], 0);
+            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, S[q]), rsrc, (int)voff[q], base[q], 0);
+            voff[q] += inc;
             S[q] = fix ? fixval : S[q];
             X[q] = wv_dpp<DPP_SHL4, 0x6>(S[q], S[q]);                            // block (hi, lo) <- x~_hi
             f1[q] = n1[q]; f2[q] = n2[q];
         }
-        voff += inc;
     };
     {
         int k = 0;
@@ -436,7 +442,7 @@ __device__ __forceinline__ void mfma_forward(const Params& P, const MfmaLane<NX>
     if (st && !m.dz_next) {                                                  // du_N = 0
 #pragma unroll
         for (int q = 0; q < NI; ++q)
-            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, 0.0), rsrc, (int)voff, base[q], 0);
+            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, 0.0), rsrc, (int)voff[q], base[q], 0);
     }
 }
 

@@ -131,6 +131,11 @@ struct Params {
     double *KK;                  // [N*(2*NX+2)][Bp]     feedback gains K_k, k_k
     double *BLK;                 // [(N+1)*NBLK][Bp]     condensed stage blocks consumed by the Riccati sweep
     double *ROLL;                // [(N+1)*NX][Bp]       dynamics rollout of the warm-start controls (start-point safeguard)
+    // "mailbox" copies of the three arrays the stage phases and the KKT solve hand to each other, instance-major ([instance][stage][row],
+    // behind the tile-major section of the same workspace): used by the workgroup-resident path (k_solve_wg), where one wavefront reads
+    // all stages of one or two instances -- in the tile-major layout every (stage, row pair) of an instance is a different 1 KiB row, so
+    // the 14 / 4 / 17 sixteen-byte pieces of a thread lie in as many cache lines; here they are 224 / 64 / 272 contiguous bytes
+    double *MBLK, *MPK, *MDZ;
     double *SC;                  // [SC_COUNT][Bp]
     double *FILT;                // [2*FILTER_MAX][Bp]
     const double* OBST;          // [6][Bp] per-instance obstacle centres (optional)
@@ -242,7 +247,11 @@ __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, u
 //   MPC_UK(arr, R, k, e)  same kernels, row e of stage k (R rows per stage) with a loop-variant k and a literal e: ONE scalar
 //                         offset per (array, stage), the literal goes into the instruction's immediate / a hoisted lane offset
 #define MPC_UK(ptr, R, k_, e) ws_ref3(P, (ptr), (uint32_t)(k_) * (MPC_EV(R) * 64u), (uint32_t)bb, mpc_prow((uint32_t)(e)))
+//   MPC_KM(arr, R, dk, e) mailbox array (instance-major): row e of stage k + dk of thread c
+#define MPC_KM(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, ((uint32_t)(dk) * MPC_EV(R) + (uint32_t)(e)) * 8u, \
+                                     (((uint32_t)c.b * (uint32_t)(P.N + 1) + (uint32_t)c.k) * MPC_EV(R)) * 8u}
 #else
+#define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
 #define MPC_SD(ptr, row) MPC_S(ptr, row)
@@ -825,7 +834,9 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 
 // all array loads of the stage kernel in ONE batch (no dependence on the per-instance scalars), plus the arithmetic
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
-template <int NX>
+// MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
+// mailbox arrays instead of the tile-major ones (workgroup-resident path)
+template <int NX, bool MB = false>
 MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -834,7 +845,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     load_obst(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
-    ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
+    if (MB) ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 0, e)), c.dz); else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         // multipliers of bounds that exist nowhere are never read (a_0 has per-instance bounds: stage 0 always loads its pair);
@@ -854,7 +865,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     if (k < N) {
         ws_load_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 1, e)), c.rn);
         ws_load_rows<NX>(MPC_ROWS(MPC_K(P.Z, NZ, 1, 2 + e)), c.xn);
-        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
+        if (MB) ws_load_rows<NX>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 1, 2 + e)), c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
@@ -862,7 +873,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     ws_load_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
     for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
-    ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
+    if (MB) ws_load_rows<D::NPK>(MPC_ROWS(MPC_KM(P.MPK, D::NPK, 0, e)), tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
     ws_load_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
     ws_load_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
     if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo); else { c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0; }
@@ -1219,7 +1230,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 //          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
 // =========================================================================================================
 // REUSE: the update phase ran before and left 1/gap of every bound side at the new iterate in c.ig* (no division here)
-template <int NX, bool REUSE = false, bool RES = false>
+template <int NX, bool REUSE = false, bool RES = false, bool MB = false>
 MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
@@ -1408,6 +1419,10 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 #pragma unroll
             for (int i = 0; i < D::NH; ++i) c.slot[SL::H + i] = hh[i];
             c.slot[SL::ZERO] = 0.0;
+        } else if (MB) {
+            ws_store_rows<8>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
+            ws_store_rows<NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
+            ws_store_rows<D::NH>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
         } else {
             ws_store_rows<8>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_CN + e)), cn);
@@ -1422,7 +1437,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 // =========================================================================================================
 // Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
 // =========================================================================================================
-template <int NX, bool RES = false>
+template <int NX, bool RES = false, bool MB = false>
 MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
     using D = Dim<NX>;
     if (!c.active) return;
@@ -1461,6 +1476,9 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
             for (int i = 0; i < NX; ++i) c.slot[SL::GX + i] = gx[i];
             c.slot[SL::GU] = c.gua[0] + mu * c.gub[0];
             c.slot[SL::GU + 1] = c.gua[1] + mu * c.gub[1];
+        } else if (MB) {
+            ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), gx);
+            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
         } else {
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_K(P.BLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);

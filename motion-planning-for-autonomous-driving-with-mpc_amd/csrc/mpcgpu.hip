@@ -144,7 +144,7 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
-template <int NX, bool INIT, int MAXT>
+template <int NX, bool INIT, int MAXT, bool MB = false>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true) {
     int or_parity = 0;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        phase_preload<NX>(P, c, tmp);                  // every array load of the kernel is in flight before the first wait
+        phase_preload<NX, MB>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
@@ -218,11 +218,11 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     }
     MPC_STAMP(7);
     Red3 r3;
-    phase_eval_assemble<NX, !INIT>(P, c, r3);
+    phase_eval_assemble<NX, !INIT, false, MB>(P, c, r3);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
-    phase_finish<NX>(P, c, r3, n_mult, n_z);
+    phase_finish<NX, false, MB>(P, c, r3, n_mult, n_z);
     MPC_STAMP(10);
     // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
     if (P.run_counter != nullptr && t < 64) {
@@ -917,7 +917,10 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         // ---- stage blocks -> LDS records, instance-major (every stage thread its own; defect negated, three constants, Hux of stage 0)
         if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
             double blk[MPC_EV(D::NBLK)];
-            ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
+            // (the blocks this launch starts from were written tile-major by the start-iterate kernel or the pipeline; its own rounds
+            //  write the instance-major mailbox: 272 contiguous bytes per thread instead of 17 pieces in 17 lines)
+            if (rounds == 1u) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
+            else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), blk);
             double hx0 = 0.0, hx1 = 0.0;
             if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
             const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
@@ -941,7 +944,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         {
             auto inst_of = [&](int g, MfmaInst& in, double& x0) {
                 const int bb = (int)b0 + g;
-                in.ws_lane_off = ((uint32_t)bb >> 6) * P.tile_elems * 8u + ((uint32_t)bb & 63u) * 16u;
+                in.inst = (uint32_t)bb;
                 in.delta_last = MPC_UB(P.SC, (uint32_t)SC_DLAST, bb);
                 // x~_0 = (-c_0, 0.., 1) as B operand of the forward sweep (requested now, needed after the backward sweep)
                 x0 = 0.0;
@@ -997,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(14);
         // ---- the stage work of the round
-        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u);
+        stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64) k_test(const Params P, const double* recs 
     mpc_lds_ptr rec[NI];
     for (int q = 0; q < NI; ++q) {
         const int b = inst * NI + q;
-        in[q].ws_lane_off = (uint32_t)b * 16u;
+        in[q].inst = (uint32_t)b;
         in[q].delta_last = dlast[b];
         rec[q] = (mpc_lds_ptr)(lp)lrec + q * (N + 1) * stride;
         x0[q] = 0.0;
@@ -84,12 +84,12 @@ static int run(int N, int NI, bool nonconvex) {
             r[RC::HX] = k == 0 ? hux[b * 2] : 0.0; r[RC::HX + 1] = k == 0 ? hux[b * 2 + 1] : 0.0;
         }
     }
-    // workspace of one tile: PK rows then DZ rows
-    const size_t pk_el = (size_t)(N + 1) * MPC_EV(D::NPK) * 64, dz_el = (size_t)(N + 1) * MPC_EV(D::NZ) * 64;
+    // workspace: mailbox PK rows then DZ rows ([instance][stage][row]), then a dump row
+    const size_t pk_el = (size_t)(N + 1) * MPC_EV(D::NPK) * NI, dz_el = (size_t)(N + 1) * MPC_EV(D::NZ) * NI;
     double* d_ws; (void)hipMalloc(&d_ws, (pk_el + dz_el + 128) * 8); (void)hipMemset(d_ws, 0, (pk_el + dz_el + 128) * 8);
     Params P{};
     P.N = N; P.dt = dt; P.B = NI; P.Bp = 64; P.nx = NX;
-    P.WS = d_ws; P.ws_bytes = (uint32_t)((pk_el + dz_el + 128) * 8); P.PK = d_ws; P.DZ = d_ws + pk_el; P.KK = d_ws + pk_el + dz_el; P.tile_elems = (uint32_t)(pk_el + dz_el + 128);
+    P.WS = d_ws; P.ws_bytes = (uint32_t)((pk_el + dz_el + 128) * 8); P.MPK = d_ws; P.MDZ = d_ws + pk_el; P.KK = d_ws + pk_el + dz_el; P.tile_elems = (uint32_t)(pk_el + dz_el + 128);
     double *d_rec, *d_c0, *d_hux, *d_dl, *d_k, *d_do; unsigned long long* d_clk; int* d_ok;
     (void)hipMalloc(&d_rec, recs.size() * 8); (void)hipMemcpy(d_rec, recs.data(), recs.size() * 8, hipMemcpyHostToDevice);
     (void)hipMalloc(&d_c0, c0.size() * 8); (void)hipMemcpy(d_c0, c0.data(), c0.size() * 8, hipMemcpyHostToDevice);
@@ -109,7 +109,7 @@ static int run(int N, int NI, bool nonconvex) {
     // host reference
     Params Ph{}; Ph.dt = dt; Ph.N = N;
     double eP = 0, ep = 0, eK = 0, eD = 0; int bad = 0;
-    auto wsat = [&](const double* base, int rows_ev, int k, int e, int b) { return base[(size_t)k * rows_ev * 64 + mpc_prow(e) + b * 2]; };
+    auto wsat = [&](const double* base, int rows_ev, int k, int e, int b) { return base[((size_t)b * (N + 1) + k) * rows_ev + e]; };
     for (int b = 0; b < NI; ++b) {
         double delta = 0.0; bool ok = false; int sweeps = 0;
         std::vector<double> Pk((size_t)(N + 1) * NS), pk((size_t)(N + 1) * NX), Kk((size_t)N * (2 * NX + 2));
