@@ -256,9 +256,9 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
     }
     for (;;) {
         ++sweeps;
-        bool symm = false;
+        bool symm = false, symq[NI];
 #pragma unroll
-        for (int q = 0; q < NI; ++q) symm = symm || sym[q] || delta[q] != 0.0;
+        for (int q = 0; q < NI; ++q) { symq[q] = sym[q] || delta[q] != 0.0; symm = symm || symq[q]; }
         double M[NI], b0[NI], b1[NI], aa0[NI], aa1[NI], hc[NI], ha[NI], ruu0[NI], ruu1[NI];
         bool good[NI];
         // (per-lane store offsets: the lanes with an entry walk down the stages of their instance's mailbox rows, the others stay on
@@ -342,7 +342,8 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
                 const double GA = wv_dpp<DPP_SHL4, 0x6>(G[q], G[q]);               // block (hi, lo) = column block hi of Gt (read transposed)
                 Kt[q] = ca * G[q] - i01[q] * Gs[q];                                // Kt = -Lam^-1 Gt
                 M[q] = wv_mfma(GA, Kt[q], T[q]) + delta[q] * m.dmask;              // M = T + Gt' Kt + delta_w I
-                if (SYM) M[q] = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr));
+                // (per instance, so that the result of an instance does not depend on which instance shares its wavefront)
+                if (SYM) { const double Ms = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr)); M[q] = symq[q] ? Ms : M[q]; }
                 rec[q][w_first[q] - wdec] = Kt[q];                                              // gains for the forward sweep (lanes without an entry: the dump area)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff[q], pkb[q], 0);   // cost-to-go for the stage threads
                 b0[q] = nb0[q]; b1[q] = nb1[q]; aa0[q] = naa0[q]; aa1[q] = naa1[q]; hc[q] = nhc[q]; ha[q] = nha[q]; ruu0[q] = nruu0[q]; ruu1[q] = nruu1[q];

@@ -1803,7 +1803,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 0, hybrid_bx = 1, hybrid_live = -1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 2, hybrid_live = -1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1835,8 +1835,8 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "prestart_chains") k.prestart_chains = on != 0;
     else if (n == "resident") k.resident = value == nullptr ? 0 : (int)iv;
     else if (n == "res_timing") k.res_timing = on != 0;
-    else if (n == "hybrid") k.hybrid = value == nullptr ? 0 : (int)iv;
-    else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 1 : (int)iv;
+    else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
+    else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 2 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
@@ -2266,7 +2266,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
     int hyb_bx = (kn.hybrid_bx == 2 && S * 2 <= 64) ? 2 : 1;
-    const bool hyb_ok = kn.hybrid && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
+    const bool hyb_ok = kn.hybrid && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
     if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
     const size_t lds_wg = wg_lds(bx);

@@ -93,6 +93,7 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 600, **kw)
     s = make_solver(cfg)
+    s.set_option("hybrid", "0")                # (the streaming paths against each other: the hybrid solve rounds differently)
     ref = s.solve(x0, p)
     s.set_option(env[len("MPCGPU_"):].lower(), "2" if env == "MPCGPU_GROUPS" else "1")
     for _ in range(4):
@@ -140,6 +141,7 @@ def test_single_launch_pipeline_is_bit_identical(B, fixed, monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, B, **kw)
     s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
+    s.set_option("hybrid", "0")                # (the pure pipeline; the hybrid solve has its own tests below)
     s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     assert not s.get_pipeline_profile()["ran"]
@@ -158,6 +160,7 @@ def test_single_launch_pipeline_on_collision_avoidance(monkeypatch):
     x0, p = ca_batch(CA_CFG, B)
     s = make_solver(CA_CFG)
     set_cfg_bounds(s, CA_CFG)
+    s.set_option("hybrid", "0")
     s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     s.set_option("pipeline", "1")
@@ -173,6 +176,7 @@ def test_pipeline_on_a_subset_of_the_xcds(mask, monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 1500, **kw)
     s = make_solver(cfg)
+    s.set_option("hybrid", "0")
     s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     s.set_option("pipeline", "1")
@@ -188,6 +192,7 @@ def test_pipeline_release_protocol_and_restart(monkeypatch):
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 2048, **kw)
     s = make_solver(cfg)
+    s.set_option("hybrid", "0")
     s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     s.set_option("pipeline", "1")
@@ -198,7 +203,12 @@ def test_pipeline_release_protocol_and_restart(monkeypatch):
     assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]
     s.set_option("pipe_test_abort", None)
     assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]      # this handle stays on the per-kernel path
-    assert _same(make_solver(cfg).solve(x0, p), ref)
+    # the same with the hybrid solve behind the pipeline: the kernel that finishes the stragglers sees the abort word and leaves,
+    # the restart is the per-kernel path
+    s2 = make_solver(cfg)
+    s2.set_option("hybrid_live", "16")
+    s2.set_option("pipe_test_abort", "1")
+    assert _same(s2.solve(x0, p), ref) and not s2.get_pipeline_profile()["ran"]
 
 
 def test_two_handles_solve_concurrently():
@@ -227,19 +237,28 @@ def test_two_handles_solve_concurrently():
 
 def test_full_size_batch_properties():
     """BASELINE metric size: N = 30, nx = 6, B = 4096.  Size-independent properties: every instance converged;
-    permuting instances permutes results bit-exactly; splitting the batch changes nothing; the returned points
-    satisfy the reference's constraints g (checked with the oracle's g on a sample) and beat the warm start."""
+    permuting instances / splitting the batch changes nothing -- bit-exactly on the streaming paths; with the hybrid solve (default)
+    which KKT solver (one instance per lane, or one per wavefront on the matrix pipe) serves an iteration of an instance depends on
+    how many instances of its tile are still iterating, the two round differently, and the property holds to 1e-9 with the same
+    iteration counts; the returned points satisfy the reference's constraints g (checked with the oracle's g on a sample)."""
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     B = 4096
     x0, p = synthetic_batch(cfg, B, **kw)
-    s = make_solver(cfg)
-    r = s.solve(x0, p)
-    assert np.all(r.status == 1) and r.kkt.max() <= 1e-8 and r.iters.max() <= 40
     perm = np.random.default_rng(0).permutation(B)
-    rp = s.solve(x0[perm], p[perm])
-    assert np.array_equal(rp.x, r.x[perm]) and np.array_equal(rp.iters, r.iters[perm])
-    h1, h2 = s.solve(x0[:1000], p[:1000]), s.solve(x0[1000:], p[1000:])
-    assert np.array_equal(np.vstack([h1.x, h2.x]), r.x)
+    s = make_solver(cfg)
+    for hybrid in ("0", "1"):
+        s.set_option("hybrid", hybrid)
+        r = s.solve(x0, p)
+        assert np.all(r.status == 1) and r.kkt.max() <= 1e-8 and r.iters.max() <= 40
+        rp = s.solve(x0[perm], p[perm])
+        h1, h2 = s.solve(x0[:1000], p[:1000]), s.solve(x0[1000:], p[1000:])
+        if hybrid == "0":
+            assert np.array_equal(rp.x, r.x[perm]) and np.array_equal(rp.iters, r.iters[perm])
+            assert np.array_equal(np.vstack([h1.x, h2.x]), r.x)
+        else:
+            assert np.abs(rp.x - r.x[perm]).max() < 1e-9 and np.array_equal(rp.iters, r.iters[perm])
+            assert np.abs(np.vstack([h1.x, h2.x]) - r.x).max() < 1e-9
+            assert np.array_equal(s.solve(x0, p).x, r.x)                      # the same batch again: the same bits
     o = OracleSolver(cfg)
     lbg, ubg, lbx, ubx = BicycleNLP(cfg).bounds()
     for b in range(0, B, 97):
@@ -588,4 +607,64 @@ def test_closed_loop_without_host_round_trips_nx6_and_applied_noise():
     want0 = np.stack([nz.applied_noise(5, b, 0, 0.05) for b in range(256)])
     assert np.abs(c2[:, 0] - c_a[:256, 0] - want0).max() < 1e-12 and np.array_equal(t2[:, 0], t_a[:256, 0])
     t0, c0, _ = s5.closed_loop(init[:256], path[:256], orient[:256], vdes[:256], L, noise_mode=2, sigma=0.0, seed=5)
-    assert np.array_equal(t0, t_a[:256]) and np.array_equal(c0, c_a[:256])
+    # (a 256-ego batch is solved by the wave-per-instance kernel alone, the 4096-ego one starts in the pipeline: same optima,
+    #  different rounding of the KKT solves)
+    assert np.abs(t0 - t_a[:256]).max() < 1e-8 and np.abs(c0 - c_a[:256]).max() < 1e-8
+
+
+# ---- hybrid solve: pipeline while a tile has many instances iterating, then one wavefront per instance with the MFMA Riccati ----------
+
+@pytest.mark.parametrize("B", [4096, 3000, 256])
+def test_hybrid_solve_matches_oracle_and_the_pipeline(B):
+    """default path at the BASELINE size and below: both kernels took part (B = 4096, 3000) or the wave-per-instance kernel alone
+    (B = 256: every tile would hand over at once); against the oracle 1e-8 with the same iteration counts, against the pure
+    pipeline 1e-9"""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg)
+    r = s.solve(x0, p)
+    pp, rp = s.get_pipeline_profile(), s.get_resident_profile()
+    assert np.all(r.status == 1) and r.kkt.max() <= 1e-8
+    if B == 256:
+        assert not pp["ran"] and rp["ran"] and rp["rounds"] == int(r.iters.max())
+    else:
+        assert pp["ran"] and 0 < pp["rounds"] < int(r.iters.max())
+    s.set_option("hybrid", "0")
+    ref = s.solve(x0, p)
+    assert np.array_equal(r.iters, ref.iters) and np.array_equal(r.status, ref.status) and np.abs(r.x - ref.x).max() < 1e-9
+    sub = slice(0, B, max(1, B // 64))
+    ro = OracleSolver(cfg).solve_batch(x0[sub], p[sub], nthreads=8)
+    assert np.array_equal(r.iters[sub], ro["iters"]) and np.abs(r.x[sub] - ro["x"]).max() < TOL_ORACLE
+
+
+@pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "usalf_n50_nx5", "ca"])
+def test_wave_per_instance_kernel_options_agree(fam):
+    """k_solve_wg alone (hand-over threshold 64) with one or two instances per wavefront, and with a whole 8-instance workgroup
+    (option resident = 2): an instance's result does not depend on which instance shares its wavefront -- bit-identical"""
+    if fam == "ca":
+        cfg = CA_CFG
+        x0, p = ca_batch(cfg, 256)
+    else:
+        cfg, kw = FAMILIES[fam]
+        x0, p = synthetic_batch(cfg, 256, **kw)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    s.set_option("rescue", "0")
+    s.set_option("hybrid_live", "64")
+    res = []
+    for bx in ("1", "2"):
+        s.set_option("hybrid_bx", bx)
+        res.append(s.solve(x0, p))
+        assert s.get_resident_profile()["ran"] and not s.get_pipeline_profile()["ran"]
+    s.set_option("hybrid", "0")
+    s.set_option("resident", "2")
+    res.append(s.solve(x0, p))
+    assert s.get_resident_profile()["ran"]
+    assert _same(res[0], res[1]) and _same(res[0], res[2])
+    ro = OracleSolver(cfg).solve_batch(x0[:64], p[:64], nthreads=8)
+    both = (res[0].status[:64] == 1) & (ro["status"] == 1)
+    assert both.mean() > 0.9
+    if fam != "ca":
+        assert np.array_equal(res[0].iters[:64], ro["iters"]) and np.abs(res[0].x[:64] - ro["x"]).max() < TOL_ORACLE
+    else:       # nonconvex: the same basin for nearly all, a handful may differ
+        assert np.mean(np.abs(res[0].x[:64][both] - ro["x"][both]).max(axis=1) < 1e-6) > 0.9
