@@ -20,10 +20,13 @@ devices are visible; it never reports a smaller n_gpus than it was asked for.
 problem families, one handle per family, one padded all-gather at the end).
 
 Prints ONE JSON line on rank 0 (contract of the build driver) with extra objects:
-  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the solve
-                stream, measured in a second, profiled pass over the same K steps) against the 8 TB/s HBM peak, and
-                against the copy bandwidth measured in this process; `traffic` = HBM bytes per launch from rocprofv3
-                PMC passes run by this very process (FETCH_SIZE / WRITE_SIZE, gfx950 correction), see measure_traffic()
+  roofline      the iteration loop of a solve = ONE launch of k_pipeline (tiles with many instances iterating) followed by ONE launch
+                of k_solve_wg (the stragglers, one wavefront per two instances): algorithmic bytes of the instance-iterations
+                each performed / its mean launch duration (HIP events on the solve stream, a second, profiled pass over the
+                same K steps); `achieved` = bytes of both / duration of both, against the 8 TB/s HBM peak and against the
+                library's own streaming copy kernel; `kernels` has the two launches one by one; `traffic` = HBM bytes per
+                launch pair from rocprofv3 PMC passes run by this very process (FETCH_SIZE / WRITE_SIZE, gfx950 correction)
+  configs       BASELINE.json configurations 2, 3, 4 and one shard of 5 under the same clock (a few batches each)
   cpu_baseline  the oracle (oracle/mpc_oracle.c, "port") on the host cores, bounded sample of the same workload;
                 plus a run-time probe for CasADi/IPOPT (the reference's own solver) on the host
 """
@@ -72,8 +75,8 @@ def committed_traffic(kernel):
         return None
 
 
-def measure_traffic(kernel_tag, timeout=240):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,
+def measure_traffic(kernel_tags, timeout=240):
+    """HBM bytes per solve of the kernels of the iteration loop (mean per launch, summed over the kernels), measured NOW: two rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,
     kernel trace only -- counters get their own runs, MI355X_MICROARCH.md) over `bench.py --pmc-child`, which performs three
     converged-mode solves of the headline batch and nothing else.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: on gfx950
     FETCH_SIZE counts 64 B per 128-byte request (the guide's correction; re-checked with tools/ubench/ldpat.hip).
@@ -93,39 +96,27 @@ def measure_traffic(kernel_tag, timeout=240):
         except (subprocess.SubprocessError, OSError) as e:
             shutil.rmtree(out, ignore_errors=True)
             return committed_traffic("k_pipeline"), "rocprofv3 pass failed (%s); committed profiles/pmc_traffic.json" % type(e).__name__
-        v = []
+        per_kernel = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                        v.append(float(row["Counter_Value"]))
-        if not v:
+                    for tag in kernel_tags:
+                        if tag in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            per_kernel.setdefault(tag, []).append(float(row["Counter_Value"]))
+        if kernel_tags[0] not in per_kernel:
             shutil.rmtree(out, ignore_errors=True)
-            return committed_traffic("k_pipeline"), "no %s rows for %s; committed profiles/pmc_traffic.json" % (ctr, kernel_tag)
-        vals[ctr] = sum(v) / len(v)
+            return committed_traffic("k_pipeline"), "no %s rows for %s; committed profiles/pmc_traffic.json" % (ctr, kernel_tags[0])
+        # (every dispatch is one row per XCD-summed counter; per solve: one launch of each kernel)
+        vals[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
     shutil.rmtree(out, ignore_errors=True)
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
         "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this process (2*FETCH_SIZE + WRITE_SIZE, KiB)"
 
 
-def copy_bandwidth(torch, dev):
-    """achievable HBM bandwidth by a plain device-to-device copy kernel (read + write bytes / time), GB/s"""
-    n = 1 << 28                                           # 2 GiB of doubles in, 2 GiB out
-    a = torch.empty(n, dtype=torch.float64, device=dev).normal_()
-    b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 0.0
-    for _ in range(5):
-        e0.record()
-        b.copy_(a)
-        e1.record()
-        e1.synchronize()
-        best = max(best, 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del a, b
-    torch.cuda.empty_cache()
-    return best
+def copy_bandwidth(solver):
+    """achievable HBM bandwidth of a kernel that only moves data: the library's own streaming copy (16 bytes per lane and access,
+    1 GiB in, 1 GiB out; bytes read + written / time), GB/s -- MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy"""
+    return solver.measure_copy_bandwidth(1 << 30, 5)
 
 
 def casadi_probe(fam, x0, p, wl):
@@ -302,8 +293,8 @@ def main():
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch
     ab = algorithmic_bytes(fam.N, fam.nx)
     solver.set_profiling(True)
-    ric_ms = ric_n = stg_ms = stg_n = pipe_ms = pipe_n = 0.0
-    pipe_stats = None
+    ric_ms = ric_n = stg_ms = stg_n = pipe_ms = pipe_n = wg_ms = wg_n = wg_it = 0.0
+    pipe_stats = wg_stats = None
     torch.cuda.synchronize(dev)
     tp0 = time.perf_counter()
     for _ in range(args.steps):
@@ -312,41 +303,53 @@ def main():
         ric_ms += pr["riccati_ms"]; ric_n += pr["riccati_launches"]
         stg_ms += pr["stage_ms"]; stg_n += pr["stage_launches"]
         pp = solver.get_pipeline_profile()
-        if pp["ran"]:                                    # all iterations in ONE persistent launch (k_pipeline)
+        if pp["ran"]:                                    # the iterations of the tiles with many instances: ONE persistent launch (k_pipeline)
             pipe_ms += pp["ms"]; pipe_n += 1
             pipe_stats = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in pp.items()}
+        rp = solver.get_resident_profile()
+        if rp["ran"]:                                    # the stragglers: ONE launch of k_solve_wg behind it
+            wg_ms += rp["ms"]; wg_n += 1; wg_it += rp["instance_iterations"]
+            wg_stats = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in rp.items()}
     torch.cuda.synchronize(dev)
     prof_ms_per_step = (time.perf_counter() - tp0) / args.steps * 1e3
     solver.set_profiling(False)
     inst_iters = float(it.sum())                         # instance-iterations actually performed per step
+    wg_iters = wg_it / max(wg_n, 1)                      # ... of which in k_solve_wg
     kern = {}
-    for name, ms, n, bpi in (("k_riccati", ric_ms, ric_n, ab["b_riccati"]), ("k_stage", stg_ms, stg_n, ab["b_stage"]),
-                             ("k_pipeline", pipe_ms, pipe_n, ab["b_riccati"] + ab["b_stage"])):
+    for name, ms, n, bpi, iters in (("k_riccati", ric_ms, ric_n, ab["b_riccati"], inst_iters), ("k_stage", stg_ms, stg_n, ab["b_stage"], inst_iters),
+                                    ("k_pipeline", pipe_ms, pipe_n, ab["b_iter"], inst_iters - wg_iters), ("k_solve_wg", wg_ms, wg_n, ab["b_iter"], wg_iters)):
         if n == 0:
             continue
         n_per_step = n / args.steps
         avg_us = ms / max(n, 1) * 1e3
-        bytes_per_launch = bpi * inst_iters / max(n_per_step, 1)      # active instances per launch x bytes per instance
-        kern[name] = dict(avg_us=avg_us, launches_per_step=n_per_step, bytes_per_launch=bytes_per_launch,
-                          gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9, total_ms_per_step=ms / args.steps)
-    dom = max(kern, key=lambda k: kern[k]["total_ms_per_step"])
-    copy_gbs = copy_bandwidth(torch, dev) if rank == 0 else None
+        bytes_per_launch = bpi * iters / max(n_per_step, 1)           # instance-iterations of the launch x bytes per instance-iteration
+        kern[name] = dict(avg_us=avg_us, launches_per_step=n_per_step, instance_iterations_per_launch=iters / max(n_per_step, 1),
+                          bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9, total_ms_per_step=ms / args.steps)
+    loop = [k for k in ("k_pipeline", "k_solve_wg") if k in kern]
+    if not loop:                                         # one launch per kernel and iteration (pipeline switched off): the heavier of the two
+        loop = [max(kern, key=lambda k: kern[k]["total_ms_per_step"])]
+    loop_bytes = sum(kern[k]["bytes_per_launch"] * kern[k]["launches_per_step"] for k in loop)
+    loop_us = sum(kern[k]["avg_us"] * kern[k]["launches_per_step"] for k in loop)
+    loop_gbs = loop_bytes / (loop_us * 1e-6) / 1e9
+    copy_gbs = copy_bandwidth(solver) if rank == 0 else None
     traffic, traffic_src = None, "not measured (multi-GPU run or --no-traffic)"
+    tags = {"k_pipeline": "k_pipeline<6", "k_solve_wg": "k_solve_wg<6", "k_stage": "k_stage<6, false", "k_riccati": "k_riccati<6"}
     if rank == 0 and world == 1 and not args.no_traffic:
-        tag = {"k_pipeline": "k_pipeline<6", "k_stage": "k_stage<6, false", "k_riccati": "k_riccati<6"}[dom]
-        traffic, traffic_src = measure_traffic(tag)
+        traffic, traffic_src = measure_traffic([tags[k] for k in loop])
     elif rank == 0:
-        traffic, traffic_src = committed_traffic(dom), "committed profiles/pmc_traffic.json"
-    roofline = dict(bound="hbm", kernel=dom, achieved=kern[dom]["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=kern[dom]["gbs"] / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                    measured_copy_bw_gbs=copy_gbs, frac_vs_measured_copy_bw=(kern[dom]["gbs"] / copy_gbs) if copy_gbs else None,
-                    avg_launch_us=kern[dom]["avg_us"], launches_per_step=kern[dom]["launches_per_step"],
-                    algorithmic_bytes_per_launch=kern[dom]["bytes_per_launch"],
-                    other_kernel={k: v for k, v in kern.items() if k != dom},
+        traffic, traffic_src = committed_traffic("+".join(loop)), "committed profiles/pmc_traffic.json"
+    roofline = dict(bound="hbm", kernel="+".join(loop), achieved=loop_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=loop_gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                    measured_copy_bw_gbs=copy_gbs, frac_vs_measured_copy_bw=(loop_gbs / copy_gbs) if copy_gbs else None,
+                    copy_bw_note="the library's own 16-byte streaming copy (mpc_measure_copy_bandwidth), read + write bytes; the guide's float4 copy: 6290 GB/s",
+                    avg_launch_us=loop_us, launches_per_step=len(loop), algorithmic_bytes_per_launch=loop_bytes,
+                    note="a solve's iteration loop is one launch of each kernel listed, back to back on one stream; achieved = algorithmic "
+                         "bytes of the instance-iterations performed (%d B each) / the sum of the launch durations" % ab["b_iter"],
+                    kernels={k: dict(v, frac=v["gbs"] / HBM_PEAK_GBS) for k, v in kern.items()},
                     whole_step=dict(bytes_per_mpc_step=ab["b_io"] + mean_it * ab["b_iter"],
                                     gbs=value / world * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9,
                                     frac=value / world * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS),
-                    profiled_ms_per_step=prof_ms_per_step, pipeline=pipe_stats)
+                    profiled_ms_per_step=prof_ms_per_step, pipeline=pipe_stats, solve_wg=wg_stats)
 
     # ---- deterministic-work variant (exactly 20 iterations per instance, no early exit).  NOT the headline: an
     # instance that has reached the tolerance keeps iterating (steps accepted as they come), so only mean_iters / 20 of the
@@ -396,6 +399,11 @@ def main():
                             single_thread_value=1024 / t_one, cpu_model=model, host_cpus=avail,
                             casadi_ipopt=casadi_probe(fam, x0, p, wl), published_casadi_ipopt=PUBLISHED_CASADI)
 
+    # ---- BASELINE.json configurations 2 - 5 under the same clock (single-GPU run only; a few batches each, ~1 s in total)
+    configs = None
+    if rank == 0 and world == 1:
+        configs = other_configs(torch, wl, local_rank, dev, stream)
+
     # ---- the paths around the solve, single-GPU run only, a few hundred milliseconds in total
     other_paths = None
     if rank == 0 and world == 1:
@@ -411,10 +419,72 @@ def main():
                                mode="converged", gpu=torch.cuda.get_device_name(dev)),
                    ms_per_step_median=med * 1e3, value_median_batch=world * B / med if world == 1 else None,
                    converged_frac=converged, mean_iters=mean_it, max_iters=max_it, kkt_max=float(kkt.max()),
-                   fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, other_paths=other_paths)
+                   fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, configs=configs, other_paths=other_paths)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(torch, wl, local_rank, dev, stream):
+    """BASELINE.json configs[1..4]: ms per batch, steps/s, converged fraction, iterations and the roofline fraction of the iteration loop
+    (algorithmic bytes of the instance-iterations performed / duration of the launches of the loop), device-resident buffers"""
+    out = []
+
+    def run(label, fams_rows, reps=5):
+        """fams_rows: [(family, x0, p)] solved back to back per batch (one handle per family)"""
+        items = []
+        for fam, x0, p in fams_rows:
+            B = len(x0)
+            s = wl.make_solver(fam, device=local_rank)
+            d = dict(s=s, fam=fam, B=B, x0=torch.from_numpy(x0).to(dev), p=torch.from_numpy(p).to(dev))
+            d["out"] = torch.empty_like(d["x0"])
+            d["st"] = torch.empty(B, dtype=torch.int32, device=dev)
+            d["it"] = torch.empty(B, dtype=torch.int32, device=dev)
+            d["kkt"] = torch.empty(B, dtype=torch.float64, device=dev)
+            items.append(d)
+
+        def once():
+            for d in items:
+                d["s"].solve_device(d["B"], d["x0"].data_ptr(), d["p"].data_ptr(), d["out"].data_ptr(), d["st"].data_ptr(), d["it"].data_ptr(),
+                                    d["kkt"].data_ptr(), stream=stream)
+        once()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        loop_ms = loop_bytes = 0.0
+        for d in items:                              # one profiled batch: launch durations of the iteration loop
+            d["s"].set_profiling(True)
+        once()
+        torch.cuda.synchronize(dev)
+        for d in items:
+            ab = algorithmic_bytes(d["fam"].N, d["fam"].nx)
+            pr, pp, rp = d["s"].get_profile(), d["s"].get_pipeline_profile(), d["s"].get_resident_profile()
+            loop_ms += pp["ms"] + rp["ms"] + pr["riccati_ms"] + pr["stage_ms"]
+            loop_bytes += float(d["it"].sum().item()) * ab["b_iter"]
+            d["s"].set_profiling(False)
+            if d["s"].last_rescued() > 0:                # several solves behind one call (second chance): the figures above are the last one's
+                loop_ms = float("nan")
+        Bt = sum(d["B"] for d in items)
+        st = torch.cat([d["st"] for d in items]).cpu().numpy()
+        it = torch.cat([d["it"] for d in items]).cpu().numpy()
+        out.append(dict(config=label, batch=Bt, ms_per_batch=dt * 1e3, steps_per_s=Bt / dt, converged_frac=float((st == 1).mean()),
+                        mean_iters=float(it.mean()), max_iters=int(it.max()), loop_launch_ms=loop_ms if loop_ms == loop_ms else None,
+                        roofline_frac=(loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if loop_ms > 0 else None,
+                        rescued=int(sum(d["s"].last_rescued() for d in items))))
+    try:
+        f2, f3, f4 = wl.FAMILIES["zamlf_n30_nx6"], wl.FAMILIES["zamca_n30_nx5"], wl.FAMILIES["usalf_n50_nx5"]
+        run("2: N=30 nx=6 lane following, batch=256", [(f2,) + tuple(wl.batch(f2, 256))])
+        run("3: ZAM_Over-1_1 collision avoidance (cold starts through the obstacle), N=30, batch=1024", [(f3,) + tuple(wl.batch(f3, 1024))])
+        run("4: USA_Lanker weights, N=50, batch=4096", [(f4,) + tuple(wl.batch(f4, 4096))])
+        shard = wl.mixed_shard(0, 8)
+        run("5: mixed scenario sweep, shard 0 of 8 (4096 rows over the three families, one handle each, back to back)",
+            [(wl.FAMILIES[name], x0, p) for name, (rows, x0, p) in shard.items()], reps=3)
+    except Exception as e:                               # the headline must not die of a side measurement
+        out.append(dict(error=repr(e)))
+    return out
 
 
 def side_paths(torch, mpc_amd, fam, B, local_rank):

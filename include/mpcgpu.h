@@ -255,12 +255,19 @@ int mpc_get_profile(const mpc_handle* h, double out[6]);
  * summed over workers, out[5] = ms the stage workers spent on work items, out[6] = work items processed,
  * out[7] = stage workers + Riccati workers / 1000.                                                          */
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]);
-/* When the last call ran as ONE resident launch (k_resident: a workgroup owns up to 8 instances for all iterations, iterate in registers,
- * stage blocks / cost-to-go / step in LDS, lane-parallel Riccati sweep; the default for horizons up to 63, option "resident" = 0 turns it
- * off) both sets of figures above are zero and this reports: out[0] = ms of that launch (profiling enabled only), out[1] = 1 if the
- * resident path ran, out[2] = rounds (iterations) of the slowest workgroup, out[3] = workgroups of the launch, out[4] = rounds summed
- * over the workgroups, out[5] = backward Riccati sweeps summed over the workgroups (> out[4] when inertia corrections repeat a sweep). */
+/* The workgroup-resident kernels.  k_solve_wg (a workgroup keeps its instances for all their remaining iterations: the stage phases of
+ * the other paths + a wave-per-instance Riccati on the fp64 matrix pipe) finishes the instances of the tiles that left the pipeline
+ * (hybrid solve, the default: options "hybrid", "hybrid_bx", "hybrid_live") or solves a small batch alone; option "resident" = 2 runs it
+ * with whole 8-instance workgroups, "resident" = 1 the first resident kernel (k_resident, lane-parallel Riccati out of LDS).
+ * out[0] = ms of that launch (profiling enabled only), out[1] = 1 if such a kernel ran in the last call, out[2] = rounds (iterations)
+ * of its slowest workgroup, out[3] = workgroups of the launch, out[4] = rounds summed over the workgroups, out[5] = backward Riccati
+ * sweeps (> rounds when inertia corrections repeat a sweep; two instances of a wavefront share a sweep), out[6] = instance-iterations
+ * it performed (the rest of the call's iterations ran in the pipeline).                                                             */
 int mpc_get_resident_profile(const mpc_handle* h, double out[8]);
+/* Measurement helper for the roofline of bench.py: GB/s (bytes read + bytes written per second) of a plain streaming copy kernel of
+ * this library (16 bytes per lane and access, grid-stride loop over `bytes` of device memory, best of `reps` launches on the handle's
+ * stream) -- the bandwidth a kernel that only moves data reaches on this device, next to the 8 TB/s of the data sheet.              */
+int mpc_measure_copy_bandwidth(mpc_handle* h, size_t bytes, int32_t reps, double* gbs);
 
 /* debugging: per-iteration per-instance scalars of a host solve.  trace: [max_iter+1, 8, B] doubles
  * rows {mu, theta, phi, alpha, alpha_dual, delta_w, E0, n_trials}; returns iterations launched in *n_it. */

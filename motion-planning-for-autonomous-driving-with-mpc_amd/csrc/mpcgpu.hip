@@ -523,6 +523,12 @@ __device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_at
 __device__ __forceinline__ void pipe_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pipe_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// measurement helper (mpc_measure_copy_bandwidth): the plain streaming copy, 16 bytes per lane and access, grid-stride
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // which XCDs does this device have?  (one bit per HW_REG_XCC_ID that some workgroup of a grid of 4 x CUs ran on)
 __global__ void k_xcd_census(uint32_t* mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -900,7 +906,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
     const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * nw + RC::SIZE;
     const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * wave;
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    uint32_t rounds = 0, sweeps = 0;
+    uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
     for (;;) {
         // ---- which of my instances are iterating (status rows of the workspace; written by phase_finish / the sweeps below)
         if (t < 64) {
@@ -913,6 +919,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         const uint32_t mask = sh_mask;
         if (mask == 0u) break;
         ++rounds;
+        inst_rounds += (uint32_t)__popc(mask);
         WG_STAMP(12);
         // ---- stage blocks -> LDS records, instance-major (every stage thread its own; defect negated, three constants, Hux of stage 0)
         if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
@@ -1012,6 +1019,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         atomicMax(stats + 0, rounds);
         atomicAdd(stats + 1, rounds);
         atomicAdd(stats + 2, sweeps);
+        atomicAdd(stats + 3, inst_rounds);
     }
 #endif
 }
@@ -2024,6 +2032,34 @@ int mpc_get_resident_profile(const mpc_handle* h, double out[8]) {
     return MPC_OK;
 }
 
+int mpc_measure_copy_bandwidth(mpc_handle* h, size_t bytes, int32_t reps, double* gbs) {
+    if (!h || !gbs || reps < 1 || bytes < (1u << 20)) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->hp.desc.device));
+    const size_t n = bytes / 16;
+    DevTmp a, b;
+    HIP_TRY(h, hipMalloc(&a.p, n * 16));
+    HIP_TRY(h, hipMalloc(&b.p, n * 16));
+    HIP_TRY(h, hipMemsetAsync(a.p, 1, n * 16, h->own_stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    const int blocks = h->n_cu * 8;
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        HIP_TRY(h, hipEventRecord(e0, h->own_stream));
+        hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, h->own_stream, reinterpret_cast<const uint4*>(a.p), reinterpret_cast<uint4*>(b.p), n);
+        HIP_TRY(h, hipEventRecord(e1, h->own_stream));
+        HIP_TRY(h, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n * 16.0 / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbs = best;
+    return MPC_OK;
+}
+
 int mpc_get_profile(const mpc_handle* h, double out[6]) {
     if (!h || !out) return MPC_ERR_INVALID;
     for (int i = 0; i < 6; ++i) out[i] = h->prof[i];
@@ -2266,7 +2302,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
     int hyb_bx = (kn.hybrid_bx == 2 && S * 2 <= 64) ? 2 : 1;
-    const bool hyb_ok = kn.hybrid && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
+    // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
+    const bool hyb_ok = kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
     if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
     const size_t lds_wg = wg_lds(bx);
@@ -2274,7 +2311,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (use_res || (use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
         // ---- resident solves: ALL iterations of every instance in one launch, one workgroup per bx instances
         if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 3 * sizeof(uint32_t), stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
         const size_t lds_res = resident_lds_doubles<NX>(S, bx, threads, stash_rows) * sizeof(double);
         const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
         DevTmp t_rdbg;
@@ -2296,7 +2333,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             h->async_ok = true;
             return MPC_OK;
         }
-        HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, wait_stream(h, stream));
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
             std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
@@ -2331,7 +2368,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         }
         piped = true;
         it = (int)h->h_fail[2];
-        h->res_prof[1] = 1; h->res_prof[2] = it; h->res_prof[3] = nblk_dbg; h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4];
+        h->res_prof[1] = 1; h->res_prof[2] = it; h->res_prof[3] = nblk_dbg; h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
     } else {
         uint32_t xcd_mask = h->xcd_mask;
         if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
@@ -2380,7 +2417,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
             if (hand > 0) {
-                HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 3 * sizeof(uint32_t), stream));
+                HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
                 prof.begin(5, stream);
                 launch_wg(hyb_bx, (const uint32_t*)(h->d_pipe + PIPE_ABORT));
                 prof.end(stream);
@@ -2403,8 +2440,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 return MPC_OK;
             }
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (hand > 0) HIP_TRY(h, hipMemcpyAsync(h->h_fail + 2, h->d_fail + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
+            if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
+                h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = (B + hyb_bx - 1) / hyb_bx;
+                h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
+            }
             if (h->h_pipe[0] != 0u) {
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
                 // through an iteration, so start over with one launch per kernel -- and stay there for this handle

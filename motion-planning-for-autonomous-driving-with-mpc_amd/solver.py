@@ -336,11 +336,19 @@ class BatchedMPCSolver:
                     other_ms=out[4], iterations=int(out[5]))
 
     def get_resident_profile(self):
-        """Figures of the resident solve (k_resident: one workgroup owns up to 8 instances for all iterations) for the last solve;
-        `ran` is False when the solve used a streaming path (horizons above 63, trace mode, option "resident" = 0)."""
+        """Figures of the workgroup-resident kernel of the last solve (k_solve_wg: finishes the instances of the tiles that left the
+        pipeline -- the hybrid solve -- or solves a small batch alone); `ran` is False when only streaming paths ran.
+        `instance_iterations`: interior-point iterations it performed (the others ran in the pipeline)."""
         out = np.zeros(8)
         self._check(self._lib.mpc_get_resident_profile(self._h, _abi.as_dp(out)))
-        return dict(ms=out[0], ran=bool(out[1]), rounds=int(out[2]), workgroups=int(out[3]), workgroup_rounds=int(out[4]), sweeps=int(out[5]))
+        return dict(ms=out[0], ran=bool(out[1]), rounds=int(out[2]), workgroups=int(out[3]), workgroup_rounds=int(out[4]), sweeps=int(out[5]),
+                    instance_iterations=int(out[6]))
+
+    def measure_copy_bandwidth(self, nbytes=1 << 30, reps=5):
+        """GB/s (read + write) of the library's own streaming copy kernel on this device (roofline denominator of bench.py)"""
+        out = np.zeros(1)
+        self._check(self._lib.mpc_measure_copy_bandwidth(self._h, nbytes, reps, _abi.as_dp(out)))
+        return float(out[0])
 
     def get_pipeline_profile(self):
         """Figures of the single-launch pipeline (k_pipeline) for the last solve; `ran` is False when the solve used one
