@@ -240,6 +240,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve)
  * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);
+/* current value of an option (so that a caller that changes one for a moment can put the PREVIOUS value back, not the default) */
+int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value);
 
 /* ---- measurement helpers (bench.py / tests) ---------------------------------------------------------- */
 /* kernel timing of the LAST mpc_solve_batch[_dev] call, measured with HIP events on the solve stream when

@@ -45,7 +45,7 @@ EXPORTS = [
     "mpc_default_desc", "mpc_create", "mpc_destroy", "mpc_last_error", "mpc_set_bounds", "mpc_solve_batch",
     "mpc_solve_batch_dev", "mpc_plant_step", "mpc_set_profiling", "mpc_get_profile", "mpc_solve_batch_trace",
     "mpc_abi_version", "mpc_closed_loop_batch", "mpc_closed_loop_batch_dev", "mpc_metrics_batch", "mpc_forces_stage_eval", "mpc_forces_solve_batch",
-    "mpc_get_pipeline_profile", "mpc_get_resident_profile", "mpc_measure_copy_bandwidth", "mpc_plant_step_dev", "mpc_metrics_batch_dev", "mpc_forces_solve_batch_dev", "mpc_set_option", "mpc_last_rescued", "mpc_closed_loop_batch_ex", "mpc_closed_loop_batch_dev_ex", "mpc_last_loop_replayed", "mpc_validity_batch", "mpc_validity_batch_dev", "mpc_forces_closed_loop_batch", "mpc_forces_closed_loop_batch_dev",
+    "mpc_get_pipeline_profile", "mpc_get_resident_profile", "mpc_measure_copy_bandwidth", "mpc_get_option", "mpc_plant_step_dev", "mpc_metrics_batch_dev", "mpc_forces_solve_batch_dev", "mpc_set_option", "mpc_last_rescued", "mpc_closed_loop_batch_ex", "mpc_closed_loop_batch_dev_ex", "mpc_last_loop_replayed", "mpc_validity_batch", "mpc_validity_batch_dev", "mpc_forces_closed_loop_batch", "mpc_forces_closed_loop_batch_dev",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library(path: str | None = None):
     L.mpc_get_pipeline_profile.restype = C.c_int
     L.mpc_get_resident_profile.argtypes = [vp, _dp]
     L.mpc_get_resident_profile.restype = C.c_int
+    L.mpc_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.mpc_get_option.restype = C.c_int
     L.mpc_measure_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int32, _dp]
     L.mpc_measure_copy_bandwidth.restype = C.c_int
     L.mpc_solve_batch_trace.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp, C.c_int32, _ip]

@@ -1815,7 +1815,7 @@ struct mpc_handle {
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
-    static constexpr int N_SCRATCH = 32;
+    static constexpr int N_SCRATCH = 40;
     void* scratch[N_SCRATCH] = {};
     size_t scratch_cap[N_SCRATCH] = {};
 };
@@ -1847,6 +1847,30 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 2 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
+    else return MPC_ERR_INVALID;
+    return MPC_OK;
+}
+static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
+    const std::string n(name ? name : "");
+    if (n == "big_wg") *out = k.big_wg;
+    else if (n == "stage_timing") *out = k.stage_timing;
+    else if (n == "groups") *out = k.groups;
+    else if (n == "pipeline") *out = k.pipeline;
+    else if (n == "pipe_ric") *out = k.pipe_ric;
+    else if (n == "pipe_release") *out = k.pipe_release;
+    else if (n == "pipe_test_abort") *out = k.pipe_test_abort;
+    else if (n == "pipe_timing") *out = k.pipe_timing;
+    else if (n == "rescue") *out = k.rescue;
+    else if (n == "loop_async") *out = k.loop_async;
+    else if (n == "sync_spin") *out = k.sync_spin;
+    else if (n == "max_batch") *out = k.max_batch;
+    else if (n == "prestart_chains") *out = k.prestart_chains;
+    else if (n == "resident") *out = k.resident;
+    else if (n == "res_timing") *out = k.res_timing;
+    else if (n == "hybrid") *out = k.hybrid;
+    else if (n == "hybrid_bx") *out = k.hybrid_bx;
+    else if (n == "hybrid_live") *out = k.hybrid_live;
+    else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
@@ -2018,6 +2042,14 @@ int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
     return rc;
 }
 
+int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value) {
+    if (!h || !name || !value) return MPC_ERR_INVALID;
+    long v = 0;
+    const int rc = get_knob(h->knobs, name, &v);
+    if (rc == MPC_OK) *value = (int64_t)v;
+    return rc;
+}
+
 int mpc_last_rescued(const mpc_handle* h) { return h ? h->rescued_last : MPC_ERR_INVALID; }
 
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]) {
@@ -2034,7 +2066,7 @@ int mpc_get_resident_profile(const mpc_handle* h, double out[8]) {
 
 int mpc_measure_copy_bandwidth(mpc_handle* h, size_t bytes, int32_t reps, double* gbs) {
     if (!h || !gbs || reps < 1 || bytes < (1u << 20)) return MPC_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->hp.desc.device));
+    HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = bytes / 16;
     DevTmp a, b;
     HIP_TRY(h, hipMalloc(&a.p, n * 16));
@@ -2666,6 +2698,15 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
     return rc;
 }
 
+// instances one solve can take: the workspace (tile-major section + mailbox arrays, both linear in the number of tiles) is addressed
+// with 32-bit buffer offsets
+static size_t max_rows_per_solve(const mpc_handle* h) {
+    const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64);
+    size_t max_b = (((size_t)1 << 32) - 1) / (w1.total * sizeof(double)) * 64;
+    if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
+    return max_b;
+}
+
 static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double* d_p, const double* d_obst, double* d_x_out,
                      int32_t* d_status, int32_t* d_iters, double* d_kkt, hipStream_t stream, double* trace, int32_t trace_rows,
                      int32_t* n_it) {
@@ -2683,9 +2724,7 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
     // The workspace is addressed with 32-bit buffer offsets (< 4 GiB): a batch beyond that is solved in chunks of whole tiles, one after
     // the other on the same stream (instances are independent; the rows of a chunk are a contiguous slice of every caller buffer).
     {
-        const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64);
-        size_t max_b = (((size_t)1 << 32) - 1) / (w1.tile_elems * sizeof(double)) * 64;
-        if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
+        const size_t max_b = max_rows_per_solve(h);
         if ((size_t)B > max_b && !trace && !h->async_loop) {
             const size_t nw = h->hp.n_w();
             int rescued = 0;
@@ -2837,7 +2876,8 @@ int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp
     // that needs the second chance -- is recorded on the device and looked at ONCE, at the end; then the loop is replayed
     // step by step with the host in between (the per-kernel path polls for convergence, the second chance needs the count).
     bool replay = true;
-    if (d.fixed_iters <= 0 && h->knobs.pipeline && !h->pipe_disabled && h->knobs.loop_async) {
+    // (a batch beyond the workspace limit is solved in chunks, which the step-by-step form below does)
+    if (d.fixed_iters <= 0 && h->knobs.pipeline && !h->pipe_disabled && h->knobs.loop_async && (size_t)B <= max_rows_per_solve(h)) {
         HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 2 * sizeof(uint32_t), stream));
         A.abort_flag = h->d_fail + 1;
         hipLaunchKernelGGL(k_loop_setup, grid, block, 0, stream, A);
@@ -2886,14 +2926,16 @@ int mpc_closed_loop_batch_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, co
     if (!h) return MPC_ERR_INVALID;
     if (B <= 0 || L <= 0 || Lp <= 0 || !init_state || !path || !orient || !vdes || !traj || !ctrl) { h->err = "closed loop: null or empty argument"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
-    double *di = nullptr, *dp = nullptr, *dor = nullptr, *dv = nullptr, *dt_ = nullptr, *dc = nullptr;
-    int32_t* ds = nullptr;
+    // staging buffers of the host-buffer form: owned by the handle, grow-only (no allocation per call once they have their size)
     const size_t nB = (size_t)B;
-    auto cleanup = [&]() { (void)hipFree(di); (void)hipFree(dp); (void)hipFree(dor); (void)hipFree(dv); (void)hipFree(dt_); (void)hipFree(dc); (void)hipFree(ds); };
-    if (hipMalloc(&di, nB * 5 * 8) != hipSuccess || hipMalloc(&dp, nB * Lp * 2 * 8) != hipSuccess || hipMalloc(&dor, nB * Lp * 8) != hipSuccess ||
-        hipMalloc(&dv, nB * 8) != hipSuccess || hipMalloc(&dt_, nB * L * 5 * 8) != hipSuccess || hipMalloc(&dc, nB * L * 2 * 8) != hipSuccess ||
-        hipMalloc(&ds, nB * L * 4) != hipSuccess) {
-        cleanup();
+    double* di = static_cast<double*>(scratch_get(h, 29, nB * 5 * 8));
+    double* dp = static_cast<double*>(scratch_get(h, 30, nB * Lp * 2 * 8));
+    double* dor = static_cast<double*>(scratch_get(h, 31, nB * Lp * 8));
+    double* dv = static_cast<double*>(scratch_get(h, 32, nB * 8));
+    double* dt_ = static_cast<double*>(scratch_get(h, 33, nB * L * 5 * 8));
+    double* dc = static_cast<double*>(scratch_get(h, 34, nB * L * 2 * 8));
+    int32_t* ds = static_cast<int32_t*>(scratch_get(h, 35, nB * L * 4));
+    if (!di || !dp || !dor || !dv || !dt_ || !dc || !ds) {
         h->err = "closed loop: out of device memory";
         return MPC_ERR_HIP;
     }
@@ -2912,7 +2954,6 @@ int mpc_closed_loop_batch_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp, co
             rc = MPC_ERR_HIP;
         }
     }
-    cleanup();
     return rc;
 }
 
@@ -3047,6 +3088,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     if (B <= 0 || !d_x0 || !d_xinit || !d_all_parameters || !lb || !ub || !hl || !hu || !d_x_out) { h->err = "forces solve: null or empty argument"; return MPC_ERR_INVALID; }
     const mpc_problem_desc& d = h->hp.desc;
     if (d.nx != 5) { h->err = "the FORCES formulation has 5 states (z = [deltaDot, aLong, x, y, delta, v, psi])"; return MPC_ERR_INVALID; }
+    // (k_forces_qp holds all stages of an instance in one workgroup of at most 256 threads, one thread per stage)
+    if (d.N > 256) { h->err = "forces solve: horizons above 256 stages are not supported (one thread per stage, 256 threads per workgroup)"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     const int N = d.N;
     const size_t nB = (size_t)B, Bp = (nB + 63) / 64 * 64;

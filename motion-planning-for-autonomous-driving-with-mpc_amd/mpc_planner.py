@@ -96,11 +96,9 @@ class MPCPlanner(object):
         assert self.results is not None, "plan() first"
         conf = self.configuration
         x = self.results["states"]
-        if conf.use_case == "collision_avoidance":
-            obst = _scenario.obstacle_rectangles(self.scenario, x.shape[0])
-        else:                                         # the lane-following variant of a scenario carries no obstacle (ZAM_Over-1_1_LF.xml)
-            dyn = SimpleNamespace(obstacles=[], dynamic_obstacles=getattr(self.scenario, "dynamic_obstacles", []))
-            obst = _scenario.obstacle_rectangles(dyn, x.shape[0])
+        # every obstacle of the scenario, static and moving, whatever the use case (the reference's test builds its collision checker from
+        # the whole scenario, test_mpc_planner.py:40; the lane-following variant of ZAM_Over-1_1 simply has none)
+        obst = _scenario.obstacle_rectangles(self.scenario, x.shape[0])
         left, right = _scenario.road_corridor(self.scenario, conf.lanelets_leading_to_goal)
         return _metrics.collision_verdict(self._backend(), x, obst, left, right, EGO_SHAPE.length, EGO_SHAPE.width)
 

@@ -136,10 +136,11 @@ class NlpSolverHandle:
             be.set_bounds(lbx, ubx, lbg, ubg)
         res = be.solve(x0a, pa)
         rescued = np.zeros(res.status.shape[0], dtype=bool)
+        n_rescued = int(be.last_rescued()) if hasattr(be, "last_rescued") else 0      # the second chance behind the C-ABI (a count, not a mask)
         if (self.rescue and not isinstance(be, BatchedMPCSolver) and not np.all(res.status == 1) and lbg is not None and lbx is not None
                 and ubg is not None and ubx is not None):
             res, rescued = rescue_failed(be, x0a, pa, res, (lbx, ubx, lbg, ubg))      # stands in for IPOPT's restoration phase
-        self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(), rescued=rescued,
+        self._stats = dict(status=res.status.copy(), iter_count=res.iters.copy(), kkt=res.kkt.copy(), rescued=rescued, n_rescued=n_rescued + int(rescued.sum()),
                            success=bool(np.all(res.status == 1)),
                            return_status="Solve_Succeeded" if np.all(res.status == 1) else "Not_Converged")
         x = res.x if batched else res.x.reshape(-1, 1)
@@ -424,8 +425,11 @@ class ForcesproOptimizer(Optimizer):
             Pt = [w["weight_x_terminate"], w["weight_y_terminate"], w["weight_steering_angle_terminate"],
                   w["weight_velocity_terminate"], w["weight_heading_angle_terminate"]]
             _, disc_distance = compute_approximating_circle_radius(self.configuration.p.l, self.configuration.p.w)
+            # (the obstacle circle centres are run-time parameters 4..9 of every stage in the reference, optimizer.py:319-323; the
+            #  device loop fills them from the handle's description, the host loop from runtime_parameters(): the same centres)
             backend = BatchedMPCSolver(self.predict_horizon, 5, dt=0.1, Q=Q, R=R, P=Pt,            # integrator_stepsize = 0.1, optimizer.py:97
-                                       friction_div=self.configuration.wheelbase, ego_offset=(disc_distance / 2) / 2, device=self._device)
+                                       friction_div=self.configuration.wheelbase, ego_offset=(disc_distance / 2) / 2,
+                                       obstacle_centers=np.array(self.obstacle_circles_centers_tuple, dtype=np.float64), device=self._device)
             lb, ub, hl, hu = self.inequal_constraint()
             model = ForcesModel(self.predict_horizon, backend, lb, ub, hl, hu)
             self._pair = (model, ForcesSolverHandle(backend, model, self.hessian_mode))

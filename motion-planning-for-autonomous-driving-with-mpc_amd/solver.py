@@ -130,11 +130,12 @@ class BatchedMPCSolver:
         """diagnostic form of solve(): the second chance for stalled instances (homotopy on the obstacle radius) runs on the
         device behind the C-ABI in every solve; this returns the result together with the mask of the instances that needed
         it, found by solving once with the option "rescue" off.  Returns (SolveResult, rescued mask)."""
+        before = self.get_option("rescue")
         self.set_option("rescue", "0")
         try:
             plain = self.solve(x0, p)
         finally:
-            self.set_option("rescue", None)
+            self.set_option("rescue", before)          # what it was (the environment or the caller may have switched it off)
         if np.all(plain.status == 1):
             return plain, np.zeros(plain.status.shape[0], dtype=bool)
         res = self.solve(x0, p)
@@ -325,6 +326,13 @@ class BatchedMPCSolver:
         environment (MPCGPU_<NAME>) is only read when the handle is created."""
         v = None if value is None else str(value).encode()
         self._check(self._lib.mpc_set_option(self._h, str(name).encode(), v))
+
+    def get_option(self, name):
+        """current value of a run-time switch (include/mpcgpu.h: mpc_get_option)"""
+        import ctypes
+        v = ctypes.c_int64(0)
+        self._check(self._lib.mpc_get_option(self._h, str(name).encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def set_profiling(self, enable=True):
         self._check(self._lib.mpc_set_profiling(self._h, 1 if enable else 0))

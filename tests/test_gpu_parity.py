@@ -288,16 +288,24 @@ def test_collision_avoidance_batch():
     s = make_solver(CA_CFG)
     set_cfg_bounds(s, CA_CFG)
     r = s.solve(x0, p)
-    ok = r.status == 1
-    assert ok.mean() > 0.9
+    # every cold start comes home through the C-ABI (the stalled ones by the second chance), to the tolerance of the original NLP
+    assert np.all(r.status == 1) and r.kkt.max() <= 1e-8 and s.last_rescued() > 0
     nlp = BicycleNLP(CA_CFG)
-    for w in r.x[ok][::37]:
+    for w in r.x[::37]:
         _, X = nlp.split(w)
         assert min(nlp.obstacle_rows(x)[0].min() for x in X) >= CA_CFG.r_sum - 1e-6
+    # against the oracle: nonconvex (pass left / right), two correct solvers may end in different local optima -- where they end in the
+    # same one (the large majority) they agree to 1e-6, and what the kernels return elsewhere is a KKT point by the certificate that uses
+    # the numpy restatement of the NLP alone
+    from helpers import kkt_certificate
     ro = OracleSolver(CA_CFG).solve_batch(x0[:64], p[:64], nthreads=8)
-    both = ok[:64] & (ro["status"] == 1)
-    # long (40-60 iteration) nonconvex solves: require agreement to the north-star tolerance where both converge
-    assert np.abs(r.x[:64][both] - ro["x"][both]).max() < 1e-4
+    both = ro["status"] == 1
+    dist = np.abs(r.x[:64] - ro["x"]).max(axis=1)
+    same = both & (dist < 1e-6)
+    assert same.sum() >= 0.85 * both.sum()
+    for b in np.nonzero(~same)[0][:4]:
+        cert = kkt_certificate(nlp, r.x[b], p[b])
+        assert cert["stationarity"] <= 1e-6 and cert["feasibility"] <= 1e-6, (b, cert)
     per = s.solve(x0[:32], p[:32], obst=np.tile(CA_CFG.obstacle_centers.ravel(), (32, 1)))
     assert np.array_equal(per.x, r.x[:32])
 
