@@ -259,8 +259,8 @@ int mpc_get_profile(const mpc_handle* h, double out[6]);
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]);
 /* The workgroup-resident kernels.  k_solve_wg (a workgroup keeps its instances for all their remaining iterations: the stage phases of
  * the other paths + a wave-per-instance Riccati on the fp64 matrix pipe) finishes the instances of the tiles that left the pipeline
- * (hybrid solve, the default: options "hybrid", "hybrid_bx", "hybrid_live") or solves a small batch alone; option "resident" = 2 runs it
- * with whole 8-instance workgroups, "resident" = 1 the first resident kernel (k_resident, lane-parallel Riccati out of LDS).
+ * (hybrid solve, the default: options "hybrid", "hybrid_bx", "hybrid_live") or solves a small batch alone; option "resident" = 1 runs it
+ * alone with whole 8-instance workgroups.
  * out[0] = ms of that launch (profiling enabled only), out[1] = 1 if such a kernel ran in the last call, out[2] = rounds (iterations)
  * of its slowest workgroup, out[3] = workgroups of the launch, out[4] = rounds summed over the workgroups, out[5] = backward Riccati
  * sweeps (> rounds when inertia corrections repeat a sweep; two instances of a wavefront share a sweep), out[6] = instance-iterations

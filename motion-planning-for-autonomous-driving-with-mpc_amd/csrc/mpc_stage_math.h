@@ -81,31 +81,6 @@ enum ScRow {
     SC_COUNT
 };
 enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW, IS_COUNT };
-// resident solve path: per-instance record in LDS (what the k = 0 stage thread and the Riccati lanes tell each other, and the filter)
-enum InstRow { IR_C0 = 0, IR_HUX0 = 6, IR_HUX1, IR_DLAST, IR_DELTA, IR_RSTAT, IR_FILT = 12, IR_SIZE = IR_FILT + 2 * 32 };
-// LDS record of one (instance, stage) of the resident path, in doubles: inputs of the Riccati sweep written by the stage threads
-// (phase_eval_assemble / phase_finish with RES = true), P_k written by the backward sweep; after a successful sweep the gain phase
-// overwrites [RUU, ZERO) with the rows of the forward sweep (mpc_riccati_lanes.h).  Vector-read sub-arrays start at even indices.
-template <int NX>
-struct Slot {
-    static constexpr int NH = NX + 5, NS = NX * (NX + 1) / 2;
-    static constexpr int A = 0;                          // 6: a03 a04 a13 a14 a42 a43
-    static constexpr int CN = 6;                         // NX: defect c_{k+1}
-    static constexpr int RUU = (6 + NX + 1) & ~1;        // 2
-    static constexpr int GU = RUU + 2;                   // 2
-    static constexpr int GX = GU + 2;                    // NX
-    static constexpr int H = GX + NX;                    // NH structural nonzeros of the stage Hessian (Dim::hrow)
-    static constexpr int ZERO = H + NH;                  // one double that is always 0.0 (target of the "no entry" offsets)
-    static constexpr int PK = (ZERO + 1 + 1) & ~1;       // NS + NX: P_k upper triangle, p_k
-    static constexpr int SIZE = (PK + NS + NX + 1) & ~1;
-    // written by lane_gain over the consumed inputs:
-    static constexpr int DK0 = RUU;                      // NX: dt * K0
-    static constexpr int DK1 = DK0 + NX;                 // NX: dt * K1
-    static constexpr int DKF = DK1 + NX;                 // 2:  dt * k_ff
-    static constexpr int DX = DKF + 2;                   // NX: dx_k (forward sweep)
-    static_assert(DX + NX <= ZERO, "forward-sweep rows must fit into the consumed inputs");
-};
-
 struct Params {
     int32_t B, Bp, N, nx, bx;    // instances, padded instances (multiple of 64), horizon, states, instances/block
     int32_t obst_mult, max_iter, fixed_iters;
@@ -434,13 +409,6 @@ struct Ctx {
     int bnd_ub;
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
-    // --- resident solve path only (RES = true instantiations of the phases; mpc_resident.h): the per-instance scalars the other path
-    //     keeps in the SC / ISC rows of the workspace stay in these registers, the stage blocks go to the LDS slot of the thread
-    bool haveth0;                    // theta_max / theta_min have been fixed (IS_HAVETH0)
-    double fcost, logsum, e0;        // SC_FCOST, SC_LOGSUM, SC_E0
-    double K0[NX], K1[NX], kf0, kf1; // gains of stage k (lane_gain), consumed by res_round_begin
-    mpc_lds_ptr slot;                // LDS record of (instance, stage): Slot<NX> in mpc_riccati_lanes.h
-    mpc_lds_ptr inst;                // LDS record of the instance: InstRow
 };
 
 // bounds of variable i of stage k; a_0 (k = 0, i = 1) carries the per-instance presolved friction bound
@@ -673,10 +641,7 @@ MPC_HD void prestart_instance(const Params& P, int b) {
 // =========================================================================================================
 // Phase 0 (init kernel only): build the start iterate from the caller's x0 (IPOPT section 3.6)
 // =========================================================================================================
-// RES (here and in the phases below): instantiation of the resident solve path -- nothing is stored to the workspace, per-instance
-// scalars stay in the context, stage blocks go to the thread's LDS slot (mpc_resident.h)
-#define MPC_WS(stmt) do { if (!RES) { stmt; } } while (0)
-template <int NX, bool RES = false>
+template <int NX>
 MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -706,16 +671,16 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
         }
         const double v = push_in(raw, lb, ub);
         c.z[i] = v;
-        MPC_WS(MPC_K(P.Z, NZ, 0, i) = v);
+        MPC_K(P.Z, NZ, 0, i) = v;
         c.zl[i] = has_lo(lb) ? 1.0 : 0.0;
         c.zu[i] = has_hi(ub) ? 1.0 : 0.0;
-        MPC_WS(MPC_K(P.ZL, NZ, 0, i) = c.zl[i]);
-        MPC_WS(MPC_K(P.ZU, NZ, 0, i) = c.zu[i]);
-        MPC_WS(MPC_K(P.DZ, NZ, 0, i) = 0.0);
+        MPC_K(P.ZL, NZ, 0, i) = c.zl[i];
+        MPC_K(P.ZU, NZ, 0, i) = c.zu[i];
+        MPC_K(P.DZ, NZ, 0, i) = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        MPC_WS(MPC_K(P.LAM, NX, 0, i) = 0.0);
+        MPC_K(P.LAM, NX, 0, i) = 0.0;
         c.lam[i] = 0.0;
         c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
         c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
@@ -733,47 +698,38 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         c.so[j] = push_in(dist[j], ol, ou);
-        MPC_WS(MPC_K(P.SO, 3, 0, j) = c.so[j]);
+        MPC_K(P.SO, 3, 0, j) = c.so[j];
         c.nuo[j] = 0.0;
         c.zlo[j] = P.has_ol ? 1.0 : 0.0;
         c.zuo[j] = P.has_ou ? 1.0 : 0.0;
-        MPC_WS(MPC_K(P.NUO, 3, 0, j) = 0.0);
-        MPC_WS(MPC_K(P.ZLO, 3, 0, j) = c.zlo[j]);
-        MPC_WS(MPC_K(P.ZUO, 3, 0, j) = c.zuo[j]);
+        MPC_K(P.NUO, 3, 0, j) = 0.0;
+        MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
+        MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
     }
     if (k == 0) {
         const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
         const double dfr = c.fric_row ? friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false) : 0.0;
         c.sf = c.fric_row ? push_in(dfr, fl, fu) : 0.0;
-        MPC_WS(MPC_S(P.SC, SC_SF) = c.sf);
+        MPC_S(P.SC, SC_SF) = c.sf;
         c.nuf = 0.0;
         c.zlf = (c.fric_row && P.has_fl) ? 1.0 : 0.0;
         c.zuf = (c.fric_row && P.has_fu) ? 1.0 : 0.0;
-        if (!RES) {
-            MPC_S(P.SC, SC_NUF) = 0.0;
-            MPC_S(P.SC, SC_ZLF) = c.zlf;
-            MPC_S(P.SC, SC_ZUF) = c.zuf;
-            MPC_S(P.SC, SC_DFRIC) = 0.0;
-            MPC_S(P.SC, SC_GFR0) = 0.0;
-            MPC_S(P.SC, SC_GFR1) = 0.0;
-            MPC_S(P.SC, SC_GFR2) = 0.0;
-            MPC_S(P.SC, SC_HUX0) = 0.0;
-            MPC_S(P.SC, SC_HUX1) = 0.0;
-        } else {
-            c.dsf = c.dfric0 = 0.0;
-            c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
-        }
-    } else if (RES) {
-        c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
-        c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
+        MPC_S(P.SC, SC_NUF) = 0.0;
+        MPC_S(P.SC, SC_ZLF) = c.zlf;
+        MPC_S(P.SC, SC_ZUF) = c.zuf;
+        MPC_S(P.SC, SC_DFRIC) = 0.0;
+        MPC_S(P.SC, SC_GFR0) = 0.0;
+        MPC_S(P.SC, SC_GFR1) = 0.0;
+        MPC_S(P.SC, SC_GFR2) = 0.0;
+        MPC_S(P.SC, SC_HUX0) = 0.0;
+        MPC_S(P.SC, SC_HUX1) = 0.0;
     }
     red.gmax = gmax;
 }
 
-template <int NX, bool RES = false>
+template <int NX>
 MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
     if (!c.valid) return;
-    if (RES) { c.haveth0 = false; c.theta = c.phi = c.fcost = c.logsum = c.e0 = 0.0; }
     c.df = red.gmax > SCALING_MAX_GRAD ? SCALING_MAX_GRAD / red.gmax : 1.0;
     c.mu = MU_INIT;
     c.tau = fmax(TAU_MIN, 1.0 - c.mu);
@@ -784,7 +740,6 @@ MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
     c.conv = false;
     c.thmax = 0.0;
     c.thmin = 0.0;
-    if (RES) return;
     if (c.k == 0) {
         MPC_S(P.SC, SC_DF) = c.df;
         MPC_S(P.SC, SC_DLAST) = 0.0;
@@ -1070,7 +1025,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
 }
 
 // acceptance test of the trial point against the filter, the switching and the Armijo conditions
-template <int NX, bool RES = false>
+template <int NX>
 MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red) {
     if (!(c.active && c.searching)) return;
     ++c.ntrial;
@@ -1078,7 +1033,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
     const double ph_t = red.bad > 0.0 ? INFINITY : c.df * red.fcost - c.mu * red.logsum;
     bool good = isfinite(th_t) && isfinite(ph_t) && th_t <= c.thmax;
     for (int q = 0; q < c.nfilt && good; ++q) {
-        const double tf = RES ? c.inst[IR_FILT + 2 * q] : (double)MPC_SD(P.FILT, 2 * q), pf = RES ? c.inst[IR_FILT + 2 * q + 1] : (double)MPC_SD(P.FILT, 2 * q + 1);
+        const double tf = MPC_SD(P.FILT, 2 * q), pf = MPC_SD(P.FILT, 2 * q + 1);
         if (!(cmp_le(fmax(th_t, THETA_FLOOR), fmax(tf, THETA_FLOOR), tf) || cmp_le(ph_t, pf, pf))) good = false;
     }
     if (good && c.conv) {
@@ -1104,7 +1059,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX, bool RES = false>
+template <int NX>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1112,7 +1067,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     const int N = P.N, k = c.k;
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
-        if (k == 0 && !RES) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
+        if (k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
@@ -1126,10 +1081,9 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         c.z[i] = zn;
     }
     // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
-    if (!RES) ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+    ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
-        if (RES) break;
         const bool a0 = (i == 0) && (k == 0);
         const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
         if (((P.lo_mask >> i) & both) || a0) {
@@ -1142,7 +1096,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
 #pragma unroll
     for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
-    if (!RES) ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), c.lam);
+    ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), c.lam);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
@@ -1162,12 +1116,10 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
         c.so[j] = sn;
     }
-    if (!RES) {
-        if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo);
-        if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo);
-        ws_store_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
-        ws_store_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
-    }
+    if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo);
+    if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
     if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
@@ -1175,17 +1127,17 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
             const double ig = 1.0 / (s - P.fl);
             sg += c.zlf * ig; gb -= mu * ig;
             c.zlf = side_update(ig, c.zlf, ds, mu, ad, 1.0 / (sn - P.fl));
-            MPC_WS(MPC_S(P.SC, SC_ZLF) = c.zlf);
+            MPC_S(P.SC, SC_ZLF) = c.zlf;
         }
         if (P.has_fu) {
             const double ig = 1.0 / (P.fu - s);
             sg += c.zuf * ig; gb += mu * ig;
             c.zuf = side_update(ig, c.zuf, -ds, mu, ad, 1.0 / (P.fu - sn));
-            MPC_WS(MPC_S(P.SC, SC_ZUF) = c.zuf);
+            MPC_S(P.SC, SC_ZUF) = c.zuf;
         }
         c.nuf += al * (gb - c.nuf + sg * ds);
-        MPC_WS(MPC_S(P.SC, SC_NUF) = c.nuf);
-        MPC_WS(MPC_S(P.SC, SC_SF) = sn);
+        MPC_S(P.SC, SC_NUF) = c.nuf;
+        MPC_S(P.SC, SC_SF) = sn;
         c.sf = sn;
     }
     if (k == 0) {
@@ -1194,33 +1146,24 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
             int nf = c.nfilt;
             if (nf == FILTER_MAX) {
                 for (int q = 1; q < FILTER_MAX; ++q) {
-                    if (RES) { c.inst[IR_FILT + 2 * (q - 1)] = c.inst[IR_FILT + 2 * q]; c.inst[IR_FILT + 2 * (q - 1) + 1] = c.inst[IR_FILT + 2 * q + 1]; continue; }
                     MPC_SD(P.FILT, 2 * (q - 1)) = MPC_SD(P.FILT, 2 * q);
                     MPC_SD(P.FILT, 2 * (q - 1) + 1) = MPC_SD(P.FILT, 2 * q + 1);
                 }
                 --nf;
             }
-            if (RES) {
-                c.inst[IR_FILT + 2 * nf] = (1 - GAMMA_THETA) * c.theta;
-                c.inst[IR_FILT + 2 * nf + 1] = c.phi - GAMMA_PHI * c.theta;
-            } else {
-                MPC_SD(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
-                MPC_SD(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
-                MPC_S(P.ISC, IS_NFILT) = nf + 1;
-            }
+            MPC_SD(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
+            MPC_SD(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
+            MPC_S(P.ISC, IS_NFILT) = nf + 1;
         }
-        if (!RES) {
-            MPC_S(P.ISC, IS_ITERS) = c.iters + 1;
-            MPC_S(P.ISC, IS_HAVETH0) = 1;
-            MPC_S(P.SC, SC_THMAX) = c.thmax;
-            MPC_S(P.SC, SC_THMIN) = c.thmin;
-            MPC_S(P.SC, SC_ALPHA) = al;
-            MPC_S(P.SC, SC_ADU) = ad;
-            MPC_S(P.SC, SC_PHI) = c.phi;
-            MPC_S(P.SC, SC_NTRIAL) = c.ntrial;
-        }
+        MPC_S(P.ISC, IS_ITERS) = c.iters + 1;
+        MPC_S(P.ISC, IS_HAVETH0) = 1;
+        MPC_S(P.SC, SC_THMAX) = c.thmax;
+        MPC_S(P.SC, SC_THMIN) = c.thmin;
+        MPC_S(P.SC, SC_ALPHA) = al;
+        MPC_S(P.SC, SC_ADU) = ad;
+        MPC_S(P.SC, SC_PHI) = c.phi;
+        MPC_S(P.SC, SC_NTRIAL) = c.ntrial;
     }
-    if (RES) c.haveth0 = true;
     if (!c.ftype) { if (c.nfilt == FILTER_MAX) --c.nfilt; ++c.nfilt; }
     ++c.iters;
 }
@@ -1230,7 +1173,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 //          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
 // =========================================================================================================
 // REUSE: the update phase ran before and left 1/gap of every bound side at the new iterate in c.ig* (no division here)
-template <int NX, bool REUSE = false, bool RES = false, bool MB = false>
+template <int NX, bool REUSE = false, bool MB = false>
 MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
@@ -1308,7 +1251,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double c0 = x[i] - c.r0[i];
-            if (RES) c.inst[IR_C0 + i] = c0; else MPC_S(P.SC, SC_C0 + i) = c0;
+            MPC_S(P.SC, SC_C0 + i) = c0;
             theta += fabs(c0);
             prim = fmax(prim, fabs(c0));
         }
@@ -1376,19 +1319,12 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         H[D::sidx(2, 2)] += nu * h[1] + sg * g[1] * g[1];
         H[D::sidx(2, 3)] += nu * h[2] + sg * g[1] * g[2];
         H[D::sidx(3, 3)] += nu * h[3] + sg * g[2] * g[2];
-        if (RES) {
-            c.inst[IR_HUX0] = sg * g[0] * g[1];
-            c.inst[IR_HUX1] = sg * g[0] * g[2];
-            c.dfric0 = dfr;
-            c.gfr0[0] = g[0]; c.gfr0[1] = g[1]; c.gfr0[2] = g[2];
-        } else {
-            MPC_S(P.SC, SC_HUX0) = sg * g[0] * g[1];
-            MPC_S(P.SC, SC_HUX1) = sg * g[0] * g[2];
-            MPC_S(P.SC, SC_DFRIC) = dfr;
-            MPC_S(P.SC, SC_GFR0) = g[0];
-            MPC_S(P.SC, SC_GFR1) = g[1];
-            MPC_S(P.SC, SC_GFR2) = g[2];
-        }
+        MPC_S(P.SC, SC_HUX0) = sg * g[0] * g[1];
+        MPC_S(P.SC, SC_HUX1) = sg * g[0] * g[2];
+        MPC_S(P.SC, SC_DFRIC) = dfr;
+        MPC_S(P.SC, SC_GFR0) = g[0];
+        MPC_S(P.SC, SC_GFR1) = g[1];
+        MPC_S(P.SC, SC_GFR2) = g[2];
     }
     double nanflag = 0.0;
 #pragma unroll
@@ -1408,18 +1344,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
             for (int j = i; j < NX; ++j)
                 if (D::hrow(i, j) >= 0) hh[D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0] = H[D::sidx(i, j)];
         }
-        if (RES) {
-            using SL = Slot<NX>;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c.slot[SL::A + i] = head[i];
-            c.slot[SL::RUU] = ruu[0];
-            c.slot[SL::RUU + 1] = ruu[1];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) c.slot[SL::CN + i] = cn[i];
-#pragma unroll
-            for (int i = 0; i < D::NH; ++i) c.slot[SL::H + i] = hh[i];
-            c.slot[SL::ZERO] = 0.0;
-        } else if (MB) {
+        if (MB) {
             ws_store_rows<8>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
             ws_store_rows<D::NH>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
@@ -1437,7 +1362,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 // =========================================================================================================
 // Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
 // =========================================================================================================
-template <int NX, bool RES = false, bool MB = false>
+template <int NX, bool MB = false>
 MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
     using D = Dim<NX>;
     if (!c.active) return;
@@ -1470,13 +1395,7 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         double gx[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) gx[i] = c.gxa[i] + mu * c.gxb[i];
-        if (RES) {
-            using SL = Slot<NX>;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) c.slot[SL::GX + i] = gx[i];
-            c.slot[SL::GU] = c.gua[0] + mu * c.gub[0];
-            c.slot[SL::GU + 1] = c.gua[1] + mu * c.gub[1];
-        } else if (MB) {
+        if (MB) {
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
         } else {
@@ -1485,15 +1404,6 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         }
     }
     c.status = status;
-    if (RES) {
-        // what the other path writes to the SC / ISC rows and reloads in phase_load_scalars
-        c.mu = mu; c.tau = tau;
-        c.theta = red.theta; c.fcost = red.fcost; c.logsum = red.logsum; c.e0 = E0;
-        c.phi = c.df * red.fcost - mu * red.logsum;
-        if (mu_changed) c.nfilt = 0;
-        if (P.fixed_iters > 0 && E0 <= P.tol) c.conv = true;
-        return;
-    }
     if (k == 0) {
         MPC_S(P.SC, SC_MU) = mu;
         MPC_S(P.SC, SC_TAU) = tau;

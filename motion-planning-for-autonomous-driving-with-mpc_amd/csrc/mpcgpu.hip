@@ -35,7 +35,6 @@
 #include "mpc_host_common.h"
 #include "mpc_closed_loop.h"
 #include "mpc_forces_qp.h"
-#include "mpc_riccati_lanes.h"
 #include "mpc_riccati_mfma.h"
 
 using namespace mpc;
@@ -218,11 +217,11 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     }
     MPC_STAMP(7);
     Red3 r3;
-    phase_eval_assemble<NX, !INIT, false, MB>(P, c, r3);
+    phase_eval_assemble<NX, !INIT, MB>(P, c, r3);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
-    phase_finish<NX, false, MB>(P, c, r3, n_mult, n_z);
+    phase_finish<NX, MB>(P, c, r3, n_mult, n_z);
     MPC_STAMP(10);
     // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
     if (P.run_counter != nullptr && t < 64) {
@@ -678,198 +677,6 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
         atomicAdd(st + 2, busy + wall_clock64());
         atomicAdd(st + 3, (unsigned long long)n_items);
         pipe_add(A.ctl + PIPE_STATS + 10, 1u);
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_resident: the whole solve of `bx` instances by ONE workgroup, on chip.  The streaming paths above move every instance through HBM
-// twice per iteration (stage kernel <-> Riccati kernel, 71 KB per instance-iteration) and chain two latencies per round: a 31-stage
-// Riccati pass of a 64-instance tile (42 us whatever the number of live lanes) and a stage work item (24 us) plus hand-offs.  Here a
-// workgroup keeps the iterate, multipliers and per-instance scalars of its instances in REGISTERS for all iterations (Ctx of the stage
-// phases, RES = true instantiations: nothing is written back between iterations), the condensed stage blocks, the cost-to-go and the
-// Newton step in LDS slots (Slot<NX>, one per (instance, stage)), and the KKT solve is the lane-parallel Riccati recursion of
-// mpc_riccati_lanes.h run by wavefront 0 out of those slots: rows of the cost-to-go over the lanes, one LDS round trip per stage for 8
-// instances.  No hand-off, no queue, no global memory traffic inside the loop; an instance that has converged only idles its own lanes,
-// and a workgroup leaves when its last instance is done -- the hardware dispatcher hands the CU to the next workgroup of the grid.
-// One round of a workgroup:
-//   stage phases (all threads)  step lengths, line search, update, derivatives, KKT error, barrier update  -> stage blocks into the slots
-//   backward sweep (wave 0)     P_N ... P_0 into the slots (repeated with IPOPT's delta_w schedule while some Lam is indefinite)
-//   gain phase (all threads)    K, k_ff of every stage at once from P_{k+1}; closed-loop rows for the forward sweep into the slots
-//   forward sweep (wave 0)      dx_0 ... dx_N, one LDS round trip per stage
-// Start iterate (phase_init_point) and the first evaluation run in the same launch; k_ingest / k_prestart* before and k_egest behind it
-// are the streaming path's kernels.
-// LDS: [reduction scratch | bounds table | instance records | sweep exchange | slots] -- the multiplier stash of the line search and the
-// neighbour-stage exchange rows alias the slot region (its contents are dead between res_round_begin and the next assembly).
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wavefront execute in program order: what is needed is only that the compiler keeps that order
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-template <int NX>
-__host__ __device__ inline size_t resident_region_doubles(int S, int bx, int threads, int stash_rows) {
-    const size_t slots = (size_t)Slot<NX>::SIZE * S * bx, stash = (size_t)stash_rows * threads, ex = (size_t)2 * NX * threads;
-    return slots > stash ? (slots > ex ? slots : ex) : (stash > ex ? stash : ex);
-}
-template <int NX>
-__host__ __device__ inline size_t resident_lds_doubles(int S, int bx, int threads, int stash_rows) {
-    const size_t nb = ((size_t)S * (NX + 2) + 1) & ~(size_t)1;
-    return (size_t)(threads >> 6) * 10 * bx + 2 * nb + (size_t)bx * IR_SIZE + (size_t)8 * Xch<NX>::GROUP + resident_region_doubles<NX>(S, bx, threads, stash_rows);
-}
-
-template <int NX>
-__global__ void __launch_bounds__(256) k_resident(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ int or_slots[2][8];
-    using SL = Slot<NX>;
-    using XC = Xch<NX>;
-    int or_parity = 0;
-    Ctx<NX> c;
-    const int bx = P.bx, t = threadIdx.x, T = blockDim.x, N = P.N;
-    const uint32_t b0 = (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
-    c.k = t / bx;
-    c.b = (int)b0 + (t & (bx - 1));
-    c.valid = (c.k <= N) && (c.b < P.B);
-    c.active = false;
-    c.status = 0;
-    c.iters = 0;
-    const int nb = (N + 1) * (NX + 2), nbe = (nb + 1) & ~1;
-    double* lds_b = lds + (T >> 6) * 10 * bx;
-    double* lds_i = lds_b + 2 * nbe;
-    double* lds_xc = lds_i + bx * IR_SIZE;
-    double* lds_s = lds_xc + 8 * XC::GROUP;
-    for (int q = t; q < nb; q += T) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
-    for (int q = t; q < bx * (int)IR_SIZE; q += T) lds_i[q] = 0.0;
-    c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
-    c.bnd_ub = nb;
-    const mpc_lds_ptr slots = (mpc_lds_ptr)(lds_ptr_t)lds_s;
-    const mpc_lds_ptr insts = (mpc_lds_ptr)(lds_ptr_t)lds_i;
-    const mpc_lds_ptr xch = (mpc_lds_ptr)(lds_ptr_t)lds_xc;
-    const int ts = (c.k <= N) ? t : 0;                         // (padding threads of the last wavefront never touch their slot)
-    c.slot = slots + ts * SL::SIZE;
-    c.inst = insts + (t & (bx - 1)) * (int)IR_SIZE;
-    const mpc_lds_cptr slot_next = (c.k < N) ? (mpc_lds_cptr)(c.slot + bx * SL::SIZE) : (mpc_lds_cptr)c.slot;
-    lds_barrier();
-    // neighbour-stage exchange through LDS (rows alias the slot region: barrier on both sides)
-    auto exchange = [&]() {
-        double* ex = lds_s;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { ex[i * T + t] = c.z[2 + i]; ex[(NX + i) * T + t] = c.lam[i]; }
-        lds_barrier();
-        const int tn = t + bx;
-        if (tn < T) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { c.xn[i] = ex[i * T + tn]; c.lamn[i] = ex[(NX + i) * T + tn]; }
-        }
-        lds_barrier();
-    };
-    {
-        Red0 r0;
-        phase_init_point<NX, true>(P, c, r0);
-        block_reduce(r0, bx, lds);
-        phase_init_scalars<NX, true>(P, c, r0);
-        exchange();
-        Red3 r3;
-        phase_eval_assemble<NX, false, true>(P, c, r3);
-        block_reduce(r3, bx, lds);
-        phase_finish<NX, true>(P, c, r3, n_mult, n_z);
-    }
-    uint32_t rounds = 0, sweeps = 0;
-    // (profiling aid, option "res_timing": shader-clock stamps of the workgroup's third round)
-#define RES_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (;;) {
-        if (!block_or((c.valid && c.status == ST_RUNNING) ? 1 : 0, or_slots, or_parity)) break;
-        ++rounds;
-        RES_STAMP(0);
-        res_announce<NX>(c);
-        lds_barrier();                                           // stage blocks and activity flags are in LDS
-        // ---------------------------------------------------------------- backward sweep(s): wavefront 0, lane = 8 * instance + row
-        if (t < 64) {
-            const int g = t >> 3, gs = g < bx ? g : 0;
-            const mpc_lds_ptr ig = insts + gs * (int)IR_SIZE;
-            const bool ia = g < bx && ig[IR_RSTAT] > 0.0;
-            const mpc_lds_ptr xg = xch + g * XC::GROUP;
-            LaneRic<NX> L;
-            lane_setup<NX>(L, t, bx, ia, ig);
-            for (;;) {
-                ++sweeps;
-                lane_terminal<NX>(L, slots + (N * bx + gs) * SL::SIZE);
-                for (int k = N - 1; k >= 0; --k) {
-                    const mpc_lds_ptr s = slots + (k * bx + gs) * SL::SIZE;
-                    lane_bwd_A<NX>(P, L, s, xg);
-                    wave_lds_sync();
-                    lane_bwd_B<NX>(P, L, k, s, xg);
-                    wave_lds_sync();
-                    lane_sym_out<NX>(L, xg);
-                    wave_lds_sync();
-                    lane_sym_in<NX>(L, xg);
-                    lane_bwd_store<NX>(L, s);
-                    wave_lds_sync();
-                }
-                lane_sweep_decide<NX>(L);
-                if (!__any(L.need ? 1 : 0)) break;
-            }
-            lane_sweep_finish<NX>(L, ia, ig);
-        }
-        lds_barrier();
-        RES_STAMP(1);
-        // ---------------------------------------------------------------- gains of all stages at once
-        res_gain<NX>(P, c, slot_next);
-        lds_barrier();
-        RES_STAMP(2);
-        // ---------------------------------------------------------------- forward sweep: wavefront 0, lane = 8 * instance + component
-        if (t < 64) {
-            const int g = t >> 3, gs = g < bx ? g : 0, r = t & 7;
-            const mpc_lds_ptr ig = insts + gs * (int)IR_SIZE;
-            const bool go = g < bx && r < NX && ig[IR_RSTAT] > 0.0;
-            if (go) slots[gs * SL::SIZE + SL::DX + r] = -ig[IR_C0 + r];
-            for (int k = 0; k < N; ++k) {
-                wave_lds_sync();
-                if (go) {
-                    const double v = lane_forward_step<NX>(P, r, slots + (k * bx + gs) * SL::SIZE);
-                    slots[((k + 1) * bx + gs) * SL::SIZE + SL::DX + r] = v;
-                }
-            }
-        }
-        lds_barrier();
-        RES_STAMP(3);
-        res_round_begin<NX>(P, c, slot_next);
-        if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) continue;
-        RES_STAMP(4);
-        Red1 r1;
-        phase_step_candidates<NX>(P, c, r1);
-        block_reduce(r1, bx, lds);
-        phase_linesearch_begin<NX>(P, c, r1);
-        RES_STAMP(5);
-        double* stash = lds_s;                                   // (every slot read of this round is behind the barrier of block_or)
-        if (MPC_STAGE_STASH) stash_xfer<NX, true>(c, stash, T, t, P.has_ou != 0);
-        while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
-            Red2 r2;
-            phase_trial_eval<NX>(P, c, r2);
-            block_reduce(r2, bx, lds);
-            phase_linesearch_decide<NX, true>(P, c, r2);
-        }
-        if (MPC_STAGE_STASH) stash_xfer<NX, false>(c, stash, T, t, P.has_ou != 0);
-        RES_STAMP(6);
-        phase_apply_update<NX, true>(P, c);
-        RES_STAMP(7);
-        exchange();
-        RES_STAMP(8);
-        Red3 r3;
-        phase_eval_assemble<NX, true, true>(P, c, r3);
-        RES_STAMP(9);
-        block_reduce(r3, bx, lds);
-        phase_finish<NX, true>(P, c, r3, n_mult, n_z);
-        RES_STAMP(10);
-    }
-#undef RES_STAMP
-    res_store<NX>(P, c);
-    if (stats != nullptr && t == 0) {
-        atomicMax(stats + 0, rounds);
-        atomicAdd(stats + 1, rounds);
-        atomicAdd(stats + 2, sweeps);
     }
 #endif
 }
@@ -1777,7 +1584,7 @@ struct mpc_handle {
     size_t pipe_words = 0;
     uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (16 words)
     bool pipe_disabled = false;        // set when a pipeline launch had to be abandoned (see k_pipeline)
-    int last_mode = 0;                 // 0: one launch per kernel and iteration, 1: single-launch pipeline, 2: resident solve (k_resident)
+    int last_mode = 0;                 // 0: one launch per kernel and iteration, 1: single-launch pipeline (+ k_solve_wg behind it), 2: k_solve_wg alone
     int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
     int32_t* h_counter = nullptr;      // pinned, [MAX_GROUPS][2] (double-buffered per poll)
     hipEvent_t ev_poll[4][2] = {};
@@ -1794,12 +1601,12 @@ struct mpc_handle {
     // profiling
     bool profiling = false;
     double prof[6] = {0, 0, 0, 0, 0, 0};
-    double res_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // k_resident: ms (profiling only), ran, rounds of the slowest workgroup, workgroups, workgroup-rounds, Riccati sweeps
+    double res_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // k_solve_wg: ms (profiling only), ran, rounds of the slowest workgroup, workgroups, workgroup-rounds, Riccati sweeps, instance-iterations
     double pipe_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // k_pipeline: ms (profiling only), launches, rounds, Riccati-wait / stage-wait / stage-busy ms summed over workers, items, stage workers + riccati workers / 1000
     int n_cu = 256;
     uint32_t xcd_mask = 0xFFu;          // XCDs seen by k_xcd_census
     std::vector<hipEvent_t> ev_pool;
-    uint32_t* d_fail = nullptr;         // [0] instances of the last solve that did not converge (counted by k_egest); [1] sticky abort word of an asynchronous closed loop; [2..4] k_resident: rounds of the slowest workgroup, workgroup-rounds, Riccati sweeps
+    uint32_t* d_fail = nullptr;         // [0] instances of the last solve that did not converge (counted by k_egest); [1] sticky abort word of an asynchronous closed loop; [2..5] k_solve_wg: rounds of the slowest workgroup, workgroup-rounds, Riccati sweeps, instance-iterations
     bool async_loop = false;            // solves are being enqueued by the closed-loop driver without host synchronisation
     bool async_ok = false;              // ... and the last one really went out that way
     uint32_t* h_fail = nullptr;         // pinned copy
@@ -2174,15 +1981,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const mpc_handle::Knobs& kn = h->knobs;
     const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
     int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
-    // resident solve (k_resident): a workgroup owns up to 8 instances (one lane group of the Riccati wavefront each) for all iterations
-    // workgroup-resident solve (k_solve_wg, option resident = 2): the stage phases of the streaming paths + a wave-per-instance MFMA Riccati
-    const bool use_wg = kn.resident == 2 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
-    bool use_res = kn.resident == 1 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
-    if (use_res) {
-        const int bxr = std::min(bx, 8), thr = ((((int)d.N + 1) * bxr + 63) / 64) * 64;
-        const int srows = MPC_STAGE_STASH ? std::max(Stash<NX>::rows(h->hp.has_ou != 0), 2 * NX) : 2 * NX;
-        if (thr <= 256 && resident_lds_doubles<NX>(d.N + 1, bxr, thr, srows) * sizeof(double) <= (size_t)160 * 1024 - 1024) bx = bxr; else use_res = false;
-    }
+    // workgroup-resident solve with whole 8-instance workgroups (k_solve_wg, option resident): the stage phases of the streaming paths +
+    // the wave-per-instance MFMA Riccati, no pipeline at all (the hybrid solve uses the same kernel with one wavefront per workgroup)
+    const bool use_wg = kn.resident != 0 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
@@ -2217,7 +2018,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resident<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
         }
@@ -2278,7 +2078,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
         else
             hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
-        if (!use_res) launch_stage(q, true);
+        launch_stage(q, true);
         prof.end(q.st);
     }
 
@@ -2340,11 +2140,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
     const size_t lds_wg = wg_lds(bx);
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
-    if (use_res || (use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
-        // ---- resident solves: ALL iterations of every instance in one launch, one workgroup per bx instances
+    if ((use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
+        // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
         if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
         HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
-        const size_t lds_res = resident_lds_doubles<NX>(S, bx, threads, stash_rows) * sizeof(double);
         const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
@@ -2353,8 +2152,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             P.DBG = t_rdbg.as<unsigned long long>();
         }
         prof.begin(5, stream);
-        if (use_res) hipLaunchKernelGGL((k_resident<NX>), dim3(nblk), dim3(threads), lds_res, stream, P, h->hp.n_mult, h->hp.n_z, stash_rows, h->d_fail + 2);
-        else launch_wg(wg_only ? hyb_bx : bx, nullptr);
+        launch_wg(wg_only ? hyb_bx : bx, nullptr);
         prof.end(stream);
         prof.begin(2, stream);
         hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail);
@@ -2372,17 +2170,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipMemcpy(hd.data(), P.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             double acc[16] = {0};
             int cnt = 0;
-            if (use_res) {
-                for (int bq = 0; bq < nblk; ++bq) {
-                    const unsigned long long* r = hd.data() + (size_t)bq * 16;
-                    if (!r[10]) continue;
-                    for (int q = 0; q < 10; ++q) acc[q] += (double)(long long)(r[q + 1] - r[q]);
-                    ++cnt;
-                }
-                static const char* names[10] = {"backward", "gains", "forward", "round-begin", "P1+reduce1", "linesearch", "P3-update", "exchange", "P4-eval", "reduce3+P5"};
-                fprintf(stderr, "[mpcgpu resident timing, shader-clock ticks, third round of %d workgroups]", cnt);
-                for (int q = 0; q < 10; ++q) fprintf(stderr, " %s=%.0f", names[q], cnt ? acc[q] / cnt : 0.0);
-            } else {
+            {
                 // k_solve_wg: 12 round start, 13 records in LDS, 14 sweeps done, [0..10 stage_block's own stamps], 15 round end
                 const int order[16] = {12, 13, 14, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 15};
                 for (int bq = 0; bq < nblk_dbg; ++bq) {

@@ -9,7 +9,6 @@ LIB = os.path.join(HERE, "libmpc_emu.so")
 DEPS = [SRC,
         os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpc_stage_math.h"),
         os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpc_host_common.h"),
-        os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpc_riccati_lanes.h"),
         os.path.join(ROOT, "include", "mpcgpu.h"),
         os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpc_closed_loop.h"),
         os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "mpc_forces_qp.h")]

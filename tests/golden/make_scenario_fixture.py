@@ -1,39 +1,74 @@
 #!/usr/bin/env python3
 """
-Cuts tests/golden/scenarios/USA_Lanker-2_18_T-1_route.xml out of the reference's scenario file: the lanelets the route of
-planning problem 21007 touches plus their neighbours (predecessors, successors, adjacent lanes, the other goal lanelets) and the
-planning problem itself -- DATA of a CommonRoad scenario -- and, of its 83 dynamic obstacles (which the lane-following use case
-never reads), the four that come closest to the recorded ego trajectory (for the collision verdict of row f4).  Run in the build container: `python tests/golden/make_scenario_fixture.py`.
+Writes the scenario DATA fixtures of tests/golden/scenarios/ from the reference's scenario files (run in the build container:
+`python tests/golden/make_scenario_fixture.py`; the GPU box has no /root/reference):
+
+  USA_Lanker-2_18_T-1_route.xml  cut out of scenarios/USA_Lanker-2_18_T-1.xml (2.4 MB): the lanelets the route of planning problem 21007
+                                 touches plus their neighbours (predecessors, successors, adjacent lanes, the other goal lanelets), the
+                                 planning problem itself and, of its 83 dynamic obstacles (which the lane-following use case never reads),
+                                 the four that come closest to the recorded ego trajectory (for the collision verdict of row f4)
+  USA_Peach-2_1_T-1_route.xml    the same cut of scenarios/USA_Peach-2_1_T-1.xml (549 kB) for planning problem 1500: the ten lanelets of
+                                 its route with their neighbours, the planning problem, the four dynamic obstacles nearest to the route
+  ZAM_Tutorial_Urban-3_2.xml     scenarios/ZAM_Tutorial_Urban-3_2.xml unchanged (61 kB: two lanelets, one parked vehicle, planning problem 11)
 """
 import os
+import shutil
 import xml.etree.ElementTree as ET
 
-SRC = "/root/reference/scenarios/USA_Lanker-2_18_T-1.xml"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenarios", "USA_Lanker-2_18_T-1_route.xml")
-ROUTE = [3672, 3452, 3454, 3456]
-OBSTACLES = [2829, 2839, 2716, 2858]
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenarios")
+REF = "/root/reference/scenarios"
 
 
-def main():
-    root = ET.parse(SRC).getroot()
+def cut(src, out, route, obstacles):
+    root = ET.parse(os.path.join(REF, src)).getroot()
     lan = {int(l.attrib["id"]): l for l in root.findall("lanelet")}
-    keep = set(ROUTE)
+    keep = set(route)
     pp = root.find("planningProblem")
     keep |= {int(g.attrib["ref"]) for g in pp.findall("goalState/position/lanelet")}
     for lid in list(keep):
         for tag in ("predecessor", "successor", "adjacentLeft", "adjacentRight"):
             keep |= {int(n.attrib["ref"]) for n in lan[lid].findall(tag)}
     keep = {k for k in keep if k in lan}
-    out = ET.Element("commonRoad", root.attrib)
+    new = ET.Element("commonRoad", root.attrib)
     for lid in sorted(keep):
-        out.append(lan[lid])
-    for o in root.findall("obstacle"):
-        if int(o.attrib["id"]) in OBSTACLES:
-            out.append(o)
-    out.append(pp)
-    ET.indent(out) if hasattr(ET, "indent") else None
-    ET.ElementTree(out).write(OUT, xml_declaration=True, encoding="utf-8")
-    print("wrote", OUT, "with lanelets", sorted(keep), os.path.getsize(OUT), "bytes")
+        new.append(lan[lid])
+    for tag in ("obstacle", "dynamicObstacle", "staticObstacle"):
+        for o in root.findall(tag):
+            if int(o.attrib["id"]) in obstacles:
+                new.append(o)
+    new.append(pp)
+    ET.indent(new) if hasattr(ET, "indent") else None
+    path = os.path.join(HERE, out)
+    ET.ElementTree(new).write(path, xml_declaration=True, encoding="utf-8")
+    print("wrote", path, "with lanelets", sorted(keep), os.path.getsize(path), "bytes")
+
+
+def nearest_dynamic_obstacles(src, route_pts, n=4):
+    """ids of the n moving obstacles whose trajectories come closest to the polyline `route_pts`"""
+    import numpy as np
+    root = ET.parse(os.path.join(REF, src)).getroot()
+    best = []
+    for tag in ("obstacle", "dynamicObstacle"):
+        for o in root.findall(tag):
+            pts = np.array([[float(s.find("position/point/x").text), float(s.find("position/point/y").text)]
+                            for s in o.findall("trajectory/state") if s.find("position/point/x") is not None])
+            if len(pts):
+                d = np.min(np.linalg.norm(pts[:, None, :] - route_pts[None, :, :], axis=-1))
+                best.append((d, int(o.attrib["id"])))
+    return [i for _, i in sorted(best)[:n]]
+
+
+def main():
+    import sys
+    import numpy as np
+    cut("USA_Lanker-2_18_T-1.xml", "USA_Lanker-2_18_T-1_route.xml", [3672, 3452, 3454, 3456], [2829, 2839, 2716, 2858])
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "..", ".."))
+    scn = __import__("importlib").import_module("motion-planning-for-autonomous-driving-with-mpc_amd.scenario")
+    sc = scn.read_scenario(os.path.join(REF, "USA_Peach-2_1_T-1.xml"))
+    path, ids = scn.plan_route(sc, sc.planning_problems[1500])
+    cut("USA_Peach-2_1_T-1.xml", "USA_Peach-2_1_T-1_route.xml", ids, nearest_dynamic_obstacles("USA_Peach-2_1_T-1.xml", np.asarray(path)))
+    shutil.copyfile(os.path.join(REF, "ZAM_Tutorial_Urban-3_2.xml"), os.path.join(HERE, "ZAM_Tutorial_Urban-3_2.xml"))
+    print("copied ZAM_Tutorial_Urban-3_2.xml")
 
 
 if __name__ == "__main__":

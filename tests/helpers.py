@@ -72,8 +72,6 @@ def emu_lib():
         L.emu_solve_batch.argtypes = [C.POINTER(abi.MpcProblemDesc), dp, dp, dp, dp, C.c_int32, dp, dp, dp, dp, ip, ip, dp, dp,
                                       C.c_int32, ip, C.c_int32]
         L.emu_solve_batch.restype = C.c_int
-        L.emu_solve_batch_resident.argtypes = [C.POINTER(abi.MpcProblemDesc), dp, dp, dp, dp, C.c_int32, dp, dp, dp, dp, ip, ip, dp, ip, C.c_int32, ip]
-        L.emu_solve_batch_resident.restype = C.c_int
         L.emu_default_desc.argtypes = [C.POINTER(abi.MpcProblemDesc), C.c_int32, C.c_int32]
         L.emu_closed_loop_piece.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp, ip, C.c_int32, C.c_int32, C.c_double, C.c_uint64]
@@ -122,27 +120,6 @@ def emu_solve(cfg, x0, p, bx=0, bounds=None, obst=None, fixed_iters=0, want_rc=F
         return rc
     assert rc == 0, rc
     return dict(x=out, status=st, iters=it, kkt=kkt, trace=tr[: nit[0] + 1])
-
-
-def emu_solve_resident(cfg, x0, p, bx=0, bounds=None, obst=None, fixed_iters=0):
-    """the resident solve path (k_resident: lane-parallel Riccati, iterate kept on chip) stepped on the CPU"""
-    x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    p = np.ascontiguousarray(p, dtype=np.float64)
-    if bounds is None:
-        bounds = BicycleNLP(cfg).bounds()
-    lbg, ubg, lbx, ubx = [np.ascontiguousarray(a, dtype=np.float64) for a in bounds]
-    B = x0.shape[0]
-    out = np.zeros_like(x0)
-    st, it, kkt = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
-    nit, nsw = np.zeros(1, np.int32), np.zeros(1, np.int32)
-    d = emu_desc(cfg, fixed_iters)
-    if obst is not None:
-        obst = np.ascontiguousarray(obst, dtype=np.float64)
-    rc = emu_lib().emu_solve_batch_resident(C.byref(d), abi.as_dp(lbx), abi.as_dp(ubx), abi.as_dp(lbg), abi.as_dp(ubg), B, abi.as_dp(x0),
-                                            abi.as_dp(p), abi.as_dp(obst), abi.as_dp(out), abi.as_ip(st), abi.as_ip(it), abi.as_dp(kkt),
-                                            abi.as_ip(nit), bx, abi.as_ip(nsw))
-    assert rc == 0, rc
-    return dict(x=out, status=st, iters=it, kkt=kkt, rounds=int(nit[0]), sweeps=int(nsw[0]))
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -488,7 +488,7 @@ def test_bad_inputs_are_contained_and_reported():
 
 
 def test_mixed_sweep_shard_matches_oracle():
-    """BASELINE configuration 5, one shard on one GPU: 4096 rows dealt over the three problem families (tools/workloads.py), one
+    """BASELINE configuration 5, one shard on one GPU: 4096 rows dealt over the four problem families (tools/workloads.py), one
     handle per family; a sample of every family is checked against the oracle, every converged row against its own constraints"""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -501,17 +501,48 @@ def test_mixed_sweep_shard_matches_oracle():
         s = wl.make_solver(fam)
         r = s.solve(x0, p)
         ok = r.status == 1
-        assert ok.mean() >= (0.98 if fam.kind == "ca" else 1.0), (name, ok.mean())
+        assert ok.all(), (name, ok.mean())                  # (the collision-avoidance cold starts included: second chance behind the C-ABI)
         sel = np.arange(0, len(rows), max(1, len(rows) // 48))[:48]
         ro = OracleSolver(cfg).solve_batch(x0[sel], p[sel], nthreads=8)
         both = ok[sel] & (ro["status"] == 1)
         assert both.mean() >= 0.95
-        assert np.abs(r.x[sel][both] - ro["x"][both]).max() < (1e-6 if fam.kind == "ca" else TOL_ORACLE), name
+        if fam.kind == "ca":                                 # nonconvex: the same local optimum for the large majority
+            assert np.mean(np.abs(r.x[sel][both] - ro["x"][both]).max(axis=1) < 1e-6) >= 0.85
+        else:
+            assert np.abs(r.x[sel][both] - ro["x"][both]).max() < TOL_ORACLE, name
         nlp = BicycleNLP(cfg)
         lbg, ubg, lbx, ubx = nlp.bounds()
         for b in np.nonzero(ok)[0][:: max(1, int(ok.sum()) // 64)]:
             g = nlp.g(r.x[b], p[b])
             assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6) and np.all(r.x[b] >= lbx - 1e-7) and np.all(r.x[b] <= ubx + 1e-7)
+
+
+def test_mixed_sweep_every_shard_maps_rows_to_families():
+    """shards 1..7 of BASELINE configuration 5 (an 8-GPU run solves them on ranks 1..7; one GPU here): the rows a rank would solve,
+    with the handle of the family the generator assigns them to, against per-row oracle solves of the GLOBAL row index -- the
+    generator + family mapping of every shard, not only shard 0"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import workloads as wl
+    solvers = {name: wl.make_solver(wl.FAMILIES[name]) for name in wl.MIXED_ORDER}
+    for rank in range(1, 8):
+        shard = wl.mixed_shard(rank, 8)
+        lo = rank * wl.MIXED_SHARD
+        for i, name in enumerate(wl.MIXED_ORDER):
+            rows, x0, p = shard[name]
+            assert rows[0] >= lo and rows[-1] < lo + wl.MIXED_SHARD and np.all(rows % len(wl.MIXED_ORDER) == i)
+            fam = wl.FAMILIES[name]
+            sel = np.arange(0, len(rows), len(rows) // 6)[:6]
+            r = solvers[name].solve(x0[sel], p[sel])
+            cfg = NLPConfig(N=fam.N, nx=fam.nx, dt=fam.dt, Q=fam.Q, R=fam.R, obstacle=fam.obstacle)
+            for j, g in enumerate(rows[sel]):
+                xg, pg = wl.instance(fam, int(g))                         # the row by its GLOBAL index
+                assert np.array_equal(xg, x0[sel][j]) and np.array_equal(pg, p[sel][j])
+            ro = OracleSolver(cfg).solve_batch(x0[sel], p[sel], nthreads=6)
+            both = (r.status == 1) & (ro["status"] == 1)
+            assert both.mean() >= 0.8, (rank, name)
+            d = np.abs(r.x[both] - ro["x"][both]).max(axis=1)
+            assert (np.mean(d < 1e-6) >= 0.8) if fam.kind == "ca" else (d.max() < TOL_ORACLE), (rank, name, d)
 
 
 def test_gpu_replays_the_dense_ipm_closed_loop_triplets(golden_dir):
@@ -648,7 +679,7 @@ def test_hybrid_solve_matches_oracle_and_the_pipeline(B):
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "usalf_n50_nx5", "ca"])
 def test_wave_per_instance_kernel_options_agree(fam):
     """k_solve_wg alone (hand-over threshold 64) with one or two instances per wavefront, and with a whole 8-instance workgroup
-    (option resident = 2): an instance's result does not depend on which instance shares its wavefront -- bit-identical"""
+    (option resident = 1): an instance's result does not depend on which instance shares its wavefront -- bit-identical"""
     if fam == "ca":
         cfg = CA_CFG
         x0, p = ca_batch(cfg, 256)
@@ -665,7 +696,7 @@ def test_wave_per_instance_kernel_options_agree(fam):
         res.append(s.solve(x0, p))
         assert s.get_resident_profile()["ran"] and not s.get_pipeline_profile()["ran"]
     s.set_option("hybrid", "0")
-    s.set_option("resident", "2")
+    s.set_option("resident", "1")
     res.append(s.solve(x0, p))
     assert s.get_resident_profile()["ran"]
     assert _same(res[0], res[1]) and _same(res[0], res[2])

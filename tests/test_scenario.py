@@ -237,3 +237,75 @@ def test_mpc_planner_plan_and_collision_check(tmp_path, framework, use_case):
         sc.obstacles = []                                        # ... and nothing on the obstacle-free variant
         collides, _, off_road, _ = planner.collision_check()
         assert not collides and not off_road
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The other two plannable scenarios of the reference's scenarios/ directory (no recorded runs, no yaml: lane-following weights of
+# config_LF_ZAM_Over-1_1.yaml): ZAM_Tutorial_Urban-3_2 (planning problem 11, goal rectangle at (92.5, 0), time 30..40:
+# ZAM_Tutorial_Urban-3_2.xml:3430-3446) and USA_Peach-2_1_T-1 (planning problem 1500, ten lanelets through an intersection).
+# (ZAM_Tutorial-1_2_T-1 is the one without a goal state: test_planning_problem_without_goal_is_refused.)
+# ---------------------------------------------------------------------------------------------------------------------------
+XML_TUT = os.path.join(ROOT, "tests", "golden", "scenarios", "ZAM_Tutorial_Urban-3_2.xml")
+XML_PEACH = os.path.join(ROOT, "tests", "golden", "scenarios", "USA_Peach-2_1_T-1_route.xml")
+
+
+def _lf_configuration(xml, pid, predict_horizon=10):
+    settings = {k: (dict(v) if isinstance(v, dict) else v) for k, v in SETTINGS_LF.items()}
+    settings["general_planning_settings"] = dict(settings["general_planning_settings"], predict_horizon=predict_horizon)
+    settings["vehicle_settings"] = {pid: dict(reference_point="rear", vehicle_model="parameters_vehicle2", wheelbase=2.578, resampling_reference_path=True)}
+    sc = scn.read_scenario(xml)
+    return sc, scn.Configuration(settings, sc, pid).configuration
+
+
+def test_tutorial_urban_and_peach_configurations():
+    """configuration.py:499-552 on the two scenarios no recorded run exists for: run length = the goal's time limit, desired velocity =
+    clipped path length / ((T - 1) dt) rounded up to 1e-4 (:538-544), path resampled at v_des * dt from the initial position to the goal"""
+    sc, conf = _lf_configuration(XML_TUT, 11)
+    pp = sc.planning_problems[11]
+    assert np.array_equal(pp.initial_position, [60.0, 0.06]) and pp.initial_velocity == 9.0 and pp.goal_time_end == 40
+    assert len(sc.lanelets) == 2 and len(sc.obstacles) == 1 and conf.lanelets_leading_to_goal == [1]
+    assert conf.iter_length == 40 and conf.reference_path.shape == (40, 2) and np.array_equal(conf.reference_path[0], [60.0, 0.06])
+    assert np.abs(conf.reference_path[-1] - [92.5, 0.0]).max() < 0.2                                  # ends at the goal rectangle's centre
+    length = np.linalg.norm(np.diff(conf.reference_path, axis=0), axis=1).sum()
+    assert conf.delta_t == 0.25                                                                          # this scenario's timeStepSize
+    assert abs(conf.desired_velocity - 3.3338) < 1e-9 and abs(length / (39 * 0.25) - conf.desired_velocity) < 0.02
+    sc, conf = _lf_configuration(XML_PEACH, 1500)
+    pp = sc.planning_problems[1500]
+    assert np.array_equal(pp.initial_position, [0.0, 0.0]) and pp.initial_velocity == 0.0 and pp.goal_time_end == 105
+    assert conf.lanelets_leading_to_goal == [53836, 53838, 53806, 53812, 53818, 53866, 53864, 53862, 53894, 53902]
+    assert conf.iter_length == 105 and conf.reference_path.shape == (105, 2) and abs(conf.desired_velocity - 8.9804) < 1e-9
+    step = np.linalg.norm(np.diff(conf.reference_path, axis=0), axis=1)
+    assert np.all(np.abs(step[1:-1] / (conf.desired_velocity * conf.delta_t) - 1.0) < 0.05)      # (first / last: the joints to the initial and goal positions)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["tutorial_urban", "peach"])
+def test_tutorial_urban_and_peach_closed_loop_on_the_gpu(which):
+    """scenario file -> configuration -> CasadiOptimizer.optimize (device loop): every step converges, the plant pins consecutive
+    rows, the vehicle ends near the goal having tracked the path (Tutorial: time step 0.25 s, brakes from 9 to 3.3 m/s; Peach: starts at rest and turns
+    through the intersection)"""
+    pkg = __import__("importlib").import_module("motion-planning-for-autonomous-driving-with-mpc_amd")
+    xml, pid = (XML_TUT, 11) if which == "tutorial_urban" else (XML_PEACH, 1500)
+    sc, conf = _lf_configuration(xml, pid)
+    L = conf.iter_length
+
+    def run():
+        o = pkg.CasadiOptimizer(configuration=conf, init_values=scn.init_values(sc, pid), predict_horizon=10)
+        states, controls, _ = o.optimize()
+        assert states.shape == (L, 5) and controls.shape == (L, 2) and o._sol.stats()["success"]
+        x, u = states[:-1], controls[:-1]
+        xn = x + conf.delta_t * np.stack([x[:, 3] * np.cos(x[:, 4]), x[:, 3] * np.sin(x[:, 4]), u[:, 0], u[:, 1], x[:, 3] / 2.5789128 * np.tan(x[:, 2])], -1)
+        assert np.abs(states[1:] - xn).max() < 1e-12
+        return states
+    states = run()
+    dev = M.deviation_euclidean(states, conf.origin_reference_path)
+    if which == "peach":
+        # A standing start (v_0 = 0) against reference points that move on at v_des = 9 m/s from the first step (the window is indexed by
+        # TIME, optimizer.py:657-702) and an acceleration capped at sqrt(11.5) by the stage-0 friction row: the ego runs some ten metres
+        # behind its reference points and cuts the corners of the intersection -- every solve converges (asserted in run()), the plan is
+        # the reference formulation's.  It reaches the desired speed and stays within a lane width or two of the route.
+        assert states[:, 3].max() > 0.9 * conf.desired_velocity and dev.max() < 8.0
+        return
+    # (before the reference window freezes at step L - N, optimizer.py:670-683: from there on the vehicle is pulled to a fixed set of points)
+    assert dev[10:L - 10].max() < 0.6, dev[10:L - 10].max()
+    assert np.linalg.norm(states[L - 11, :2] - conf.reference_path[L - 11]) < 3.0

@@ -25,10 +25,11 @@ def _cfg_of(fam):
 
 
 def test_generators_agree_with_the_oracle_side():
-    for name, kw in (("zamlf_n30_nx6", {}), ("usalf_n50_nx5", dict(v_range=(5.0, 9.0)))):
+    for name, oname, kw in (("zamlf_n30_nx6", "zamlf_n30_nx6", {}), ("usalf_n50_nx5", "usalf_n50_nx5", dict(v_range=(5.0, 9.0))),
+                            ("tutlf_n30_nx5", "zamlf_n30_nx5", dict(v_range=(3.0, 9.0)))):
         fam = wl.FAMILIES[name]
         x0, p = wl.batch(fam, 9, start=5)
-        xo, po = synthetic_batch(FAMILIES[name][0], 9, start=5, **kw)
+        xo, po = synthetic_batch(FAMILIES[oname][0], 9, start=5, **kw)
         assert np.array_equal(x0, xo) and np.array_equal(p, po)
     fam = wl.FAMILIES["zamca_n30_nx5"]
     x0, p = wl.batch(fam, 7, start=3)
@@ -47,15 +48,15 @@ def test_bounds_agree_with_the_oracle_side(name):
 
 
 def test_mixed_sweep_partition():
-    """32 768 rows, 8 shards of 4096, three families dealt row by row: every row exactly once, shards contiguous"""
+    """32 768 rows, 8 shards of 4096, four families dealt row by row: every row exactly once, shards contiguous"""
     seen = np.zeros(wl.MIXED_TOTAL, dtype=int)
     for r in range(8):
         rows = wl.mixed_shard_rows(r, 8)
         allr = np.sort(np.concatenate(list(rows.values())))
         assert allr[0] == r * wl.MIXED_SHARD and allr[-1] == (r + 1) * wl.MIXED_SHARD - 1 and len(allr) == wl.MIXED_SHARD
         for i, name in enumerate(wl.MIXED_ORDER):
-            assert np.all(rows[name] % 3 == i)
-            assert 1365 <= len(rows[name]) <= 1366
+            assert np.all(rows[name] % len(wl.MIXED_ORDER) == i)
+            assert len(rows[name]) == wl.MIXED_SHARD // len(wl.MIXED_ORDER)
         seen[allr] += 1
     assert np.all(seen == 1)
     assert wl.MIXED_ROW_WIDTH == 355
@@ -80,7 +81,7 @@ def _free_port():
     return port
 
 
-TOTAL = 24          # a small "sweep": 2 shards of 12 rows, 4 rows per family and shard
+TOTAL = 24          # a small "sweep": 2 shards of 12 rows, 3 rows per family and shard
 
 
 def _worker(rank, world, port, outdir):
@@ -106,7 +107,7 @@ def test_mixed_sweep_two_ranks_gloo(tmp_path):
     got = np.load(tmp_path / "mixed.npy")
     assert got.shape == (TOTAL, wl.MIXED_ROW_WIDTH)
     for g in range(TOTAL):
-        fam = wl.FAMILIES[wl.MIXED_ORDER[g % 3]]
+        fam = wl.FAMILIES[wl.MIXED_ORDER[g % len(wl.MIXED_ORDER)]]
         x0, p = wl.instance(fam, g)
         ref = emu_solve(_cfg_of(fam), x0[None], p[None])["x"][0]
         assert np.abs(got[g, : fam.n_w] - ref).max() < 1e-12 and np.all(got[g, fam.n_w:] == 0.0)

@@ -7,7 +7,10 @@ oracle tests use).
   zamlf_n30_nx6     2 / headline      30       6   config_LF_ZAM_Over-1_1.yaml:19-31                  dummy (-100, 0)
   zamca_n30_nx5     3                 30       5   config_CA_ZAM_Over-1_1.yaml:38-50                  ZAM_Over-1_1.xml:3235-3258
   usalf_n50_nx5     4                 50       5   config_LF_USA_Lanker-2_18_T-1.yaml:19-31           dummy
-  mixed sweep       5                 all three, dealt row by row (global row g -> family g % 3), 4096 rows per shard
+  tutlf_n30_nx5     5 ("Tutorial")    30       5   config_LF_ZAM_Over-1_1.yaml:19-31 (the reference      dummy
+                                                   ships no yaml for ZAM_Tutorial_Urban-3_2; its planning
+                                                   problem 11 is slow urban lane following: 9 m/s start, 3.3 m/s desired)
+  mixed sweep       5                 all four, dealt row by row (global row g -> family g % 4), 4096 rows per shard
 
 Every instance b draws from numpy.random.default_rng(20240929 + b): constant-curvature reference arc, perturbed initial state,
 warm start = [0 ; tile(X_ref[:, 0])] (the layout of optimizer.py:550).
@@ -62,8 +65,9 @@ FAMILIES = {
     "zamca_n30_nx5": Family("zamca_n30_nx5", 30, 5, (2.3, 2.3, 500.0, 0.1, 160.0), (0.8, 0.8),
                             obstacle=(59.948, 0.08323, 6.0, 3.5, 0.07759), kind="ca"),
     "usalf_n50_nx5": Family("usalf_n50_nx5", 50, 5, (200.0, 200.0, 150.0, 150.0, 1.0), (100.0, 10.0), v_range=(5.0, 9.0)),
+    "tutlf_n30_nx5": Family("tutlf_n30_nx5", 30, 5, (2.3, 2.3, 500.0, 0.1, 10.0), (2.0, 0.2), v_range=(3.0, 9.0)),
 }
-MIXED_ORDER = ("zamlf_n30_nx6", "zamca_n30_nx5", "usalf_n50_nx5")
+MIXED_ORDER = ("zamlf_n30_nx6", "zamca_n30_nx5", "usalf_n50_nx5", "tutlf_n30_nx5")        # BASELINE.json configs[4]: ZAM_Over + USA_Lanker + Tutorial
 MIXED_TOTAL, MIXED_SHARD = 32768, 4096
 
 
@@ -155,7 +159,7 @@ def make_solver(fam: Family, **kw):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# configuration 5: the mixed scenario sweep.  Global row g of 32 768 belongs to family MIXED_ORDER[g % 3] and is instance g of
+# configuration 5: the mixed scenario sweep.  Global row g of 32 768 belongs to family MIXED_ORDER[g % 4] and is instance g of
 # that family's generator; shard r (one per GPU) is the contiguous block of rows [4096 r, 4096 (r + 1)).
 # ------------------------------------------------------------------------------------------------------------------------
 def mixed_family_of(g):
