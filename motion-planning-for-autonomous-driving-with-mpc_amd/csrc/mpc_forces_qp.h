@@ -41,6 +41,7 @@ struct ForcesQpArgs {
     int32_t* status;                              // [B]        exitflag: 1 solved, 0 iteration limit, -6 NaN, -7 infeasible QP (FORCESNLPsolver.h:68-106)
     double* kkt;                                  // [B]        final residual (max of dual / primal / equality / complementarity)
     double* ws;                                   // [FQP_ROWS * N][Bp]
+    uint32_t ws_bytes;                            // its size (device: buffer addressing, below 4 GiB)
 };
 
 // per-stage workspace rows
@@ -101,6 +102,13 @@ MPC_HD bool fq_row_on(const ForcesQpArgs& A, int k, int q) {
 }
 
 // FORCES-mode stage functions (row a11), one (z, p) pair: cost gradient, RK4 step + Jacobian, inequalities + Jacobian
+// (device: every loop over a fixed range is unrolled, so that the small arrays of the phases are registers with literal indices -- the
+//  RK4 sensitivities below are mostly structural zeros and ones that fold away -- instead of dynamically indexed scratch arrays)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ_UNROLL _Pragma("unroll")
+#else
+#define FQ_UNROLL
+#endif
 MPC_HD void forces_ode_eval(const double* x, const double* u, double l, double* f, double* F4, double& F42, double& F43) {
     const double sn = sin(x[4]), cs = cos(x[4]), td = tan(x[2]);
     f[0] = x[3] * cs; f[1] = x[3] * sn; f[2] = u[0]; f[3] = u[1]; f[4] = x[3] / l * td;
@@ -114,6 +122,7 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
     const double r[5] = {z[2] - p[0], z[3] - p[1], z[4], z[5] - p[2], z[6] - p[3]};
     fval = 0.0;
     gf[0] = gf[1] = 0.0;
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) { fval += w[i] * r[i] * r[i]; gf[2 + i] = 2.0 * w[i] * r[i]; }
     if (!terminal) {
         fval += A.R[0] * z[0] * z[0] + A.R[1] * z[1] * z[1];
@@ -124,21 +133,27 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
         const double* u = z;
         const double* x = z + 2;
         double xs[5], kk[5], acc[5], dk[35], dacc[35], dxs[35];
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             xs[i] = x[i];
             acc[i] = 0.0;
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) { dxs[i * 7 + j] = (j == i + 2) ? 1.0 : 0.0; dacc[i * 7 + j] = 0.0; dk[i * 7 + j] = 0.0; }
         }
         const double aw[4] = {0.0, 0.5, 0.5, 1.0}, bw[4] = {1.0, 2.0, 2.0, 1.0};
+        FQ_UNROLL
         for (int s = 0; s < 4; ++s) {
             if (s > 0) {
+                FQ_UNROLL
                 for (int i = 0; i < 5; ++i) {
                     xs[i] = x[i] + aw[s] * A.dt * kk[i];
+                    FQ_UNROLL
                     for (int j = 0; j < 7; ++j) dxs[i * 7 + j] = ((j == i + 2) ? 1.0 : 0.0) + aw[s] * A.dt * dk[i * 7 + j];
                 }
             }
             double F4[4], F42, F43;
             forces_ode_eval(xs, u, A.l, kk, F4, F42, F43);
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) {
                 dk[0 * 7 + j] = F4[0] * dxs[3 * 7 + j] + F4[1] * dxs[4 * 7 + j];
                 dk[1 * 7 + j] = F4[2] * dxs[3 * 7 + j] + F4[3] * dxs[4 * 7 + j];
@@ -146,17 +161,22 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
                 dk[3 * 7 + j] = (j == 1) ? 1.0 : 0.0;
                 dk[4 * 7 + j] = F42 * dxs[2 * 7 + j] + F43 * dxs[3 * 7 + j];
             }
+            FQ_UNROLL
             for (int i = 0; i < 5; ++i) {
                 acc[i] += bw[s] * kk[i];
+                FQ_UNROLL
                 for (int j = 0; j < 7; ++j) dacc[i * 7 + j] += bw[s] * dk[i * 7 + j];
             }
         }
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             c[i] = x[i] + A.dt / 6.0 * acc[i];
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) jc[i * 7 + j] = ((j == i + 2) ? 1.0 : 0.0) + A.dt / 6.0 * dacc[i * 7 + j];
         }
     }
     if (h != nullptr) {
+        FQ_UNROLL
         for (int i = 0; i < 70; ++i) jh[i] = 0.0;
         const double td = tan(z[4]);
         const double q = z[5] * z[5] * td / A.wb;                 // v * psi_dot
@@ -165,9 +185,11 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
         jh[4] = 2.0 * q * z[5] * z[5] * (1.0 + td * td) / A.wb;
         jh[5] = 2.0 * q * 2.0 * z[5] * td / A.wb;
         const double sn = sin(z[6]), cs = cos(z[6]);
+        FQ_UNROLL
         for (int e = 0; e < 3; ++e) {
             const double sg = (e == 0) ? 0.0 : (e == 1 ? 1.0 : -1.0);
             const double ex = z[2] + sg * A.rho * cs, ey = z[3] + sg * A.rho * sn;
+            FQ_UNROLL
             for (int j = 0; j < 3; ++j) {
                 const double dx = ex - p[4 + 2 * j], dy = ey - p[5 + 2 * j];
                 const int row = 1 + 3 * e + j;
@@ -180,14 +202,34 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
     }
 }
 
+// Workspace element (stage k_, row row_) of the thread's instance.  Device: a BUFFER access -- per-thread byte offset of (stage, instance)
+// in the vector offset, the row's offset row_ * Bp * 8 (wave-uniform; row_ is a literal after unrolling) in the scalar offset.  With
+// plain 64-bit pointers the compiler precomputed one address per row (224 pairs of registers), spilled them all to scratch before the
+// iteration loop and reloaded one before every access: 448 scratch stores and a scratch load in front of each of ~1 200 global accesses.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct FqWsRef {
+    const ForcesQpArgs& A;
+    uint32_t voff, soff;
+    __device__ __forceinline__ operator double() const {
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(A.ws, A.ws_bytes);
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, mpc_uni(soff), 0));
+    }
+    __device__ __forceinline__ double operator=(double x) const {
+        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(A.ws, A.ws_bytes);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, mpc_uni(soff), 0);
+        return x;
+    }
+    __device__ __forceinline__ double operator=(const FqWsRef& o) const { return (*this = (double)o); }
+};
+#define FQW(k_, row_) FqWsRef{A, ((uint32_t)(k_) * (uint32_t)FQ_ROWS * (uint32_t)A.Bp + (uint32_t)c.b) * 8u, (uint32_t)(row_) * (uint32_t)A.Bp * 8u}
+#else
 #define FQW(k_, row_) A.ws[((size_t)(k_) * FQ_ROWS + (size_t)(row_)) * (size_t)A.Bp + (size_t)c.b]
+#endif
 // FQL(dk, GRP, i): entry i of row group GRP (C, P, PV, DXIN) of stage k + dk of the same instance
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FQL(dk_, grp_, i_) c.loc[(FL_##grp_ + (i_)) * c.T + c.t + (dk_) * c.IB]
-#define FQ_UNROLL _Pragma("unroll")
 #else
 #define FQL(dk_, grp_, i_) FQW(c.k + (dk_), FQ_##grp_ + (i_))
-#define FQ_UNROLL
 #endif
 
 // per-(instance, stage) thread state that lives in registers across the phases of one solve
@@ -221,6 +263,7 @@ MPC_HD void fq_each_row(const ForcesQpArgs& A, const FqCtx& c, F f) {
         if (fq_row_on(A, k, 14)) f(14, 3, 1, 4, 5, a, b2, d);
         if (fq_row_on(A, k, 24)) f(24, 3, 1, 4, 5, -a, -b2, -d);
     }
+    FQ_UNROLL
     for (int j = 1; j < 10; ++j) {
         const double a = FQW(k, FQ_JHS + 3 * j), b2 = FQW(k, FQ_JHS + 3 * j + 1), d = FQW(k, FQ_JHS + 3 * j + 2);
         if (fq_row_on(A, k, 14 + j)) f(14 + j, 3, 2, 3, 6, a, b2, d);
@@ -236,19 +279,27 @@ MPC_HD void fq_build(const ForcesQpArgs& A, FqCtx& c, FqRed& part) {
     if (!c.valid) return;
     const int N = A.N, k = c.k;
     double z[7], p[10], gf[7], cc[5], jc[35], h[10], jh[70], fv;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) z[i] = A.zbar[((size_t)c.b * N + k) * 7 + i];
+    FQ_UNROLL
     for (int i = 0; i < 10; ++i) p[i] = A.params[((size_t)c.b * N + k) * 10 + i];
     const bool term = (k == N - 1);
     forces_stage_functions(A, z, p, term, fv, gf, term ? nullptr : cc, jc, h, jh);
     double gs = 1.0;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) { FQW(k, FQ_G + i) = gf[i]; FQW(k, FQ_W + i) = 0.0; gs = fmax(gs, fabs(gf[i])); }
     FQW(k, FQ_JHS + 0) = jh[1]; FQW(k, FQ_JHS + 1) = jh[4]; FQW(k, FQ_JHS + 2) = jh[5];
+    FQ_UNROLL
     for (int j = 1; j < 10; ++j) { FQW(k, FQ_JHS + 3 * j) = jh[j * 7 + 2]; FQW(k, FQ_JHS + 3 * j + 1) = jh[j * 7 + 3]; FQW(k, FQ_JHS + 3 * j + 2) = jh[j * 7 + 6]; }
     if (!term) {
+        FQ_UNROLL
         for (int i = 0; i < 35; ++i) FQL(0, C, i) = jc[i];
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) FQW(k, FQ_E + i) = cc[i] - (double)A.zbar[((size_t)c.b * N + k + 1) * 7 + 2 + i];
     }
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = 0.0;
+    FQ_UNROLL
     for (int q = 0; q < FQ_MI; ++q) {
         double d = 0.0;
         if (q < 7) d = z[q] - A.lb[q];
@@ -271,11 +322,15 @@ MPC_HD void fq_residual(const ForcesQpArgs& A, const FqCtx& c, FqRed& part) {
     double w[7], rd[7], mu = 0.0, rmax = 0.0, rdmax = 0.0;
     int M = 0;
     const double* hd = (k == N - 1) ? A.hdN : A.hd;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); rd[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i); }
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) rd[2 + i] += (double)FQW(k, FQ_PI + i);
     if (k < N - 1)
+        FQ_UNROLL
         for (int j = 0; j < 7; ++j) {
             double t = 0.0;
+            FQ_UNROLL
             for (int r = 0; r < 5; ++r) t += (double)FQL(0, C, r * 7 + j) * (double)FQW(k + 1, FQ_PI + r);
             rd[j] -= t;
         }
@@ -288,12 +343,15 @@ MPC_HD void fq_residual(const ForcesQpArgs& A, const FqCtx& c, FqRed& part) {
         mu += s * lam;
         ++M;
     });
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) rdmax = fmax(rdmax, fabs(rd[i]));
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) {
         double re;
         if (k == 0) re = w[2 + i] - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i]);
         else {
             re = w[2 + i] - (double)FQW(k - 1, FQ_E + i);
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) re -= (double)FQL(-1, C, i * 7 + j) * (double)FQW(k - 1, FQ_W + j);
         }
         rmax = fmax(rmax, fabs(re));
@@ -326,11 +384,15 @@ MPC_HD void fq_newton_prep(const ForcesQpArgs& A, FqCtx& c, bool corr, double si
     if (!(c.valid && c.run)) return;
     const int N = A.N, k = c.k;
     double w[7];
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) w[i] = FQW(k, FQ_W + i);
     const double* hd = (k == N - 1) ? A.hdN : A.hd;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) c.rho[i] = hd[i] * w[i] + (double)FQW(k, FQ_G + i);
     if (!corr) {
+        FQ_UNROLL
         for (int i = 0; i < 28; ++i) c.Phi[i] = 0.0;
+        FQ_UNROLL
         for (int i = 0; i < 7; ++i) c.Phi[i * 7 - i * (i - 1) / 2] = hd[i];
     }
     fq_each_row(A, c, [&](FQ_ROW_ARGS) {
@@ -352,10 +414,13 @@ MPC_HD void fq_newton_prep(const ForcesQpArgs& A, FqCtx& c, bool corr, double si
             }
         }
     });
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) c.eps[i] = 0.0;
     if (k < N - 1)
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * w[j];
             c.eps[i] = t;
         }
@@ -370,49 +435,67 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
     const double* Phi = c.Phi;
     const double* eps = c.eps;
     double Pp[15], pv[5];
+    FQ_UNROLL
     for (int i = 0; i < 15; ++i) Pp[i] = (k < N - 1) ? (double)FQL(1, P, i) : 0.0;
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) pv[i] = (k < N - 1) ? (double)FQL(1, PV, i) : 0.0;
     // Q-function blocks.  Stage N-1 has no successor
     double Huu[3], Hux[10], hu[2], hx[5];
     if (!corr) {
         Huu[0] = Phi[0]; Huu[1] = Phi[1]; Huu[2] = Phi[7];
+        FQ_UNROLL
         for (int j = 0; j < 5; ++j) { Hux[j] = Phi[2 + j]; Hux[5 + j] = Phi[7 + 1 + j]; }
     }
     hu[0] = rho[0]; hu[1] = rho[1];
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) hx[i] = rho[2 + i];
     double Cm[35];
     if (k < N - 1) {
         double q5[5];
+        FQ_UNROLL
         for (int i = 0; i < 35; ++i) Cm[i] = FQL(0, C, i);
         if (!corr) {
             double Pe[5];
+            FQ_UNROLL
             for (int i = 0; i < 5; ++i) {
                 double t = 0.0;
+                FQ_UNROLL
                 for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * eps[j];
                 Pe[i] = t;
                 FQW(k, FQ_PE + i) = t;
             }
-            // the u-rows of C' (P C): M = P C (5x7), then rows 0, 1 of C' M
-            double M[35];
-            for (int i = 0; i < 5; ++i)
-                for (int j = 0; j < 7; ++j) {
+            // the u-rows of C' (P C), column by column: m = column j of P C (5 numbers live at a time, not the 5 x 7 product), then
+            // rows 0, 1 of C' against it
+            FQ_UNROLL
+            for (int j = 0; j < 7; ++j) {
+                double m[5];
+                FQ_UNROLL
+                for (int i = 0; i < 5; ++i) {
                     double t = 0.0;
+                    FQ_UNROLL
                     for (int r = 0; r < 5; ++r) t += Pp[fq_sidx(i, r)] * Cm[r * 7 + j];
-                    M[i * 7 + j] = t;
+                    m[i] = t;
                 }
-            for (int i = 0; i < 2; ++i)
-                for (int j = i; j < 7; ++j) {
+                FQ_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    if (j < i) continue;
                     double t = 0.0;
-                    for (int r = 0; r < 5; ++r) t += Cm[r * 7 + i] * M[r * 7 + j];
+                    FQ_UNROLL
+                    for (int r = 0; r < 5; ++r) t += Cm[r * 7 + i] * m[r];
                     if (j < 2) Huu[i + j] += t;
                     else Hux[i * 5 + (j - 2)] += t;
                 }
+            }
+            FQ_UNROLL
             for (int i = 0; i < 5; ++i) q5[i] = Pe[i] + pv[i];
         } else {
+            FQ_UNROLL
             for (int i = 0; i < 5; ++i) q5[i] = (double)FQW(k, FQ_PE + i) + pv[i];
         }
+        FQ_UNROLL
         for (int j = 0; j < 7; ++j) {
             double t = 0.0;
+            FQ_UNROLL
             for (int r = 0; r < 5; ++r) t += Cm[r * 7 + j] * q5[r];
             if (j < 2) hu[j] += t; else hx[j - 2] += t;
         }
@@ -420,17 +503,23 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
     double hi[3], Kk[10], Puu[3], Pxu[10];
     if (!corr) {
         Puu[0] = Phi[0]; Puu[1] = Phi[1]; Puu[2] = Phi[7];
+        FQ_UNROLL
         for (int j = 0; j < 5; ++j) { Pxu[j] = Phi[2 + j]; Pxu[5 + j] = Phi[8 + j]; }
         const double det = Huu[0] * Huu[2] - Huu[1] * Huu[1];
         hi[0] = Huu[2] / det; hi[1] = -Huu[1] / det; hi[2] = Huu[0] / det;
+        FQ_UNROLL
         for (int j = 0; j < 5; ++j) {
             Kk[j] = -(hi[0] * Hux[j] + hi[1] * Hux[5 + j]);
             Kk[5 + j] = -(hi[1] * Hux[j] + hi[2] * Hux[5 + j]);
         }
+        FQ_UNROLL
         for (int i = 0; i < 3; ++i) { FQW(k, FQ_HUI + i) = hi[i]; FQW(k, FQ_PHU + i) = Puu[i]; }
+        FQ_UNROLL
         for (int i = 0; i < 10; ++i) { FQW(k, FQ_K + i) = Kk[i]; FQW(k, FQ_HXU + i) = Pxu[i]; }
     } else {
+        FQ_UNROLL
         for (int i = 0; i < 3; ++i) { hi[i] = FQW(k, FQ_HUI + i); Puu[i] = FQW(k, FQ_PHU + i); }
+        FQ_UNROLL
         for (int i = 0; i < 10; ++i) { Kk[i] = FQW(k, FQ_K + i); Pxu[i] = FQW(k, FQ_HXU + i); }
     }
     const double kf0 = -(hi[0] * hu[0] + hi[1] * hu[1]), kf1 = -(hi[1] * hu[0] + hi[2] * hu[1]);
@@ -441,47 +530,60 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
     double Acl[25], t5[5] = {0, 0, 0, 0, 0};
     if (k < N - 1) {
         double off[5];
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             off[i] = eps[i] + Cm[i * 7 + 0] * kf0 + Cm[i * 7 + 1] * kf1;
+            FQ_UNROLL
             for (int j = 0; j < 5; ++j) Acl[i * 5 + j] = Cm[i * 7 + 2 + j] + Cm[i * 7 + 0] * Kk[j] + Cm[i * 7 + 1] * Kk[5 + j];
         }
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             double t = pv[i];
+            FQ_UNROLL
             for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * off[j];
             t5[i] = t;
         }
     }
     double pn[5];
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) {
         double t = rho[2 + i] + Kk[i] * rho[0] + Kk[5 + i] * rho[1];
         t += (Pxu[i] + Kk[i] * Puu[0] + Kk[5 + i] * Puu[1]) * kf0 + (Pxu[5 + i] + Kk[i] * Puu[1] + Kk[5 + i] * Puu[2]) * kf1;
         if (k < N - 1)
+            FQ_UNROLL
             for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * t5[r];
         pn[i] = t;
     }
     if (!corr) {
-        double PA[25], P[15];                                  // P+ A_cl
-        if (k < N - 1)
-            for (int i = 0; i < 5; ++i)
-                for (int j = 0; j < 5; ++j) {
+        // column by column: pa = column j of P+ A_cl (5 numbers live at a time), entries (i <= j) of the new cost-to-go go straight out
+        FQ_UNROLL
+        for (int j = 0; j < 5; ++j) {
+            double pa[5] = {0, 0, 0, 0, 0};
+            if (k < N - 1) {
+                FQ_UNROLL
+                for (int i = 0; i < 5; ++i) {
                     double t = 0.0;
+                    FQ_UNROLL
                     for (int r = 0; r < 5; ++r) t += Pp[fq_sidx(i, r)] * Acl[r * 5 + j];
-                    PA[i * 5 + j] = t;
+                    pa[i] = t;
                 }
-        for (int i = 0; i < 5; ++i)
-            for (int j = i; j < 5; ++j) {
+            }
+            FQ_UNROLL
+            for (int i = 0; i <= j; ++i) {
                 double t = Phi[(i + 2) * 7 - (i + 2) * (i + 1) / 2 + (j - i)];
                 t += Pxu[i] * Kk[j] + Pxu[5 + i] * Kk[5 + j] + Kk[i] * Pxu[j] + Kk[5 + i] * Pxu[5 + j];
                 t += Kk[i] * (Puu[0] * Kk[j] + Puu[1] * Kk[5 + j]) + Kk[5 + i] * (Puu[1] * Kk[j] + Puu[2] * Kk[5 + j]);
                 if (k < N - 1)
-                    for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * PA[r * 5 + j];
-                P[fq_sidx(i, j)] = t;
+                    FQ_UNROLL
+                    for (int r = 0; r < 5; ++r) t += Acl[r * 5 + i] * pa[r];
+                FQL(0, P, fq_sidx(i, j)) = t;
             }
-        for (int i = 0; i < 15; ++i) FQL(0, P, i) = P[i];
+        }
     }
     // the step of u_k is finished in the forward sweep; keep kff (in the DW rows for now) and p_k
     FQW(k, FQ_DW + 0) = kf0;
     FQW(k, FQ_DW + 1) = kf1;
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) FQL(0, PV, i) = pn[i];
 }
 
@@ -491,23 +593,30 @@ MPC_HD void fq_newton_fwd(const ForcesQpArgs& A, FqCtx& c) {
     if (!(c.valid && c.run)) return;
     const int N = A.N, k = c.k;
     double dx[5];
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i)
         dx[i] = (k == 0) ? -((double)FQW(0, FQ_W + 2 + i) - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i]))
                          : (double)FQL(0, DXIN, i);
     double du[2] = {FQW(k, FQ_DW + 0), FQW(k, FQ_DW + 1)};
+    FQ_UNROLL
     for (int j = 0; j < 5; ++j) { du[0] += (double)FQW(k, FQ_K + j) * dx[j]; du[1] += (double)FQW(k, FQ_K + 5 + j) * dx[j]; }
     const double dw[7] = {du[0], du[1], dx[0], dx[1], dx[2], dx[3], dx[4]};
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) FQW(k, FQ_DW + i) = dw[i];
     // new equality multipliers of block k: -(P_k dx_k + p_k)
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) {
         double t = FQL(0, PV, i);
+        FQ_UNROLL
         for (int j = 0; j < 5; ++j) t += (double)FQL(0, P, fq_sidx(i, j)) * dx[j];
         FQW(k, FQ_DPI + i) = -t;
     }
     if (k < N - 1) {
+        FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
             // dx_{k+1} = C dw + eps,  eps = e_k - w_{k+1}[2:7] + C w_k
             double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
+            FQ_UNROLL
             for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * ((double)FQW(k, FQ_W + j) + dw[j]);
             FQL(1, DXIN, i) = t;
         }
@@ -519,6 +628,7 @@ MPC_HD void fq_newton_rows(const ForcesQpArgs& A, const FqCtx& c, bool corr, dou
     if (!(c.valid && c.run)) return;
     const int k = c.k;
     double w[7], dw[7];
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) { w[i] = FQW(k, FQ_W + i); dw[i] = FQW(k, FQ_DW + i); }
     fq_each_row(A, c, [&](FQ_ROW_ARGS) {
         const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), d = FQW(k, FQ_D + q);
@@ -540,6 +650,7 @@ MPC_HD void fq_steplen(const ForcesQpArgs& A, const FqCtx& c, double frac, FqRed
     if (!(c.valid && c.run)) return;
     const int k = c.k;
     double a_p = 1.0, a_d = 1.0;
+    FQ_UNROLL
     for (int q = 0; q < FQ_MI; ++q) {
         if (!fq_row_on(A, k, q)) continue;
         const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), ds = FQW(k, FQ_DS + q), dl = FQW(k, FQ_DL + q);
@@ -557,6 +668,7 @@ MPC_HD void fq_mu_aff(const ForcesQpArgs& A, const FqCtx& c, double a_aff, FqRed
     if (!(c.valid && c.run)) return;
     const int k = c.k;
     double m = 0.0;
+    FQ_UNROLL
     for (int q = 0; q < FQ_MI; ++q) {
         if (!fq_row_on(A, k, q)) continue;
         m += ((double)FQW(k, FQ_S + q) + a_aff * (double)FQW(k, FQ_DS + q)) * ((double)FQW(k, FQ_LAM + q) + a_aff * (double)FQW(k, FQ_DL + q));
@@ -570,8 +682,11 @@ MPC_HD void fq_max_combine(FqRed& a, const FqRed& p) { a.a = fmax(a.a, p.a); }
 MPC_HD void fq_update(const ForcesQpArgs& A, FqCtx& c, double a_p, double a_d) {
     if (!(c.valid && c.run)) return;
     const int k = c.k;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) FQW(k, FQ_W + i) = (double)FQW(k, FQ_W + i) + a_p * (double)FQW(k, FQ_DW + i);
+    FQ_UNROLL
     for (int i = 0; i < 5; ++i) FQW(k, FQ_PI + i) = (double)FQW(k, FQ_PI + i) + a_d * ((double)FQW(k, FQ_DPI + i) - (double)FQW(k, FQ_PI + i));
+    FQ_UNROLL
     for (int q = 0; q < FQ_MI; ++q) {
         if (!fq_row_on(A, k, q)) continue;
         FQW(k, FQ_S + q) = (double)FQW(k, FQ_S + q) + a_p * (double)FQW(k, FQ_DS + q);
@@ -584,6 +699,7 @@ MPC_HD void fq_update(const ForcesQpArgs& A, FqCtx& c, double a_p, double a_d) {
 MPC_HD void fq_output(const ForcesQpArgs& A, const FqCtx& c) {
     if (!c.valid) return;
     const int N = A.N, k = c.k;
+    FQ_UNROLL
     for (int i = 0; i < 7; ++i) A.z_out[((size_t)c.b * N + k) * 7 + i] = (double)A.zbar[((size_t)c.b * N + k) * 7 + i] + (double)FQW(k, FQ_W + i);
     if (k == 0) {
         if (A.iters) A.iters[c.b] = c.it;

@@ -2882,6 +2882,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     const int N = d.N;
     const size_t nB = (size_t)B, Bp = (nB + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream_;
+    if ((size_t)FQ_ROWS * N * Bp * 8 >= ((size_t)1 << 32)) { h->err = "forces solve: batch too large for one call (workspace of 4 GiB)"; return MPC_ERR_INVALID; }
     double* dws = static_cast<double*>(scratch_get(h, 10, (size_t)FQ_ROWS * N * Bp * 8));
     int32_t* dflag = d_exitflag ? d_exitflag : static_cast<int32_t*>(scratch_get(h, 11, nB * 4));
     int32_t* dit = d_it ? d_it : static_cast<int32_t*>(scratch_get(h, 12, nB * 4));
@@ -2896,7 +2897,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     forces_hessian_diag(hessian_mode, A.Q, A.R, A.Pt, A.hd, A.hdN);
     for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
     for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
-    A.zbar = d_x0; A.params = d_all_parameters; A.xinit = d_xinit; A.z_out = d_x_out; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws;
+    A.zbar = d_x0; A.params = d_all_parameters; A.xinit = d_xinit; A.z_out = d_x_out; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws; A.ws_bytes = (uint32_t)((size_t)FQ_ROWS * N * Bp * 8);
     int IB = 1;
     while (IB * 2 * N <= 256 && IB < 64) IB *= 2;                       // instances per workgroup: all N stages of IB instances in <= 256 threads
     const int threads = ((IB * N + 63) / 64) * 64;
