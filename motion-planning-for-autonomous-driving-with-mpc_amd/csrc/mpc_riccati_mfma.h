@@ -7,22 +7,26 @@
 // lies ACROSS the 64 lanes of a wavefront and one backward stage is five matrix instructions,
 //     Y = M+ At          T = At' Y + Ht          M = T + Gt' Kt (+ delta_w I)          with  Gt = B'Y + [Hux | gu],  Kt = -Lam^-1 Gt
 // (At = [A -c; 0 1], Ht = [H gx; gx' 0]: the affine terms ride along as row / column 7, so p_k and k_ff need no recursion of their
-// own), ~210 ticks of dependent latency per stage instead of ~2 200.  The forward sweep is two matrix instructions per stage:
-// x_{k+1} = (At + Bt Kt) x_k in block column 0 and du_k = Kt x_k in block column 1 of the same products.
+// own): 602 ticks per stage instead of 2 230, issue bound (~95 instructions, a wavefront issues in order).  The forward sweep is ONE
+// matrix instruction per stage: x~' = (At + Bt Kt) x~ with the two rows of Kt in the spare rows 6, 7 of the same product (150 ticks
+// against 720).
 //
 // Lane map of v_mfma_f64_4x4x4_f64 (4 blocks of 4x4x4, one double per lane and operand; measured with tools/ubench/mfma_probe.hip, the
 // guide documents the 16x16x4 form only): lane L = 16 x + 4 blk + y,
 //     A operand: A_blk[i = y][k = x]      B operand: B_blk[k = x][j = y]      C / D: D_blk[i = x][j = y].
-// An 8 x 8 matrix is 2 x 2 blocks, blk = 2 I + J: "natural" (= D) layout M[4 I + x][4 J + y], i.e. row R = 4 * bit3(L) + (L >> 4),
-// column C = L & 7.  A product X Y takes two instructions (k-steps K = 0, 1) whose operands are natural-layout registers with their
-// 4-lane banks moved inside each 16-lane row -- DPP row shifts with a bank mask, no LDS:
-//     B operand of k-step K = banks of Y  [b0 b1 b0 b1] (K = 0) / [b2 b3 b2 b3] (K = 1)
-//     A operand of k-step K = banks of X' [b0 b0 b1 b1] (K = 0) / [b2 b2 b3 b3] (K = 1)      (X' = the TRANSPOSE of X in natural layout:
-//                                                                                            a D register used as A operand is read transposed)
-// M+ is symmetric, so its own register serves as X' of the first product; At and Ht are read from the LDS record of the stage with
-// per-lane offsets (every lane knows which entry of the sparse At it needs).  The two rows of Gt come down from rows 2, 3 of Y with
-// v_permlane32_swap, their partner rows for Kt = -Lam^-1 Gt with a ds_swizzle (swap of 16-lane rows), Lam^-1 is computed by every lane
-// from three v_readlane of M+.
+// An 8 x 8 matrix is 2 x 2 blocks, blk = 2 hi + lo: "natural" (= D) layout M[4 hi + x][4 lo + y], i.e. row R = 4 * bit3(L) + (L >> 4),
+// column C = L & 7.  A D register used as A operand is read TRANSPOSED block by block; M+ is symmetric, so as A operand its block
+// (hi, lo) reads as M_{lo, hi}.  Operands that come out of a product are re-arranged by moving 4-lane banks inside each 16-lane row
+// (DPP row shifts / rotations with a bank mask, no LDS); operands that come from the stage data (At, Ht) are read from the LDS record
+// of the stage with per-lane offsets -- every lane knows which entry of the sparse At it feeds.  Per stage:
+//     Y      one instruction per column block J: block (hi, lo) = M_{lo, hi} At_{hi, J}; the sum over hi (DPP row rotation by 8 + add)
+//            leaves Y_{lo, J} in both halves of every row -- two independent instructions, no chain
+//     T      two chained instructions (k-steps); their B operands are the banks of the two Y registers merged by one DPP move each
+//     Gt     rows 2, 3 of Y (the first of those B operands) brought down to rows 0, 1 by v_permlane32_swap, replicated over hi by
+//            construction: Kt = -Lam^-1 Gt (partner row by ds_swizzle, Lam^-1 by every lane from three v_readlane of M+) IS the B
+//            operand of the rank-2 update, Gt' needs one bank move
+//     M      one instruction: T + Gt' Kt
+// (tools/ubench/ric_mfma_test.hip checks both sweeps against the scalar recursion; DESIGN.md section 4 has the history of the formulation.)
 //
 // Reference: the linear solve inside IPOPT's step computation for the NLP of MPC_Planner/optimizer.py:373-558 (the reference hands it
 // to MUMPS); recursion and inertia-correction schedule as riccati_instance (mpc_stage_math.h).  The rounding differs from the
@@ -56,33 +60,6 @@ __device__ __forceinline__ double wv_dpp(double old, double src) {
     return __hiloint2double(hi, lo);
 }
 constexpr int DPP_SHL4 = 0x104, DPP_SHL8 = 0x108, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118;     // row_shl: lane <- lane + n, row_shr: lane <- lane - n
-// B operand of k-step K from a natural-layout register
-template <int K>
-__device__ __forceinline__ double wv_opB(double v) {
-    if (K == 0) return wv_dpp<DPP_SHR8, 0xC>(v, v);           // [b0 b1 b0 b1]
-    return wv_dpp<DPP_SHL8, 0x3>(v, v);                       // [b2 b3 b2 b3]
-}
-// A operand of k-step K from the natural-layout register of the TRANSPOSED left factor
-template <int K>
-__device__ __forceinline__ double wv_opA(double v) {
-    if (K == 0) {
-        const double t = wv_dpp<DPP_SHR4, 0x6>(v, v);         // [b0 b0 b1 b3]
-        return wv_dpp<DPP_SHR8, 0x8>(t, v);                   // [b0 b0 b1 b1]
-    }
-    const double t = wv_dpp<DPP_SHL4, 0x6>(v, v);             // [b0 b2 b3 b3]
-    return wv_dpp<DPP_SHL8, 0x1>(t, v);                       // [b2 b2 b3 b3]
-}
-// every bank <- bank 2K (block column 0 of block row K): the B operand of the forward sweep
-template <int K>
-__device__ __forceinline__ double wv_bcast(double v) {
-    if (K == 0) {
-        const double t = wv_dpp<DPP_SHR4, 0x2>(v, v);         // [b0 b0 b2 b3]
-        return wv_dpp<DPP_SHR8, 0xC>(t, t);                   // [b0 b0 b0 b0]
-    }
-    double t = wv_dpp<DPP_SHL8, 0x1>(v, v);                   // [b2 b1 b2 b3]
-    t = wv_dpp<DPP_SHR4, 0x8>(t, v);                          // [b2 b1 b2 b2]
-    return wv_dpp<DPP_SHL4, 0x2>(t, v);                       // [b2 b2 b2 b2]
-}
 // lanes 0..31 <- lanes 32..63 of v, lanes 32..63 <- 0
 __device__ __forceinline__ double wv_upper_to_lower(double v) {
     const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), 0u, false, false);
@@ -198,14 +175,6 @@ struct MfmaInst {
     double delta_last;
 };
 
-// 1 / d for the 2 x 2 determinant: v_rcp_f64 + two Newton steps (the IEEE division sequence is twice as long and sits on the
-// critical path of every stage; the quotient only scales Lam^-1, whose rounding the recursion does not depend on)
-__device__ __forceinline__ double wv_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-}
 // x + (x with the two halves of every 16-lane row exchanged): the sum over the block index hi, left in both halves
 __device__ __forceinline__ double wv_sum_hi(double v) {
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x128, 0xF, 0xF, false);       // row_ror:8
@@ -333,7 +302,7 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
             for (int q = 0; q < NI; ++q) {
                 Gs[q] = wv_swap16(G[q]);
                 good[q] = good[q] && (L00[q] > 0.0) && (det[q] > 0.0);
-                i00[q] = L11[q] * rc[q]; i01[q] = -L01[q] * rc[q]; i11[q] = L00[q] * rc[q];
+                i00[q] = L11[q] * rc[q]; i01[q] = -L01[q] * rc[q]; i11[q] = L00[q] * rc[q];      // (rc = 1 / det: v_rcp_f64 + two Newton steps)
             }
             MPC_FENCE();
 #pragma unroll

@@ -522,10 +522,16 @@ __device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_at
 __device__ __forceinline__ void pipe_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pipe_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// measurement helper (mpc_measure_copy_bandwidth): the plain streaming copy, 16 bytes per lane and access, grid-stride
+// measurement helper (mpc_measure_copy_bandwidth): the plain streaming copy, 16 bytes per lane and access, four independent accesses
+// per lane and trip (a workgroup moves 16 KiB per trip), grid-stride
 __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n; i += stride) {
+        const uint4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+    }
+    for (; i < n; i += 256) dst[i] = src[i];
 }
 
 // which XCDs does this device have?  (one bit per HW_REG_XCC_ID that some workgroup of a grid of 4 x CUs ran on)
@@ -1882,7 +1888,7 @@ int mpc_measure_copy_bandwidth(mpc_handle* h, size_t bytes, int32_t reps, double
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    const int blocks = h->n_cu * 8;
+    const int blocks = h->n_cu * 16;
     double best = 0.0;
     for (int r = 0; r < reps + 1; ++r) {
         HIP_TRY(h, hipEventRecord(e0, h->own_stream));
