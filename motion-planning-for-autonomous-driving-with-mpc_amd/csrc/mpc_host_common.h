@@ -116,6 +116,7 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
 // element(row, b) = (b >> 6) * tile_elems + mpc_prow(row) + 2 * (b & 63).
 struct WsLayout {
     size_t Z, ZL, ZU, SO, NUO, ZLO, ZUO, LAM, REF, DZ, PK, KK, BLK, ROLL, SC, FILT, OBST;
+    size_t MZ, MZL, MZU, MSO, MNUO, MZLO, MZUO, MLAM, MREF;
     size_t MBLK, MPK, MDZ;       // ELEMENT offsets of the instance-major mailbox arrays ([instance][stage][rows], behind the tiles)
     size_t rows, irows;          // rows per tile (double / int32 workspace)
     size_t tile_elems, itile_elems, ntiles;
@@ -145,6 +146,15 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     w.MBLK = w.total; w.total += Bp * S * NBLK;
     w.MPK = w.total; w.total += Bp * S * NPK;
     w.MDZ = w.total; w.total += Bp * S * NZ;
+    w.MZ = w.total; w.total += Bp * S * NZ;
+    w.MZL = w.total; w.total += Bp * S * NZ;
+    w.MZU = w.total; w.total += Bp * S * NZ;
+    w.MSO = w.total; w.total += Bp * S * 4;
+    w.MNUO = w.total; w.total += Bp * S * 4;
+    w.MZLO = w.total; w.total += Bp * S * 4;
+    w.MZUO = w.total; w.total += Bp * S * 4;
+    w.MLAM = w.total; w.total += Bp * S * XS;
+    w.MREF = w.total; w.total += Bp * S * XS;
     w.itotal = w.ntiles * w.itile_elems;
     return w;
 }
@@ -186,6 +196,8 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.BLK = base + w.BLK * 64; P.ROLL = base + w.ROLL * 64; P.SC = base + w.SC * 64;
     P.FILT = base + w.FILT * 64; P.OBST = base + w.OBST * 64;
     P.MBLK = base + w.MBLK; P.MPK = base + w.MPK; P.MDZ = base + w.MDZ;
+    P.MZ = base + w.MZ; P.MZL = base + w.MZL; P.MZU = base + w.MZU; P.MSO = base + w.MSO; P.MNUO = base + w.MNUO; P.MZLO = base + w.MZLO;
+    P.MZUO = base + w.MZUO; P.MLAM = base + w.MLAM; P.MREF = base + w.MREF;
     P.tile_elems = (uint32_t)w.tile_elems; P.itile_elems = (uint32_t)w.itile_elems;
     P.ISC = ibase;
     P.WS = base; P.IWS = ibase;

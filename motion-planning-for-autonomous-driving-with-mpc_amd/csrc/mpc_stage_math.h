@@ -111,6 +111,7 @@ struct Params {
     // all stages of one or two instances -- in the tile-major layout every (stage, row pair) of an instance is a different 1 KiB row, so
     // the 14 / 4 / 17 sixteen-byte pieces of a thread lie in as many cache lines; here they are 224 / 64 / 272 contiguous bytes
     double *MBLK, *MPK, *MDZ;
+    double *MZ, *MZL, *MZU, *MSO, *MNUO, *MZLO, *MZUO, *MLAM, *MREF;     // the iterate, its multipliers and the reference, likewise (filled by k_solve_wg from the tile-major arrays when it takes an instance over)
     double *SC;                  // [SC_COUNT][Bp]
     double *FILT;                // [2*FILTER_MAX][Bp]
     const double* OBST;          // [6][Bp] per-instance obstacle centres (optional)
@@ -237,6 +238,9 @@ __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, u
 #define MPC_LD2(ref, lo, hi) do { const double* p2_ = &(ref); (lo) = p2_[0]; (hi) = p2_[1]; } while (0)
 #define MPC_ST2(ref, lo, hi) do { double* p2_ = &(ref); p2_[0] = (lo); p2_[1] = (hi); } while (0)
 #endif
+//   MPC_KX(ARR, R, dk, e) array ARR of the iterate: the instance-major mailbox copy MARR where the phase is instantiated with MB (the
+//                         workgroup-resident path), the tile-major array otherwise
+#define MPC_KX(arr_, R, dk, e) (MB ? MPC_KM(P.M##arr_, R, dk, e) : MPC_K(P.arr_, R, dk, e))
 // CNT consecutive rows starting at an EVEN row: pairs with 16-byte accesses, an odd last row on its own.  `ref(e)` names
 // row e of the run (use MPC_ROWS around one of the accessors above, written in terms of `e`).
 #define MPC_ROWS(expr) [&](int e) -> decltype(auto) { return (expr); }
@@ -799,7 +803,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     const int N = P.N, k = c.k;
     load_obst(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
-    ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+    ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
     if (MB) ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 0, e)), c.dz); else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
@@ -811,28 +815,28 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         c.zu[i] = 0.0;
         if (i + 1 < NZ) { c.zl[i + 1] = 0.0; c.zu[i + 1] = 0.0; }
         if (((P.lo_mask >> i) & both) || a0) {
-            if (i + 1 < NZ) MPC_LD2(MPC_K(P.ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_K(P.ZL, NZ, 0, i);
+            if (i + 1 < NZ) MPC_LD2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_KX(ZL, NZ, 0, i);
         }
         if (((P.hi_mask >> i) & both) || a0) {
-            if (i + 1 < NZ) MPC_LD2(MPC_K(P.ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_K(P.ZU, NZ, 0, i);
+            if (i + 1 < NZ) MPC_LD2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_KX(ZU, NZ, 0, i);
         }
     }
     if (k < N) {
-        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 1, e)), c.rn);
-        ws_load_rows<NX>(MPC_ROWS(MPC_K(P.Z, NZ, 1, 2 + e)), c.xn);
+        ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
+        ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
         if (MB) ws_load_rows<NX>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 1, 2 + e)), c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
     }
-    ws_load_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), tmp.lam);
+    ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
     for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
     if (MB) ws_load_rows<D::NPK>(MPC_ROWS(MPC_KM(P.MPK, D::NPK, 0, e)), tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
-    ws_load_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
-    ws_load_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
-    if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo); else { c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0; }
-    if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo); else { c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0; }
+    ws_load_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
+    ws_load_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
+    if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo); else { c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0; }
+    if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo); else { c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0; }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
     if (k == 0) {                                          // (fric_row is not known yet; the values are only used if it is set)
@@ -1059,7 +1063,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX>
+template <int NX, bool MB = false>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1081,22 +1085,22 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         c.z[i] = zn;
     }
     // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
-    ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+    ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         const bool a0 = (i == 0) && (k == 0);
         const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
         if (((P.lo_mask >> i) & both) || a0) {
-            if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_K(P.ZL, NZ, 0, i) = c.zl[i];
+            if (i + 1 < NZ) MPC_ST2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KX(ZL, NZ, 0, i) = c.zl[i];
         }
         if (((P.hi_mask >> i) & both) || a0) {
-            if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_K(P.ZU, NZ, 0, i) = c.zu[i];
+            if (i + 1 < NZ) MPC_ST2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_KX(ZU, NZ, 0, i) = c.zu[i];
         }
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
 #pragma unroll
     for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
-    ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), c.lam);
+    ws_store_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), c.lam);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
@@ -1116,10 +1120,10 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
         c.so[j] = sn;
     }
-    if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo);
-    if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo);
-    ws_store_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
-    ws_store_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
+    if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
+    if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
     if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;

@@ -199,7 +199,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         }
         if (STASH) stash_xfer<NX, false>(c, stash, blockDim.x, t, P.has_ou != 0);
         MPC_STAMP(5);
-        phase_apply_update<NX>(P, c);
+        phase_apply_update<NX, MB>(P, c);
         MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
@@ -734,6 +734,29 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         ++rounds;
         inst_rounds += (uint32_t)__popc(mask);
         WG_STAMP(12);
+        // ---- taking the instances over: the iterate, its multipliers and the reference move from the tile-major arrays (where the
+        //      pipeline / the start-iterate kernel left them) into the instance-major mailbox arrays the rounds below work on -- one
+        //      wavefront reads all stages of its one or two instances, and only there are the pieces of a thread contiguous
+        if (rounds == 1u && valid) {
+            constexpr bool MB = true;
+            auto move = [&](auto cnt, auto from, auto to) {
+                constexpr int CNT = decltype(cnt)::value;
+                double v[MPC_EV(CNT)];
+                ws_load_rows<CNT>(from, v);
+                ws_store_rows<CNT>(to, v);
+            };
+            constexpr int NZ = D::NZ;
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)));
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZL, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZL, NZ, 0, e)));
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZU, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZU, NZ, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.SO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MSO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MNUO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MZLO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MZUO, 3, 0, e)));
+            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), MPC_ROWS(MPC_KM(P.MLAM, NX, 0, e)));
+            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.REF, NX, 0, e)), MPC_ROWS(MPC_KM(P.MREF, NX, 0, e)));
+            (void)MB;
+        }
         // ---- stage blocks -> LDS records, instance-major (every stage thread its own; defect negated, three constants, Hux of stage 0)
         if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
             double blk[MPC_EV(D::NBLK)];
@@ -828,6 +851,12 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         WG_STAMP(15);
     }
 #undef WG_STAMP
+    // the iterate goes back to the tile-major rows k_egest reads (a workgroup that found nothing to do never moved it)
+    if (rounds > 0u && valid) {
+        double v[D::NZ];
+        ws_load_rows<D::NZ>(MPC_ROWS(MPC_KM(P.MZ, D::NZ, 0, e)), v);
+        ws_store_rows<D::NZ>(MPC_ROWS(MPC_K(P.Z, D::NZ, 0, e)), v);
+    }
     if (stats != nullptr && t == 0) {
         atomicMax(stats + 0, rounds);
         atomicAdd(stats + 1, rounds);
