@@ -229,6 +229,7 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
 #pragma unroll
         for (int q = 0; q < NI; ++q) { symq[q] = sym[q] || delta[q] != 0.0; symm = symm || symq[q]; }
         double M[NI], b0[NI], b1[NI], aa0[NI], aa1[NI], hc[NI], ha[NI], ruu0[NI], ruu1[NI];
+        mpc_lds_ptr pb0[NI], pb1[NI], paa0[NI], paa1[NI], phc[NI], pha[NI], pruu[NI];
         bool good[NI];
         // (per-lane store offsets: the lanes with an entry walk down the stages of their instance's mailbox rows, the others stay on
         //  row 0 of the KK array -- the scalar offset is the instance's, so theirs is taken relative to it)
@@ -246,29 +247,42 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
             r = rec[q] + (N - 1) * RC::SIZE;
             b0[q] = r[m.oB[0]]; b1[q] = r[m.oB[1]]; aa0[q] = r[m.oAA[0]]; aa1[q] = r[m.oAA[1]]; hc[q] = r[m.oHC]; ha[q] = r[m.oHA];
             ruu0[q] = r[RC::RUU]; ruu1[q] = r[RC::RUU + 1];
+            // operand addresses of the lane, kept on the LOWER record of the two a loop trip prefetches (the other one is an immediate
+            // offset away): seven address updates per two stages instead of one per read
+            r = rec[q] + (N - 3) * RC::SIZE;
+            pb0[q] = r + m.oB[0]; pb1[q] = r + m.oB[1]; paa0[q] = r + m.oAA[0]; paa1[q] = r + m.oAA[1]; phc[q] = r + m.oHC; pha[q] = r + m.oHA;
+            pruu[q] = r + RC::RUU;
+            // (as whole addresses in vector registers: the compiler would otherwise keep the uniform part aside and add it at every read)
+            asm volatile("" : "+v"(pb0[q]), "+v"(pb1[q]), "+v"(paa0[q]), "+v"(paa1[q]), "+v"(phc[q]), "+v"(pha[q]), "+v"(pruu[q]));
         }
-        auto stage = [&](auto sym_tag, int k) {
+        auto bump = [&](int by) {
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { pb0[q] += by; pb1[q] += by; paa0[q] += by; paa1[q] += by; phc[q] += by; pha[q] += by; pruu[q] += by; }
+        };
+        auto stage = [&](auto sym_tag, auto off_tag) {
             constexpr bool SYM = decltype(sym_tag)::value;
+            constexpr int OFF = decltype(off_tag)::value * RC::SIZE;          // the record to prefetch, from the operand addresses
 #pragma unroll
             for (int q = 0; q < NI; ++q) voff[q] -= pk_inc;
             wdec += w_inc;
             double nb0[NI], nb1[NI], naa0[NI], naa1[NI], nhc[NI], nha[NI], nruu0[NI], nruu1[NI];
-            double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], i00[NI], i01[NI], i11[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
+            double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], cl[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
             // The wavefront issues in order: the scalar chain Lam -> det -> 1 / det (ten dependent instructions) is cut into pieces that
             // are laid between the steps of the matrix chain, and the scheduling fences keep the compiler from clumping them again.
 #define MPC_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int q = 0; q < NI; ++q) {        // operands of the next stage (software pipeline; stage -1 reads the pad record)
-                mpc_lds_ptr rn = rec[q] + (k - 1) * RC::SIZE;
-                nb0[q] = rn[m.oB[0]]; nb1[q] = rn[m.oB[1]]; naa0[q] = rn[m.oAA[0]]; naa1[q] = rn[m.oAA[1]]; nhc[q] = rn[m.oHC]; nha[q] = rn[m.oHA];
-                nruu0[q] = rn[RC::RUU]; nruu1[q] = rn[RC::RUU + 1];
+                nb0[q] = pb0[q][OFF]; nb1[q] = pb1[q][OFF]; naa0[q] = paa0[q][OFF]; naa1[q] = paa1[q][OFF]; nhc[q] = phc[q][OFF]; nha[q] = pha[q][OFF];
+                nruu0[q] = pruu[q][OFF]; nruu1[q] = pruu[q][OFF + 1];
             }
 #pragma unroll
             for (int q = 0; q < NI; ++q) {        // Y = M+ At, one instruction per column block; Lam = Ruu + B'P+B (+ delta_w)
                 const double P22 = wv_readlane(M[q], 34), P23 = wv_readlane(M[q], 35), P33 = wv_readlane(M[q], 51);
                 S0[q] = wv_mfma(M[q], b0[q], 0.0);
                 S1[q] = wv_mfma(M[q], b1[q], 0.0);
-                L00[q] = ruu0[q] + dt2 * P22 + delta[q]; L01[q] = dt2 * P23; L11[q] = ruu1[q] + dt2 * P33 + delta[q];
+                L00[q] = ruu0[q] + dt2 * P22; L01[q] = dt2 * P23; L11[q] = ruu1[q] + dt2 * P33;
+                if (SYM) { L00[q] += delta[q]; L11[q] += delta[q]; }               // (the other variant runs with delta_w = 0 on every instance)
+                cl[q] = (x == 0) ? L11[q] : L00[q];                                 // the diagonal entry of adj(Lam) this lane's row of Gt meets
             }
             MPC_FENCE();
 #pragma unroll
@@ -302,15 +316,15 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
             for (int q = 0; q < NI; ++q) {
                 Gs[q] = wv_swap16(G[q]);
                 good[q] = good[q] && (L00[q] > 0.0) && (det[q] > 0.0);
-                i00[q] = L11[q] * rc[q]; i01[q] = -L01[q] * rc[q]; i11[q] = L00[q] * rc[q];      // (rc = 1 / det: v_rcp_f64 + two Newton steps)
+                Kt[q] = -cl[q] * G[q];                                              // -adj(Lam) Gt = L01 Gs - cl G, without waiting for 1 / det
             }
             MPC_FENCE();
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
-                const double ca = (x == 0) ? -i00[q] : -i11[q];
                 const double GA = wv_dpp<DPP_SHL4, 0x6>(G[q], G[q]);               // block (hi, lo) = column block hi of Gt (read transposed)
-                Kt[q] = ca * G[q] - i01[q] * Gs[q];                                // Kt = -Lam^-1 Gt
-                M[q] = wv_mfma(GA, Kt[q], T[q]) + delta[q] * m.dmask;              // M = T + Gt' Kt + delta_w I
+                Kt[q] = fma(L01[q], Gs[q], Kt[q]) * rc[q];                         // Kt = -Lam^-1 Gt  (rc = 1 / det: v_rcp_f64 + two Newton steps)
+                M[q] = wv_mfma(GA, Kt[q], T[q]);                                   // M = T + Gt' Kt + delta_w I
+                if (SYM) M[q] += delta[q] * m.dmask;
                 // (per instance, so that the result of an instance does not depend on which instance shares its wavefront)
                 if (SYM) { const double Ms = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr)); M[q] = symq[q] ? Ms : M[q]; }
                 rec[q][w_first[q] - wdec] = Kt[q];                                              // gains for the forward sweep (lanes without an entry: the dump area)
@@ -327,14 +341,16 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
         };
         // (a sweep whose every instance has met an indefinite Lam is abandoned: it is repeated with a larger delta_w anyway)
         // (two stages per trip: the operand registers of the software pipeline swap roles without copies)
+        using Off0 = std::integral_constant<int, 0>;
+        using Off1 = std::integral_constant<int, 1>;
         if (__builtin_amdgcn_ballot_w64(symm) != 0ull) {
             int k = N - 1;
-            for (; k >= 1 && alive(); k -= 2) { stage(std::true_type{}, k); stage(std::true_type{}, k - 1); }
-            if (k == 0 && alive()) stage(std::true_type{}, 0);
+            for (; k >= 1 && alive(); k -= 2) { stage(std::true_type{}, Off1{}); stage(std::true_type{}, Off0{}); bump(-2 * RC::SIZE); }
+            if (k == 0 && alive()) { bump(RC::SIZE); stage(std::true_type{}, Off0{}); }
         } else {
             int k = N - 1;
-            for (; k >= 1 && alive(); k -= 2) { stage(std::false_type{}, k); stage(std::false_type{}, k - 1); }
-            if (k == 0 && alive()) stage(std::false_type{}, 0);
+            for (; k >= 1 && alive(); k -= 2) { stage(std::false_type{}, Off1{}); stage(std::false_type{}, Off0{}); bump(-2 * RC::SIZE); }
+            if (k == 0 && alive()) { bump(RC::SIZE); stage(std::false_type{}, Off0{}); }
         }
         bool again = false;
 #pragma unroll
