@@ -839,14 +839,16 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // cost-to-go and step are in the L2
         lds_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // (this CU's vector L1 may hold the rows of the last round)
+        // (producer and consumer of every row are wavefronts of THIS workgroup: one CU, one write-through vector L1 -- workgroup scope
+        //  orders them without the cache invalidation an agent-scope acquire costs, which would send every load of the round to the HBM)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(14);
         // ---- the stage work of the round
         stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(15);
     }

@@ -36,6 +36,7 @@ def run(tag):
     print(f"{fam} B={B} {tag:28s} {ms:7.3f} ms/batch = {B / ms * 1e3 / 1e6:6.3f} M steps/s  conv={np.mean(r.status == 1):.4f} iters mean {r.iters.mean():.2f} max {r.iters.max()}"
           f"  launch ms: pipeline {pp['ms']:.3f} ({pp['rounds']} rounds) + wg {rp['ms']:.3f} (slowest {rp['rounds']} rounds, {rp['workgroup_rounds']} wg-rounds, {rp['sweeps']} sweeps)", flush=True)
     return r
+s.set_option("hybrid", "0")
 base = run("pipeline")
 for bx in (1, 2):
     for live in lives:
