@@ -2315,7 +2315,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (d_pdbg) {       // shader-clock stamps of every worker's LAST work item / tile pass
                 std::vector<unsigned long long> hd((size_t)16 * h->n_cu);
                 HIP_TRY(h, hipMemcpy(hd.data(), d_pdbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                double sa[16] = {0}, ra[4] = {0};
+                double sa[16] = {0}, ra[8] = {0};
                 int ns = 0, nr = 0;
                 for (int bq = 0; bq < h->n_cu; ++bq) {
                     const unsigned long long* r = hd.data() + (size_t)bq * 16;
@@ -2326,6 +2326,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                     } else if (r[13] && r[2]) {
                         ra[0] += (double)(long long)(r[12] - r[11]); ra[1] += (double)(long long)(r[1] - r[12]);
                         ra[2] += (double)(long long)(r[2] - r[1]); ra[3] += (double)(long long)(r[13] - r[2]);
+                        ra[4] += (double)(long long)(r[4] - r[3]); ra[5] += (double)(long long)(r[5] - r[4]);
+                        ra[6] += (double)(long long)(r[7] - r[6]); ra[7] += (double)(long long)(r[8] - r[7]);
                         ++nr;
                     }
                 }
@@ -2333,8 +2335,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                                              "exchange", "P4-eval", "reduce3", "P5", "drain", "signal"};
                 fprintf(stderr, "[mpcgpu pipeline timing, shader-clock ticks, last item of %d stage workers]", ns);
                 for (int q = 0; q < 15; ++q) fprintf(stderr, " %s=%.0f", sn[q], ns ? sa[q] / ns : 0.0);
-                fprintf(stderr, "\n[last pass of %d Riccati workers] wait=%.0f backward=%.0f forward=%.0f publish=%.0f\n", nr, nr ? ra[0] / nr : 0.0,
-                        nr ? ra[1] / nr : 0.0, nr ? ra[2] / nr : 0.0, nr ? ra[3] / nr : 0.0);
+                fprintf(stderr, "\n[last pass of %d Riccati workers] wait=%.0f backward=%.0f forward=%.0f publish=%.0f; stage 15 of the backward sweep: barrier=%.0f step=%.0f, of the forward sweep: barrier=%.0f step=%.0f\n",
+                        nr, nr ? ra[0] / nr : 0.0, nr ? ra[1] / nr : 0.0, nr ? ra[2] / nr : 0.0, nr ? ra[3] / nr : 0.0, nr ? ra[4] / nr : 0.0, nr ? ra[5] / nr : 0.0,
+                        nr ? ra[6] / nr : 0.0, nr ? ra[7] / nr : 0.0);
             }
             piped = true;
             h->last_mode = 1;
