@@ -512,7 +512,8 @@ struct PipeArgs {
 constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
 constexpr uint32_t PIPE_STATS = PIPE_ABORT + 2;         // [wait ticks riccati, wait ticks stage, busy ticks stage, items, workers stage, workers riccati]
-constexpr uint32_t PIPE_HDR = PIPE_ABORT + 16;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
+constexpr uint32_t PIPE_WG = PIPE_ABORT + 16;           // statistics of the k_solve_wg launch behind the pipeline (4 words): zeroed and copied back with the block
+constexpr uint32_t PIPE_HDR = PIPE_ABORT + 24;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
 constexpr uint32_t PIPE_EXIT = 0xFFFFFFFFu;
 constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-clock ticks = 50 ms
 __host__ __device__ inline uint32_t pipe_slots_off(uint32_t ntiles) { return (PIPE_HDR + ntiles + 1u) & ~1u; }
@@ -1619,7 +1620,7 @@ struct mpc_handle {
     size_t tile_mask_cap = 0;
     uint32_t* d_pipe = nullptr;        // control block of the single-launch pipeline (k_pipeline)
     size_t pipe_words = 0;
-    uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (16 words)
+    uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (24 words)
     bool pipe_disabled = false;        // set when a pipeline launch had to be abandoned (see k_pipeline)
     int last_mode = 0;                 // 0: one launch per kernel and iteration, 1: single-launch pipeline (+ k_solve_wg behind it), 2: k_solve_wg alone
     int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
@@ -1655,7 +1656,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 2, hybrid_live = -1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1688,7 +1689,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "resident") k.resident = value == nullptr ? 0 : (int)iv;
     else if (n == "res_timing") k.res_timing = on != 0;
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
-    else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 2 : (int)iv;
+    else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
@@ -2162,15 +2163,18 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         return std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
                         ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double));
     };
-    auto launch_wg = [&](int bxw, const uint32_t* skip_if) {
+    auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
         Params Pw = P;
         Pw.bx = bxw;
         const int thr = ((S * bxw + 63) / 64) * 64;
-        hipLaunchKernelGGL((k_solve_wg<NX>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, h->d_fail + 2, skip_if);
+        hipLaunchKernelGGL((k_solve_wg<NX>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
-    int hyb_bx = (kn.hybrid_bx == 2 && S * 2 <= 64) ? 2 : 1;
+    // instances per wavefront of k_solve_wg: two fill the lanes (62 of 64 at N = 30) and halve the wavefronts a full machine needs; a batch
+    // that fits the machine one instance per wavefront (4 wavefront slots per CU) is faster that way -- a round of a wavefront with two live
+    // instances costs 47 us against 33 us (B = 256: 0.58 -> 0.54 ms).  hybrid_bx = 1 / 2 pins it, 0 chooses.
+    int hyb_bx = ((kn.hybrid_bx == 2 || (kn.hybrid_bx == 0 && B > 4 * h->n_cu)) && S * 2 <= 64) ? 2 : 1;
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
     const bool hyb_ok = kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
@@ -2179,8 +2183,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
     if ((use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
-        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, sizeof(uint32_t), stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
+        // (one fill: outside an asynchronous closed loop word 1, its sticky abort word, means nothing)
+        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 6 * sizeof(uint32_t), stream));
+        else HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
         const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
@@ -2189,7 +2194,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             P.DBG = t_rdbg.as<unsigned long long>();
         }
         prof.begin(5, stream);
-        launch_wg(wg_only ? hyb_bx : bx, nullptr);
+        launch_wg(wg_only ? hyb_bx : bx, nullptr, h->d_fail + 2);
         prof.end(stream);
         prof.begin(2, stream);
         hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail);
@@ -2260,7 +2265,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 HIP_TRY(h, hipMalloc(&h->d_pipe, words * sizeof(uint32_t)));
                 h->pipe_words = words;
             }
-            if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 16 * sizeof(uint32_t)));
+            if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 24 * sizeof(uint32_t)));
             A.ctl = h->d_pipe;
             HIP_TRY(h, hipMemsetAsync(h->d_pipe, 0, words * sizeof(uint32_t), stream));
             unsigned long long* d_pdbg = nullptr;
@@ -2273,10 +2278,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.begin(3, stream);
             hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
-            if (hand > 0) {
-                HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
+            if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
                 prof.begin(5, stream);
-                launch_wg(hyb_bx, (const uint32_t*)(h->d_pipe + PIPE_ABORT));
+                launch_wg(hyb_bx, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_pipe + PIPE_WG);
                 prof.end(stream);
             }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
@@ -2296,10 +2300,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 h->last_mode = 1;
                 return MPC_OK;
             }
-            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            if (hand > 0) HIP_TRY(h, hipMemcpyAsync(h->h_fail + 2, h->d_fail + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
+            for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
             if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
                 h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = (B + hyb_bx - 1) / hyb_bx;
                 h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
