@@ -75,27 +75,28 @@ def committed_traffic(kernel):
         return None
 
 
-def measure_traffic(kernel_tags, timeout=240):
+def measure_traffic(kernel_tags, timeout=240, child="mpc", fallback="k_pipeline"):
     """HBM bytes per solve of the kernels of the iteration loop (mean per launch, summed over the kernels), measured NOW: two rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,
     kernel trace only -- counters get their own runs, MI355X_MICROARCH.md) over `bench.py --pmc-child`, which performs three
-    converged-mode solves of the headline batch and nothing else.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: on gfx950
+    converged-mode solves of the headline batch and nothing else (`--pmc-child forces`: three FORCES-mode SQP steps of the
+    `other_paths` batch).  bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: on gfx950
     FETCH_SIZE counts 64 B per 128-byte request (the guide's correction; re-checked with tools/ubench/ldpat.hip).
     Returns (bytes per launch | None, source text)."""
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return committed_traffic("k_pipeline"), "rocprofv3 not found; committed profiles/pmc_traffic.json"
+        return committed_traffic(fallback), "rocprofv3 not found; committed profiles/pmc_traffic.json"
     out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(out, ctr)
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--pmc-child"]
+               os.path.join(ROOT, "bench.py"), "--pmc-child", child]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         except (subprocess.SubprocessError, OSError) as e:
             shutil.rmtree(out, ignore_errors=True)
-            return committed_traffic("k_pipeline"), "rocprofv3 pass failed (%s); committed profiles/pmc_traffic.json" % type(e).__name__
+            return committed_traffic(fallback), "rocprofv3 pass failed (%s); committed profiles/pmc_traffic.json" % type(e).__name__
         per_kernel = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
@@ -105,7 +106,7 @@ def measure_traffic(kernel_tags, timeout=240):
                             per_kernel.setdefault(tag, []).append(float(row["Counter_Value"]))
         if kernel_tags[0] not in per_kernel:
             shutil.rmtree(out, ignore_errors=True)
-            return committed_traffic("k_pipeline"), "no %s rows for %s; committed profiles/pmc_traffic.json" % (ctr, kernel_tags[0])
+            return committed_traffic(fallback), "no %s rows for %s; committed profiles/pmc_traffic.json" % (ctr, kernel_tags[0])
         # (every dispatch is one row per XCD-summed counter; per solve: one launch of each kernel)
         vals[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
     shutil.rmtree(out, ignore_errors=True)
@@ -184,11 +185,45 @@ def spawn_ranks(args):
     os.execv(sys.executable, cmd)
 
 
-def pmc_child():
+def forces_setup(B, local_rank=0):
+    """the FORCES-mode SQP step of `other_paths` (row f3): solver, a closure that runs one batch on device-resident buffers, the flag /
+    iteration rows it fills, and the bound vectors of the lane-following formulation"""
+    import torch
+    import mpc_amd
+    sf = mpc_amd.BatchedMPCSolver(10, 5, Q=(2.0, 2.0, 50.0, 0.1, 5.0), R=(2.0, 0.2), P=(4.0, 4.0, 100.0, 0.2, 10.0), device=local_rank)
+    zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 19.0, 0.03495])
+    zb = np.tile(zi, (B, 10, 1))
+    kk = np.arange(1, 11)
+    par = np.tile(np.hstack([np.stack([zi[2] + kk * 2 * np.cos(0.03495), zi[3] + kk * 2 * np.sin(0.03495)], 1), np.full((10, 1), 20.0),
+                             np.full((10, 1), 0.03495), np.tile([-100.0, 0, -100, 0, -100, 0], (10, 1))]), (B, 1, 1))
+    lbf = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])
+    ubf = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
+    hlf, huf = np.concatenate(([0.0], np.full(9, 1.44))), np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
+    dev = torch.device("cuda", local_rank)
+    d_z, d_xi, d_par = torch.from_numpy(zb).to(dev), torch.from_numpy(np.ascontiguousarray(zb[:, 0, 2:])).to(dev), torch.from_numpy(par).to(dev)
+    d_o = torch.empty_like(d_z)
+    d_fl = torch.empty(B, dtype=torch.int32, device=dev)
+    d_it = torch.empty(B, dtype=torch.int32, device=dev)
+    d_rs = torch.empty(B, dtype=torch.float64, device=dev)
+
+    def fstep():
+        sf.forces_solve_device(B, d_z.data_ptr(), d_xi.data_ptr(), d_par.data_ptr(), lbf, ubf, hlf, huf, d_o.data_ptr(), d_fl.data_ptr(),
+                               d_it.data_ptr(), d_rs.data_ptr())
+    fstep.keep = (d_z, d_xi, d_par, d_o, d_rs)
+    return sf, fstep, d_fl, d_it, lbf, ubf, hlf, huf
+
+
+def pmc_child(kind="mpc"):
     """the command the PMC passes profile: three converged-mode solves of the headline batch, nothing else"""
     import torch
     import mpc_amd  # noqa: F401
     import workloads as wl
+    if kind == "forces":
+        _, fstep, *_ = forces_setup(BATCH)
+        for _ in range(3):
+            fstep()
+        torch.cuda.synchronize()
+        return
     fam = wl.FAMILIES["zamlf_n30_nx6"]
     x0, p = wl.batch(fam, BATCH)
     dev = torch.device("cuda", 0)
@@ -209,10 +244,10 @@ def main():
     ap.add_argument("--workload", choices=("headline", "mixed"), default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic falls back to the committed figure)")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", nargs="?", const="mpc", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
-        return pmc_child()
+        return pmc_child(args.pmc_child)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -407,7 +442,7 @@ def main():
     # ---- the paths around the solve, single-GPU run only, a few hundred milliseconds in total
     other_paths = None
     if rank == 0 and world == 1:
-        other_paths = side_paths(torch, mpc_amd, fam, B, local_rank)
+        other_paths = side_paths(torch, mpc_amd, fam, B, local_rank, traffic=not args.no_traffic)
 
     if rank == 0:
         out = dict(metric="MPC steps/sec (N=30, nx=6 nu=2) at batch=4096", value=value, unit="MPC steps/s", n_gpus=world,
@@ -487,7 +522,7 @@ def other_configs(torch, wl, local_rank, dev, stream):
     return out
 
 
-def side_paths(torch, mpc_amd, fam, B, local_rank):
+def side_paths(torch, mpc_amd, fam, B, local_rank, traffic=True):
     other_paths = {}
     try:
         s5 = mpc_amd.BatchedMPCSolver(N_HORIZON, 5, Q=fam.Q, R=fam.R, device=local_rank)
@@ -507,25 +542,8 @@ def side_paths(torch, mpc_amd, fam, B, local_rank):
         other_paths["closed_loop"] = dict(ego_steps_per_s=Bc * L / tcl, ms_per_step_of_batch=tcl / L * 1e3, batch=Bc, steps=L, horizon=N_HORIZON,
                                           converged_frac=float((st_ == 1).mean()),
                                           note="mpc_closed_loop_batch, nx=5, host buffers in/out once per call (row f1)")
-        sf = mpc_amd.BatchedMPCSolver(10, 5, Q=(2.0, 2.0, 50.0, 0.1, 5.0), R=(2.0, 0.2), P=(4.0, 4.0, 100.0, 0.2, 10.0), device=local_rank)
-        zi = np.array([0.0, 0.0, 29.9948, -1.1501, 0.0, 19.0, 0.03495])
-        zb = np.tile(zi, (B, 10, 1))
-        kk = np.arange(1, 11)
-        par = np.tile(np.hstack([np.stack([zi[2] + kk * 2 * np.cos(0.03495), zi[3] + kk * 2 * np.sin(0.03495)], 1), np.full((10, 1), 20.0),
-                                 np.full((10, 1), 0.03495), np.tile([-100.0, 0, -100, 0, -100, 0], (10, 1))]), (B, 1, 1))
-        lbf = np.array([-0.4, -11.5, -np.inf, -np.inf, -1.066, 0.0, -np.inf])
-        ubf = np.array([0.4, 11.5, np.inf, np.inf, 1.066, 50.8, np.inf])
-        hlf, huf = np.concatenate(([0.0], np.full(9, 1.44))), np.concatenate(([11.5 ** 2], np.full(9, np.inf)))
+        sf, fstep, d_fl, d_it, lbf, ubf, hlf, huf = forces_setup(B, local_rank)
         dev = torch.device("cuda", local_rank)
-        d_z, d_xi, d_par = torch.from_numpy(zb).to(dev), torch.from_numpy(np.ascontiguousarray(zb[:, 0, 2:])).to(dev), torch.from_numpy(par).to(dev)
-        d_o = torch.empty_like(d_z)
-        d_fl = torch.empty(B, dtype=torch.int32, device=dev)
-        d_it = torch.empty(B, dtype=torch.int32, device=dev)
-        d_rs = torch.empty(B, dtype=torch.float64, device=dev)
-
-        def fstep():
-            sf.forces_solve_device(B, d_z.data_ptr(), d_xi.data_ptr(), d_par.data_ptr(), lbf, ubf, hlf, huf, d_o.data_ptr(), d_fl.data_ptr(),
-                                   d_it.data_ptr(), d_rs.data_ptr())
         fstep()
         torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -541,10 +559,14 @@ def side_paths(torch, mpc_amd, fam, B, local_rank):
         nq = 10 * (28 + 35 + 7 + 5 + 70 + 10)
         ni = 10 * (7 + 5 + 2 * (14 + 10) * 2)
         b_it = 8 * 2 * (nq + ni)
+        f_traffic, f_src = None, "not measured (--no-traffic)"
+        if traffic and B == BATCH:
+            f_traffic, f_src = measure_traffic(["k_forces_qp", "k_forces_stage"], child="forces", fallback="k_forces_qp+k_forces_stage")
         other_paths["forces_sqp_step"] = dict(solves_per_s=B / tf, ms_per_batch=tf * 1e3, batch=B, horizon=10, solved_frac=float((fl_ == 1).mean()),
                                               mean_qp_iterations=float(it_.mean()),
                                               roofline=dict(bound="hbm", achieved=B * float(it_.mean()) * b_it / tf / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                                            frac=B * float(it_.mean()) * b_it / tf / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                                            frac=B * float(it_.mean()) * b_it / tf / 1e9 / HBM_PEAK_GBS, traffic=f_traffic, traffic_source=f_src,
+                                                            algorithmic_bytes_per_launch=B * float(it_.mean()) * b_it,
                                                             algorithmic_bytes_per_instance_iteration=b_it),
                                               note="mpc_forces_solve_batch_dev, device-resident buffers, HIP events (row f3)")
         Lf = 30

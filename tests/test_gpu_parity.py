@@ -676,6 +676,26 @@ def test_hybrid_solve_matches_oracle_and_the_pipeline(B):
     assert np.array_equal(r.iters[sub], ro["iters"]) and np.abs(r.x[sub] - ro["x"]).max() < TOL_ORACLE
 
 
+def test_instances_per_wavefront_follow_the_batch_size():
+    """hybrid_bx = 0 (the default): one instance per wavefront of k_solve_wg while the batch fits the machine that way (B <= 4 x CUs),
+    two beyond; the statistics of the launch behind a pipeline come back with the pipeline's control block"""
+    import torch
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    s = make_solver(cfg)
+    assert s.get_option("hybrid_bx") == 0 and s.get_option("hybrid") == 1
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for B in (256, 4 * n_cu, 4096):
+        x0, p = synthetic_batch(cfg, B, **kw)
+        r = s.solve(x0, p)
+        rp, pp = s.get_resident_profile(), s.get_pipeline_profile()
+        assert (r.status == 1).all() and rp["ran"]
+        bx = 1 if B <= 4 * n_cu else 2
+        assert rp["workgroups"] == (B + bx - 1) // bx
+        # every iteration of every instance is served by exactly one of the two kernels (k_solve_wg counts its own)
+        assert rp["instance_iterations"] <= int(r.iters.sum()) and rp["sweeps"] >= rp["workgroup_rounds"] > 0
+        assert pp["ran"] == (B > 2048) and (not pp["ran"] or rp["instance_iterations"] < int(r.iters.sum()))
+
+
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "usalf_n50_nx5", "ca"])
 def test_wave_per_instance_kernel_options_agree(fam):
     """k_solve_wg alone (hand-over threshold 64) with one or two instances per wavefront, and with a whole 8-instance workgroup
