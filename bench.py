@@ -535,7 +535,7 @@ def side_paths(torch, mpc_amd, fam, B, local_rank, traffic=True):
         init[:, 1] += rng.uniform(-0.5, 0.5, Bc)
         init[:, 3] *= rng.uniform(0.9, 1.1, Bc)
         P_, O_ = np.tile(path, (Bc, 1, 1)), np.full((Bc, L), 0.1)
-        s5.closed_loop(init[:64], P_[:64], O_[:64], np.full(64, 15.0), L)
+        s5.closed_loop(init, P_, O_, np.full(Bc, 15.0), L)        # warm-up at the full size (allocations)
         t0 = time.perf_counter()
         _, _, st_ = s5.closed_loop(init, P_, O_, np.full(Bc, 15.0), L)
         tcl = time.perf_counter() - t0
@@ -575,7 +575,7 @@ def side_paths(torch, mpc_amd, fam, B, local_rank, traffic=True):
         initf = np.tile([29.9948, -1.1501, 0.0, 20.0, 0.03495], (B, 1))
         initf[:, 1] += np.random.default_rng(2).uniform(-0.3, 0.3, B)
         argsf = (np.tile(pathf, (B, 1, 1)), np.full((B, Lf), 0.03495), np.full(B, 20.0), Lf, lbf, ubf, hlf, huf)
-        sf.forces_closed_loop(initf[:64], argsf[0][:64], argsf[1][:64], argsf[2][:64], *argsf[3:])
+        sf.forces_closed_loop(initf, *argsf)                     # warm-up at the full size: the grow-only scratch of the loop is allocated here
         t0 = time.perf_counter()
         _, _, flf = sf.forces_closed_loop(initf, *argsf)
         tfl = time.perf_counter() - t0
