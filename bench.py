@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--workload", choices=("headline", "mixed"), default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic falls back to the committed figure)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed converged-mode steps and their roofline pass (no fixed-20 variant, configurations 2 - 5, side paths): "
+                         "under `rocprofv3 --kernel-trace --stats` the averages of k_pipeline<6> / k_solve_wg<6> are then those of the bench line")
     ap.add_argument("--pmc-child", nargs="?", const="mpc", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -389,9 +392,12 @@ def main():
     # ---- deterministic-work variant (exactly 20 iterations per instance, no early exit).  NOT the headline: an
     # instance that has reached the tolerance keeps iterating (steps accepted as they come), so only mean_iters / 20 of the
     # instance-iterations below are iterations a solve needs; the rest is deterministic filler that shows what the pipeline moves.
-    fsolver = wl.make_solver(fam, device=local_rank, fixed_iters=20)
-    dtf, _ = timed(lambda: step(fsolver), args.steps, args.warmup)
-    fixed20 = dict(value=world * B * args.steps / dtf, ms_per_step=dtf / args.steps * 1e3,
+    fixed20 = None
+    fsolver = None if args.headline_only else wl.make_solver(fam, device=local_rank, fixed_iters=20)
+    if fsolver is not None:
+        dtf, _ = timed(lambda: step(fsolver), args.steps, args.warmup)
+    if fsolver is not None:
+        fixed20 = dict(value=world * B * args.steps / dtf, ms_per_step=dtf / args.steps * 1e3,
                    hbm_frac_all_iterations=B * args.steps / dtf * (ab["b_io"] + 20 * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS,
                    useful_iteration_share=mean_it / 20.0,
                    hbm_frac_useful_iterations=B * args.steps / dtf * (ab["b_io"] + mean_it * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS,
@@ -436,12 +442,12 @@ def main():
 
     # ---- BASELINE.json configurations 2 - 5 under the same clock (single-GPU run only; a few batches each, ~1 s in total)
     configs = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         configs = other_configs(torch, wl, local_rank, dev, stream)
 
     # ---- the paths around the solve, single-GPU run only, a few hundred milliseconds in total
     other_paths = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         other_paths = side_paths(torch, mpc_amd, fam, B, local_rank, traffic=not args.no_traffic)
 
     if rank == 0:
