@@ -11,7 +11,8 @@ nu = 2 kinematic-bicycle lane-following NLP (BASELINE.json `metric`), synthetic 
 SURVEY.md section 8(d) prescribes (tools/workloads.py), inputs and outputs resident in HBM (mpc_solve_batch_dev).
 Every instance is solved to the reference's IPOPT tolerance (tol 1e-8, max_iter 100): `value` counts converged NLP
 solves per second, whole job.  With N > 1 each rank solves its own B instances on its own GPU (weak scaling, instances
-are independent: no data-path collective) and the result rows are all-gathered over RCCL once per step.
+are independent: no data-path collective) and the result rows of every step are all-gathered over RCCL, on RCCL's own
+stream while the next batch is being solved (the last gathers are waited for inside the timed region).
 
 `--gpus N` without a torch.distributed launcher (WORLD_SIZE unset) starts the N ranks itself and FAILS when fewer than N
 devices are visible; it never reports a smaller n_gpus than it was asked for.
@@ -50,6 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 N_HORIZON, NX, NU, BATCH = 30, 6, 2, 4096
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+JSON_OUT = sys.stdout            # main() swaps it for a private copy of file descriptor 1
 PUBLISHED_CASADI = "25.1 steps/s (N=10, 1 instance, unknown CPU, graph rebuilt every step; BASELINE.md section 1: 36-41 ms per step)"
 
 
@@ -256,6 +258,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)                                # does not return
 
+    # stdout belongs to the ONE JSON line: RCCL prints its banner and warnings to file descriptor 1 (NCCL_DEBUG=VERSION is exported on
+    # the GPU boxes) -- from here on descriptor 1 is stderr for everybody, and the line goes out through a copy of the original
+    global JSON_OUT
+    sys.stdout.flush()
+    JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import mpc_amd
@@ -273,8 +282,11 @@ def main():
         raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (MPC_BENCH_FORCE_GATHER=1: a single rank goes through the collective code of the multi-GPU path -- a one-GPU box can exercise it)
+    gather = world > 1 or os.environ.get("MPC_BENCH_FORCE_GATHER") == "1"
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
@@ -283,11 +295,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(step_fn, steps, warmup):
+    def timed(step_fn, steps, warmup, finish=None):
         """contract timing: W untimed steps, then exactly K steps between two barrier + synchronize pairs, max over ranks;
-        the per-step host times (every converged-mode call ends with a stream synchronisation) give the median beside it"""
+        the per-step host times (every converged-mode call ends with a stream synchronisation) give the median beside it.
+        `finish`: waits for what the steps left in flight (the gathers of the last two steps), inside the timed region"""
         for _ in range(warmup):
             step_fn()
+        if finish:
+            finish()
         barrier()
         per = []
         t0 = time.perf_counter()
@@ -295,6 +310,8 @@ def main():
             ts = time.perf_counter()
             step_fn()
             per.append(time.perf_counter() - ts)
+        if finish:
+            finish()
         barrier()
         dt = time.perf_counter() - t0
         return (sharding.max_over_ranks(dt, device=dev) if world > 1 else dt), per
@@ -311,16 +328,34 @@ def main():
     d_st = torch.empty(B, dtype=torch.int32, device=dev)
     d_it = torch.empty(B, dtype=torch.int32, device=dev)
     d_kkt = torch.empty(B, dtype=torch.float64, device=dev)
-    gathered = [torch.empty_like(d_out) for _ in range(world)] if world > 1 else None
+    # The only exchange of the path is the final gather of the result rows (north_star).  It runs on RCCL's own stream while the next
+    # batch is being solved: two output buffers, the gather of step i is waited for before step i + 2 writes its buffer again, and
+    # the last ones inside the timed region (`drain`).  The solver's persistent kernel fills every CU, so the collective's workgroups
+    # find room in the straggler phase of the following solve, where most CUs idle.
+    d_outs = [d_out, torch.empty_like(d_out)] if gather else [d_out]
+    gathered = [torch.empty((world * B, d_out.shape[1]), dtype=d_out.dtype, device=dev) for _ in d_outs] if gather else None
+    works = [None] * len(d_outs)
+    n_step = [0]
 
     def step(solver):
-        solver.solve_device(B, d_x0.data_ptr(), d_p.data_ptr(), d_out.data_ptr(), d_st.data_ptr(), d_it.data_ptr(),
+        j = n_step[0] % len(d_outs)
+        n_step[0] += 1
+        if works[j] is not None:
+            works[j].wait()
+            works[j] = None
+        solver.solve_device(B, d_x0.data_ptr(), d_p.data_ptr(), d_outs[j].data_ptr(), d_st.data_ptr(), d_it.data_ptr(),
                             d_kkt.data_ptr(), stream=stream)
-        if world > 1:                                    # the only exchange of the path: final gather of the rows
-            dist.all_gather(gathered, d_out)
+        if gather:
+            works[j] = dist.all_gather_into_tensor(gathered[j], d_outs[j], async_op=True)     # (one kernel: no list of outputs to copy into)
+
+    def drain():
+        for j in range(len(works)):
+            if works[j] is not None:
+                works[j].wait()
+                works[j] = None
 
     solver = wl.make_solver(fam, device=local_rank)
-    dt, per = timed(lambda: step(solver), args.steps, args.warmup)
+    dt, per = timed(lambda: step(solver), args.steps, args.warmup, finish=drain)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     med = float(np.median(per))
@@ -348,6 +383,7 @@ def main():
         if rp["ran"]:                                    # the stragglers: ONE launch of k_solve_wg behind it
             wg_ms += rp["ms"]; wg_n += 1; wg_it += rp["instance_iterations"]
             wg_stats = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in rp.items()}
+    drain()
     torch.cuda.synchronize(dev)
     prof_ms_per_step = (time.perf_counter() - tp0) / args.steps * 1e3
     solver.set_profiling(False)
@@ -395,7 +431,7 @@ def main():
     fixed20 = None
     fsolver = None if args.headline_only else wl.make_solver(fam, device=local_rank, fixed_iters=20)
     if fsolver is not None:
-        dtf, _ = timed(lambda: step(fsolver), args.steps, args.warmup)
+        dtf, _ = timed(lambda: step(fsolver), args.steps, args.warmup, finish=drain)
     if fsolver is not None:
         fixed20 = dict(value=world * B * args.steps / dtf, ms_per_step=dtf / args.steps * 1e3,
                    hbm_frac_all_iterations=B * args.steps / dtf * (ab["b_io"] + 20 * ab["b_iter"]) / 1e9 / HBM_PEAK_GBS,
@@ -461,8 +497,8 @@ def main():
                    ms_per_step_median=med * 1e3, value_median_batch=world * B / med if world == 1 else None,
                    converged_frac=converged, mean_iters=mean_it, max_iters=max_it, kkt_max=float(kkt.max()),
                    fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, configs=configs, other_paths=other_paths)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=JSON_OUT, flush=True)
+    if gather:
         dist.destroy_process_group()
 
 
@@ -632,7 +668,7 @@ def run_mixed(args, torch, dist, mpc_amd, sharding, wl, world, rank, local_rank,
                                         "solved to tol 1e-8" % (per_gpu, ", ".join(wl.MIXED_ORDER)), rows_total=per_gpu * world,
                                parallelism="contiguous shards x%d, one padded all-gather per step" % world, gpu=torch.cuda.get_device_name(dev)),
                    families=fams)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
