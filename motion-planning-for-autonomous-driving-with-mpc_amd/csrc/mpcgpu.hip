@@ -145,7 +145,8 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
 template <int NX, bool INIT, int MAXT, bool MB = false>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
-                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true) {
+                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
+                                            uint32_t* live_out = nullptr) {
     int or_parity = 0;
     constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
@@ -224,6 +225,11 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     phase_finish<NX, MB>(P, c, r3, n_mult, n_z);
     MPC_STAMP(10);
     // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
+    // (k_solve_wg: the same ballot IS the activity mask of its next round -- bit l: instance b0 + l goes on; no status row is re-read)
+    if (live_out != nullptr && t < 64) {
+        const unsigned long long m = __ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0);
+        if (t == 0) *live_out = (uint32_t)m;
+    }
     if (P.run_counter != nullptr && t < 64) {
         const int cnt = __popcll(__ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0));
         if (t == 0 && cnt) atomicAdd(P.run_counter, cnt);
@@ -722,8 +728,9 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
     for (;;) {
-        // ---- which of my instances are iterating (status rows of the workspace; written by phase_finish / the sweeps below)
-        if (t < 64) {
+        // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
+        //      left the mask in sh_mask (an instance the sweeps gave up on is inactive there: phase_load_scalars reads its status)
+        if (rounds == 0u && t < 64) {
             const int bb = (int)b0 + t;
             const bool run = t < bx && bb < P.B && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb) == ST_RUNNING;
             const unsigned long long mk = __ballot(run ? 1 : 0);
@@ -846,7 +853,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(14);
         // ---- the stage work of the round
-        stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u);
+        if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
+        stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
