@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(192) k_riccati(const Params P) {
 // (HW_REG_XCC_ID, not a guess from blockIdx) and serves only the tiles with tile % 8 == that XCD, in the role its
 // arrival order on that XCD gives it.  Producer and consumer of every row therefore share one L2:
 //   producer: plain stores -> s_waitcnt vmcnt(0) (acknowledged by the L2) -> barrier -> agent-scope atomic on the flag
-//   consumer: relaxed agent-scope poll by one lane -> agent-scope acquire (drops this CU's vector L1) -> barrier -> loads
+//   consumer: relaxed agent-scope poll by one lane -> invalidate of this CU's vector L1 (buffer_inv sc0; pipe_acquire) -> barrier -> loads
 // The flags themselves (queue slots, counters, abort word) are agent-scope atomics, valid across XCDs.
 // Every spin is bounded: a wait longer than PIPE_SPIN_LIMIT sets the abort word, every worker leaves, and the host
 // re-runs the solve with one launch per kernel (also if the dispatcher leaves an XCD without stage workers).
@@ -513,7 +513,8 @@ struct PipeArgs {
     uint32_t handover;      // a tile with at most this many instances still iterating leaves the pipeline (0: tiles run to the end)
     uint32_t flags;         // bit 0: producers also issue an agent-scope release (MPCGPU_PIPE_RELEASE: the protocol that does not
                             // rely on a tile staying inside one L2; same results, 10-17 % slower); bit 1: raise the abort word at
-                            // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path)
+                            // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path); bit 3: consumers acquire at agent scope
+                            // (MPCGPU_PIPE_L2INV) instead of dropping their own L1 only -- implied by bit 0
 };
 constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
@@ -525,6 +526,19 @@ constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-
 __host__ __device__ inline uint32_t pipe_slots_off(uint32_t ntiles) { return (PIPE_HDR + ntiles + 1u) & ~1u; }
 __host__ __device__ inline size_t pipe_ctl_words(uint32_t ntiles, uint32_t cap) { return (size_t)pipe_slots_off(ntiles) + (size_t)16 * cap; }
 
+// acquire side of a hand-off inside one XCD: producer and consumer share the L2, so all the consumer has to drop is its own CU's
+// vector L1 (buffer_inv sc0, the workgroup-scope invalidate) -- the agent-scope acquire (buffer_inv sc1) also invalidates the XCD's L2
+// lines of this memory, for every worker of the XCD, at every work item.  `l1_only` = false: the agent-scope fence (option pipe_l2inv).
+__device__ __forceinline__ void pipe_acquire(bool l1_only) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (l1_only) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        asm volatile("buffer_inv sc0" ::: "memory");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+#endif
+}
 __device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pipe_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pipe_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -598,7 +612,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
                         __builtin_amdgcn_s_sleep(8);
                     }
                     waited += wall_clock64() - t0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    pipe_acquire((A.flags & 9u) == 0u);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the invalidate has completed before the barrier lets the other waves load
                     sh_word[1] = ok;
                 }
@@ -657,7 +671,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
             unsigned long long bits = 0ull;
             if (item != PIPE_EXIT) {
                 bits = __hip_atomic_load(P.tile_mask + (item >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                pipe_acquire((A.flags & 9u) == 0u);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             sh_word[1] = item;
@@ -1663,7 +1677,7 @@ struct mpc_handle {
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
-        int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0;
+        int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
         int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
@@ -1689,6 +1703,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pipe_release") k.pipe_release = on != 0;
     else if (n == "pipe_test_abort") k.pipe_test_abort = on != 0;
     else if (n == "pipe_timing") k.pipe_timing = on != 0;
+    else if (n == "pipe_l2inv") k.pipe_l2inv = on != 0;
     else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
@@ -1713,6 +1728,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "pipe_release") *out = k.pipe_release;
     else if (n == "pipe_test_abort") *out = k.pipe_test_abort;
     else if (n == "pipe_timing") *out = k.pipe_timing;
+    else if (n == "pipe_l2inv") *out = k.pipe_l2inv;
     else if (n == "rescue") *out = k.rescue;
     else if (n == "loop_async") *out = k.loop_async;
     else if (n == "sync_spin") *out = k.sync_spin;
@@ -1728,7 +1744,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2264,7 +2280,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.items = 64u / (uint32_t)bx;
             A.cap = 1;
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
-            A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u);
+            A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
             A.handover = (uint32_t)hand;
             const size_t words = pipe_ctl_words(A.ntiles, A.cap);
             if (h->pipe_words < words) {

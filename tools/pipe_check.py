@@ -14,6 +14,7 @@ cfg, kw = FAMILIES[fam]
 x0, p = synthetic_batch(cfg, B, **kw)
 for fixed in (0, 20):
     s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
+    s.set_option("hybrid", "0")        # pipeline against one launch per kernel: the hybrid solve rounds differently
     res = {}
     for mode in ("0", "1"):
         s.set_option("pipeline", mode)

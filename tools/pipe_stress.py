@@ -17,8 +17,10 @@ for fam, B in (("zamlf_n30_nx6", 4096), ("zamlf_n30_nx6", 1000), ("zamlf_n30_nx5
     cfg, kw = FAMILIES[fam]
     x0, p = synthetic_batch(cfg, B, **kw)
     cases.append((fam, make_solver(cfg), x0, p))
+    cases[-1][1].set_option("hybrid", "0")        # pipeline against one launch per kernel: the hybrid solve rounds differently
 x0, p = ca_batch(CA_CFG, 1024)
 s = make_solver(CA_CFG)
+s.set_option("hybrid", "0")
 set_cfg_bounds(s, CA_CFG)
 cases.append(("collision avoidance", s, x0, p))
 bad = 0
