@@ -146,7 +146,7 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 template <int NX, bool INIT, int MAXT, bool MB = false>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
-                                            uint32_t* live_out = nullptr) {
+                                            uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
     int or_parity = 0;
     constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     Ctx<NX> c;
@@ -167,7 +167,10 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
     const int nb = (P.N + 1) * (NX + 2);
     double* lds_x = lds_b + 2 * nb;
-    for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
+    // (a persistent stage worker of the pipeline copies the table -- the same for every item of the batch -- once: nothing else of
+    //  its work items touches that part of the LDS)
+    if (!bounds_in_lds)
+        for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
     c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
     c.bnd_ub = nb;
     if (INIT) lds_barrier();                           // (the iteration kernel passes a barrier before its first use anyway)
@@ -650,6 +653,7 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
     // ================================================================ stage worker: pulls (tile, sub-block) items of its XCD
     unsigned long long busy = 0;
     uint32_t n_items = 0;
+    bool have_bounds = false;
     for (;;) {
         PIPE_STAMP(11);
         if (t == 0) {
@@ -684,7 +688,9 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u);
+        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        // (an item whose instance columns have all finished leaves stage_block before the copy)
+        have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
         lds_barrier();
         PIPE_STAMP(14);
