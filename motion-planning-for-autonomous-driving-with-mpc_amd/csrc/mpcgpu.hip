@@ -447,6 +447,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
             if (k == 15) RIC_STAMP(6);
             lds_barrier();
             if (k == 15) RIC_STAMP(7);
+            if (k == 0) RIC_STAMP(9);
             FwdStage<NX> f;
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
@@ -2349,7 +2350,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (d_pdbg) {       // shader-clock stamps of every worker's LAST work item / tile pass
                 std::vector<unsigned long long> hd((size_t)16 * h->n_cu);
                 HIP_TRY(h, hipMemcpy(hd.data(), d_pdbg, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                double sa[16] = {0}, ra[8] = {0};
+                double sa[16] = {0}, ra[9] = {0};
                 int ns = 0, nr = 0;
                 for (int bq = 0; bq < h->n_cu; ++bq) {
                     const unsigned long long* r = hd.data() + (size_t)bq * 16;
@@ -2362,6 +2363,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                         ra[2] += (double)(long long)(r[2] - r[1]); ra[3] += (double)(long long)(r[13] - r[2]);
                         ra[4] += (double)(long long)(r[4] - r[3]); ra[5] += (double)(long long)(r[5] - r[4]);
                         ra[6] += (double)(long long)(r[7] - r[6]); ra[7] += (double)(long long)(r[8] - r[7]);
+                        ra[8] += (double)(long long)(r[9] - r[1]);
                         ++nr;
                     }
                 }
@@ -2369,9 +2371,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                                              "exchange", "P4-eval", "reduce3", "P5", "drain", "signal"};
                 fprintf(stderr, "[mpcgpu pipeline timing, shader-clock ticks, last item of %d stage workers]", ns);
                 for (int q = 0; q < 15; ++q) fprintf(stderr, " %s=%.0f", sn[q], ns ? sa[q] / ns : 0.0);
-                fprintf(stderr, "\n[last pass of %d Riccati workers] wait=%.0f backward=%.0f forward=%.0f publish=%.0f; stage 15 of the backward sweep: barrier=%.0f step=%.0f, of the forward sweep: barrier=%.0f step=%.0f\n",
+                fprintf(stderr, "\n[last pass of %d Riccati workers] wait=%.0f backward=%.0f forward=%.0f publish=%.0f; stage 15 of the backward sweep: barrier=%.0f step=%.0f, of the forward sweep: barrier=%.0f step=%.0f, its first stage starts %.0f ticks after the backward sweep\n",
                         nr, nr ? ra[0] / nr : 0.0, nr ? ra[1] / nr : 0.0, nr ? ra[2] / nr : 0.0, nr ? ra[3] / nr : 0.0, nr ? ra[4] / nr : 0.0, nr ? ra[5] / nr : 0.0,
-                        nr ? ra[6] / nr : 0.0, nr ? ra[7] / nr : 0.0);
+                        nr ? ra[6] / nr : 0.0, nr ? ra[7] / nr : 0.0, nr ? ra[8] / nr : 0.0);
             }
             piped = true;
             h->last_mode = 1;
