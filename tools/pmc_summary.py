@@ -21,7 +21,7 @@ def main(d, json_out=None):
                 short = name.replace("void (anonymous namespace)::", "").split("(")[0]
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k in sorted(acc, key=lambda k: -len(acc[k])):
-        if not ("k_stage" in k or "k_riccati" in k or "k_pipeline" in k):
+        if not any(t in k for t in ("k_stage", "k_riccati", "k_pipeline", "k_solve_wg", "k_forces_qp", "k_forces_stage")):
             continue
         print(f"== {k}")
         for c, v in sorted(acc[k].items()):
