@@ -415,6 +415,51 @@ struct Ctx {
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
 
+// ---- two threads per (instance, stage): the ROLE template parameter of the phases ---------------------------------------
+// ROLE_ALL  one thread does all the work of its (instance, stage) -- k_stage, the start-iterate kernel, the emulation harness
+// ROLE_A    the "model" thread: dynamics, cost, equality multipliers, stationarity residual, condensed stage block -- the K rows of
+//           SURVEY.md section 8(d)'s byte model (and the stage-0 friction row when it is kept as a row: rare, and then one lane's business)
+// ROLE_B    the "inequality" thread: the I rows -- every bound side of the variables and the circle-distance rows with their geometry,
+//           slacks and multipliers: multiplier steps, fraction to the boundary, gap products of the trial points (log barrier),
+//           multiplier updates, what the rows add to the condensed Hessian / gradient / stationarity residual
+// The two threads of a pair sit in DIFFERENT wavefronts (the role is wave-uniform: no divergence), share the per-instance scalars
+// (both take part in every reduction) and meet ONCE per iteration outside the reductions: B -> A, IneqOut, through LDS in front of
+// the barrier of the neighbour-stage exchange.  Both evaluate sin / cos of the heading they need (A for the dynamics, B for the circle
+// centres): a sincos costs less than a round trip through LDS with a barrier.  The arithmetic of every term is the same source line
+// in all three instantiations; what differs between ROLE_ALL and the pair is the order in which partial sums of a stage meet.
+constexpr int ROLE_ALL = 0, ROLE_A = 1, ROLE_B = 2;
+#define MPC_RA (ROLE != ROLE_B)
+#define MPC_RB (ROLE != ROLE_A)
+// Rows of the hand-over: 3 i + {0, 1, 2} = (sum z/gap, barrier-gradient factor, -zl + zu) of variable i; behind them the circle rows'
+// contributions to the (x, y, psi) entries of rx / gx_a / gx_b (3 each) and to the Hessian entries (xx, xy, xpsi, yy, ypsi, psipsi).
+// The phases take the carrier as a template parameter: IneqOut (registers: ROLE_ALL, the emulation harness) or the kernels' LDS column
+// (put / get of one row at a time: neither thread of a pair ever holds the 39 values at once).
+template <int NX>
+struct IneqRows {
+    static constexpr int NZ = NX + 2;
+    static constexpr int SG = 0, GBB = 1, RZ = 2;                       // + 3 i
+    static constexpr int ORX = 3 * NZ, OGXA = 3 * NZ + 3, OGXB = 3 * NZ + 6, OH = 3 * NZ + 9, COUNT = 3 * NZ + 15;
+};
+template <int NX>
+struct IneqOut {
+    double v[IneqRows<NX>::COUNT];
+    MPC_HD void put(int r, double x) { v[r] = x; }
+    MPC_HD double get(int r) const { return v[r]; }
+};
+// what the inequality rows leave for the KKT-error reduction
+struct KktPart { double dual, prim, cmin, cmax, sz, smult, theta, gp; };
+MPC_HD KktPart kkt_part_neutral() { return KktPart{0.0, 0.0, BIG, -BIG, 0.0, 0.0, 0.0, 1.0}; }
+struct Trig { double sps, cps; };
+MPC_HD Trig psi_trig(double psi) {
+    Trig t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(psi, &t.sps, &t.cps);
+#else
+    t.sps = sin(psi); t.cps = cos(psi);
+#endif
+    return t;
+}
+
 // bounds of variable i of stage k; a_0 (k = 0, i = 1) carries the per-instance presolved friction bound
 // (device: from the workgroup's LDS copy of the table, c.bnd = [LB | UB] -- a global load here would sit behind the
 //  kernel's own stores in the shared vmcnt counter and stall until all of them are acknowledged)
@@ -430,13 +475,16 @@ struct Ctx {
 
 // ---- model pieces ----------------------------------------------------------------------------------------
 // kinematic single-track ODE, configuration.py:353-368
-template <int NX>
+// (TG: sin / cos of the heading are handed in)
+template <int NX, bool TG = false>
 MPC_HD void ode_eval(const Params& P, const double* x, const double* u, double* f, double& sps, double& cps, double& td) {
+    if (!TG) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincos(x[4], &sps, &cps);
+        sincos(x[4], &sps, &cps);
 #else
-    sps = sin(x[4]); cps = cos(x[4]);
+        sps = sin(x[4]); cps = cos(x[4]);
 #endif
+    }
     td = tan(x[2]);
     f[0] = x[3] * cps;
     f[1] = x[3] * sps;
@@ -795,13 +843,13 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
 // MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
-template <int NX, bool MB = false>
+template <int NX, bool MB = false, int ROLE = ROLE_ALL>
 MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
-    load_obst(P, c);
+    if (MPC_RB) load_obst(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
     if (MB) ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 0, e)), c.dz); else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
@@ -814,14 +862,14 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         c.zl[i] = 0.0;
         c.zu[i] = 0.0;
         if (i + 1 < NZ) { c.zl[i + 1] = 0.0; c.zu[i + 1] = 0.0; }
-        if (((P.lo_mask >> i) & both) || a0) {
+        if (MPC_RB && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_KX(ZL, NZ, 0, i);
         }
-        if (((P.hi_mask >> i) & both) || a0) {
+        if (MPC_RB && (((P.hi_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_KX(ZU, NZ, 0, i);
         }
     }
-    if (k < N) {
+    if (MPC_RA && k < N) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
         if (MB) ws_load_rows<NX>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 1, 2 + e)), c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
@@ -829,17 +877,25 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
     }
-    ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
+    if (MPC_RA) {
+        ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
-    if (MB) ws_load_rows<D::NPK>(MPC_ROWS(MPC_KM(P.MPK, D::NPK, 0, e)), tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
-    ws_load_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
-    ws_load_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
-    if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo); else { c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0; }
-    if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo); else { c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0; }
+        for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+        if (MB) ws_load_rows<D::NPK>(MPC_ROWS(MPC_KM(P.MPK, D::NPK, 0, e)), tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
+    }
+    c.so[0] = c.so[1] = c.so[2] = 0.0;
+    c.nuo[0] = c.nuo[1] = c.nuo[2] = 0.0;
+    c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0;
+    c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0;
+    if (MPC_RB) {
+        ws_load_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
+        ws_load_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
+        if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
+        if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
+    }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
-    if (k == 0) {                                          // (fric_row is not known yet; the values are only used if it is set)
+    if (MPC_RA && k == 0) {                                // (fric_row is not known yet; the values are only used if it is set)
         c.sf = MPC_S(P.SC, SC_SF);
         c.nuf = MPC_S(P.SC, SC_NUF);
         c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
@@ -852,21 +908,17 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
 }
 
 // arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam
-template <int NX>
+template <int NX, int ROLE = ROLE_ALL>
 MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     if (!c.valid) return;
     // slack steps need the circle distances and their Jacobians at the iterate: recomputed here (the same evaluation
     // phase 4 of the previous launch made, bit for bit) rather than stored and re-read -- the kernel is bandwidth bound
-    const int oi[3] = {0, 1, 4};
-    {
-        double sps, cps, dist[3], J[9];
-#if defined(__HIP_DEVICE_COMPILE__)
-        sincos(c.z[2 + 4], &sps, &cps);
-#else
-        sps = sin(c.z[2 + 4]); cps = cos(c.z[2 + 4]);
-#endif
-        obstacle_eval(P, c.obst, c.z[2], c.z[3], sps, cps, dist, J, nullptr, true);
+    if (MPC_RB) {
+        const int oi[3] = {0, 1, 4};
+        double dist[3], J[9];
+        const Trig tg = psi_trig(c.z[2 + 4]);
+        obstacle_eval(P, c.obst, c.z[2], c.z[3], tg.sps, tg.cps, dist, J, nullptr, true);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             double ds = dist[j] - c.so[j];
@@ -875,18 +927,20 @@ MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
             c.dso[j] = ds;
         }
     }
+    if (MPC_RA) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double s = tmp.pk[D::NS + i];
+        for (int i = 0; i < NX; ++i) {
+            double s = tmp.pk[D::NS + i];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += tmp.pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
-        c.lam[i] = tmp.lam[i];
-        c.dlam[i] = -s - tmp.lam[i];
+            for (int j = 0; j < NX; ++j) s += tmp.pk[(i <= j) ? D::sidx(i, j) : D::sidx(j, i)] * c.dz[2 + j];
+            c.lam[i] = tmp.lam[i];
+            c.dlam[i] = -s - tmp.lam[i];
+        }
+        c.dsf = c.dfric0 - c.sf + c.gfr0[0] * c.dz[1] + c.gfr0[1] * c.dz[2 + 2] + c.gfr0[2] * c.dz[2 + 3];
     }
-    c.dsf = c.dfric0 - c.sf + c.gfr0[0] * c.dz[1] + c.gfr0[1] * c.dz[2 + 2] + c.gfr0[2] * c.dz[2 + 3];
 }
 
-template <int NX>
+template <int NX, int ROLE = ROLE_ALL>
 MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -903,12 +957,14 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         c.igl[i] = c.igu[i] = 0.0;
         if (isu && k == N) continue;
         const double zi = c.z[i], dv = c.dz[i];
-        MPC_BOUNDS(k, i, lb, ub);
         double gradf = 0.0;
-        if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
+        if (MPC_RA && k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
         double gb = 0.0;
-        if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
-        if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
+        if (MPC_RB) {
+            MPC_BOUNDS(k, i, lb, ub);
+            if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
+            if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
+        }
         dphi += (gradf + gb) * dv;
     }
 #pragma unroll
@@ -916,11 +972,11 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         const double s = c.so[j], ds = c.dso[j];
         double gb = 0.0;
         c.iglo[j] = c.iguo[j] = 0.0;
-        if (P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
-        if (P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
-        dphi += m * gb * ds;
+        if (MPC_RB && P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
+        if (MPC_RB && P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
+        if (MPC_RB) dphi += m * gb * ds;
     }
-    if (k == 0 && c.fric_row) {
+    if (MPC_RA && k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf;
         double gb = 0.0, ig;
         if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, sel, ig); gb -= mu * ig; }
@@ -967,7 +1023,7 @@ MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red)
 // =========================================================================================================
 // Phase 2: evaluate constraint violation / barrier objective at the trial point w + alpha dw
 // =========================================================================================================
-template <int NX>
+template <int NX, int ROLE = ROLE_ALL>
 MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -982,39 +1038,46 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         const double v = c.z[i] + al * c.dz[i];
         c.zt[i] = v;
         if (isu && k == N) continue;
-        MPC_BOUNDS(k, i, lb, ub);
-        if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
-        if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
-        if (k < N) {
+        if (MPC_RB) {
+            MPC_BOUNDS(k, i, lb, ub);
+            if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
+            if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
+        }
+        if (MPC_RA && k < N) {
             if (isu) fc += P.R[i] * v * v;
             else { const double e = v - c.rn[i - 2]; fc += P.Q[i - 2] * e * e; }
         }
     }
-    double f[NX], sps, cps, td;
-    ode_eval<NX>(P, c.zt + 2, c.zt, f, sps, cps, td);
-    if (k < N) {
+    const Trig tg = psi_trig(c.zt[2 + 4]);                  // (both threads of a pair: the dynamics and the circle centres need it)
+    if (MPC_RA) {
+        double f[NX], sps = tg.sps, cps = tg.cps, td;
+        ode_eval<NX, true>(P, c.zt + 2, c.zt, f, sps, cps, td);
+        if (k < N) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const double xnt = c.xn[i] + al * c.dxn[i];
-            theta += fabs(xnt - (f[i] * P.dt + c.zt[2 + i]));
+            for (int i = 0; i < NX; ++i) {
+                const double xnt = c.xn[i] + al * c.dxn[i];
+                theta += fabs(xnt - (f[i] * P.dt + c.zt[2 + i]));
+            }
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - c.r0[i]);
         }
     }
-    if (k == 0) {
+    if (MPC_RB) {
+        double dist[3];
+        obstacle_eval(P, c.obst, c.zt[2], c.zt[3], tg.sps, tg.cps, dist, nullptr, nullptr, false);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - c.r0[i]);
-    }
-    double dist[3];
-    obstacle_eval(P, c.obst, c.zt[2], c.zt[3], sps, cps, dist, nullptr, nullptr, false);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double s = c.so[j] + al * c.dso[j];
-        c.sot[j] = s;
-        theta += m * fabs(dist[j] - s);
-        if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
-        if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+        for (int j = 0; j < 3; ++j) {
+            const double s = c.so[j] + al * c.dso[j];
+            c.sot[j] = s;
+            theta += m * fabs(dist[j] - s);
+            if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+            if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+        }
     }
     c.sft = 0.0;
-    if (k == 0 && c.fric_row) {
+    if (MPC_RA && k == 0 && c.fric_row) {
         const double s = c.sf + al * c.dsf;
         c.sft = s;
         const double dfr = friction_eval(P, c.zt[1], c.zt[2 + 2], c.zt[2 + 3], nullptr, nullptr, false);
@@ -1024,7 +1087,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     }
     red.theta = theta;
     red.fcost = fc;
-    red.logsum = log(gp);
+    // (the model thread of a pair holds no gap but those of a kept friction row: its product is exactly 1 otherwise)
+    red.logsum = (ROLE == ROLE_A && !(k == 0 && c.fric_row)) ? 0.0 : log(gp);
     red.bad = bad;
 }
 
@@ -1063,7 +1127,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX, bool MB = false>
+template <int NX, bool MB = false, int ROLE = ROLE_ALL>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1071,60 +1135,67 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     const int N = P.N, k = c.k;
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
-        if (k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
+        if (MPC_RA && k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         if (i < 2 && k == N) continue;
-        MPC_BOUNDS(k, i, lb, ub);
         const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
-        if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
-        if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
+        if (MPC_RB) {
+            MPC_BOUNDS(k, i, lb, ub);
+            if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
+            if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
+        }
+        (void)zi;
         c.z[i] = zn;
     }
     // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
-    ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
+    if (MPC_RA) ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         const bool a0 = (i == 0) && (k == 0);
         const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
-        if (((P.lo_mask >> i) & both) || a0) {
+        if (MPC_RB && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KX(ZL, NZ, 0, i) = c.zl[i];
         }
-        if (((P.hi_mask >> i) & both) || a0) {
+        if (MPC_RB && (((P.hi_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_KX(ZU, NZ, 0, i) = c.zu[i];
         }
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
+    if (MPC_RA) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
-    ws_store_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), c.lam);
+        for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
+        ws_store_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), c.lam);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
         double sg = 0.0, gb = 0.0;
-        if (P.has_ol) {
+        if (MPC_RB && P.has_ol) {
             const double ig = c.iglo[j], ign = 1.0 / (sn - P.ol);
             sg += c.zlo[j] * ig; gb -= mu * ig;
             c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
             c.iglo[j] = ign;
         }
-        if (P.has_ou) {
+        if (MPC_RB && P.has_ou) {
             const double ig = c.iguo[j], ign = 1.0 / (P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
             c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
             c.iguo[j] = ign;
         }
-        c.nuo[j] += al * (gb - c.nuo[j] + sg * ds);
-        c.so[j] = sn;
+        (void)s;
+        if (MPC_RB) { c.nuo[j] += al * (gb - c.nuo[j] + sg * ds); c.so[j] = sn; }
     }
-    if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
-    if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
-    ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
-    ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
-    if (k == 0 && c.fric_row) {
+    if (MPC_RB) {
+        if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
+        if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
+        ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
+        ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
+    }
+    if (MPC_RA && k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = c.sft;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
@@ -1144,7 +1215,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         MPC_S(P.SC, SC_SF) = sn;
         c.sf = sn;
     }
-    if (k == 0) {
+    if (MPC_RA && k == 0) {
         // filter augmentation (h-type iteration) and bookkeeping
         if (!c.ftype) {
             int nf = c.nfilt;
@@ -1177,12 +1248,75 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 //          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
 // =========================================================================================================
 // REUSE: the update phase ran before and left 1/gap of every bound side at the new iterate in c.ig* (no division here)
-template <int NX, bool REUSE = false, bool MB = false>
-MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
+// the inequality rows' share of phase 4 (ROLE_B, or the first part of ROLE_ALL): sigma, barrier-gradient factor and multiplier sum of
+// every variable bound; the circle rows with their geometry (distances, Jacobians, Hessians at the new iterate) and what they add to the
+// stationarity residual, the condensed gradient and the condensed Hessian -> xo; complementarity extremes, multiplier sums, gap product,
+// the rows' primal and dual residuals -> kp.  tg: sin / cos of the heading of this stage at the new iterate
+template <int NX, bool REUSE = false, class OUT = IneqOut<NX>>
+MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& kp, const Trig& tg) {
     using D = Dim<NX>;
+    using IR = IneqRows<NX>;
+    constexpr int NZ = D::NZ;
+    kp = kkt_part_neutral();
+    if (!c.active) return;
+    const int N = P.N, k = c.k, m = P.obst_mult;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        double sg = 0.0, gbb = 0.0, rz = 0.0;
+        if (!(isu && k == N)) {
+            MPC_BOUNDS(k, i, lb, ub);
+            const double zi = c.z[i];
+            if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+            if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        }
+        xo.put(3 * i + IR::SG, sg); xo.put(3 * i + IR::GBB, gbb); xo.put(3 * i + IR::RZ, rz);
+    }
+    double dist[3], J[9], Ho[18];
+    obstacle_eval(P, c.obst, c.z[2], c.z[3], tg.sps, tg.cps, dist, J, Ho, true);
+    double orx[3] = {0.0, 0.0, 0.0}, ogxa[3] = {0.0, 0.0, 0.0}, ogxb[3] = {0.0, 0.0, 0.0}, oH[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = c.so[j], nu = c.nuo[j];
+        double sg = 0.0, gbb = 0.0, rs = -nu;
+        if (P.has_ol) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (P.has_ou) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        kp.dual = fmax(kp.dual, fabs(rs));
+        const double res = dist[j] - s;
+        kp.theta += m * fabs(res);
+        kp.prim = fmax(kp.prim, fabs(res));
+        kp.smult += m * fabs(nu);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double ja = J[3 * j + a];
+            orx[a] += m * nu * ja;
+            ogxa[a] += ja * (m * sg * res);
+            ogxb[a] += ja * (m * gbb);
+#pragma unroll
+            for (int bq = a; bq < 3; ++bq, ++q) oH[q] += m * (nu * Ho[6 * j + q] + sg * ja * J[3 * j + bq]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { xo.put(IR::ORX + a, orx[a]); xo.put(IR::OGXA + a, ogxa[a]); xo.put(IR::OGXB + a, ogxb[a]); }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) xo.put(IR::OH + q, oH[q]);
+}
+
+// xk, kp: what phase_ineq_assemble left (ROLE_ALL: this thread's; ROLE_A: xk of the inequality thread of the pair, kp neutral;
+// ROLE_B: its own -- the thread only turns kp into its share of the reduction).  TG: sin / cos of the heading are handed in (tg)
+template <int NX, bool REUSE = false, bool MB = false, int ROLE = ROLE_ALL, bool TG = false, class IN = IneqOut<NX>>
+MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN& xk, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
+    using D = Dim<NX>;
+    using IR = IneqRows<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
     red = red_neutral3();
     if (!c.active) return;
+    if (ROLE == ROLE_B) {
+        red.dual_inf = kp.dual; red.prim_inf = kp.prim; red.cmin = kp.cmin; red.cmax = kp.cmax; red.sum_mult = kp.smult; red.sum_z = kp.sz;
+        red.theta = kp.theta; red.logsum = log(kp.gp);
+        return;
+    }
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double dt = P.dt, df = c.df;
     const double* x = c.z + 2;
@@ -1190,7 +1324,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     double H[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) H[i] = 0.0;
-    double lamn[NX], lam[NX], f[NX], sps, cps, td, cn[NX];
+    double lamn[NX], lam[NX], f[NX], sps = tg.sps, cps = tg.cps, td, cn[NX];
     // c.xn / c.lamn (stage k+1 at the new iterate) were exchanged through LDS by the kernel
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1198,12 +1332,12 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         lamn[i] = (k < N) ? c.lamn[i] : 0.0;
         if (k >= N) c.xn[i] = 0.0;
     }
-    ode_eval<NX>(P, x, u, f, sps, cps, td);
+    ode_eval<NX, TG>(P, x, u, f, sps, cps, td);
     const double secd2 = 1.0 + td * td, v = x[3], il = 1.0 / P.wheelbase;      // sec^2 = 1 + tan^2 (td from ode_eval)
     // A = I + dt * df/dx : six off-identity entries
     const double a03 = dt * cps, a04 = -dt * v * sps, a13 = dt * sps, a14 = dt * v * cps;
     const double a42 = dt * v * secd2 * il, a43 = dt * td * il;
-    double theta = 0.0, fc = 0.0, ls = 0.0, prim = 0.0, dual = 0.0, cmin = BIG, cmax = -BIG, smult = 0.0, sz = 0.0;
+    double theta = kp.theta, fc = 0.0, ls = 0.0, prim = kp.prim, dual = kp.dual, cmin = kp.cmin, cmax = kp.cmax, smult = kp.smult, sz = kp.sz;
     // rx: stationarity residual of x_k ; start with lambda terms
     double rx[NX], ru[2] = {0.0, 0.0};
 #pragma unroll
@@ -1260,44 +1394,27 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
             prim = fmax(prim, fabs(c0));
         }
     }
-    // variable bounds (multipliers are register resident: c.zl / c.zu)
-    double gp = 1.0;                                           // product of all gaps; sum of logs = log(gp)
+    // variable bounds: what their sides contribute (phase_ineq_assemble)
+    double gp = kp.gp;                                         // product of all gaps; sum of logs = log(gp)
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
         if (isu && k == N) continue;
-        MPC_BOUNDS(k, i, lb, ub);
-        const double zi = c.z[i];
-        double sg = 0.0, gbb = 0.0, rz = 0.0;
-        if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-        if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+        const double sg = xk.get(3 * i + IR::SG), gbb = xk.get(3 * i + IR::GBB), rz = xk.get(3 * i + IR::RZ);
         if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
         else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
     }
-    // obstacle rows
-    double dist[3], J[9], Ho[18];
-    obstacle_eval(P, c.obst, x[0], x[1], sps, cps, dist, J, Ho, true);
-    const int oi[3] = {0, 1, 4};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double s = c.so[j], nu = c.nuo[j];
-        double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_ol) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
-        if (P.has_ou) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, cmin, cmax, sz, gp);
-        dual = fmax(dual, fabs(rs));
-        const double res = dist[j] - s;
-        theta += m * fabs(res);
-        prim = fmax(prim, fabs(res));
-        smult += m * fabs(nu);
+    // circle rows: what they add (phase_ineq_assemble)
+    {
+        const int oi[3] = {0, 1, 4};
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double ja = J[3 * j + a];
-            rx[oi[a]] += m * nu * ja;
-            c.gxa[oi[a]] += ja * (m * sg * res);
-            c.gxb[oi[a]] += ja * (m * gbb);
+            rx[oi[a]] += xk.get(IR::ORX + a);
+            c.gxa[oi[a]] += xk.get(IR::OGXA + a);
+            c.gxb[oi[a]] += xk.get(IR::OGXB + a);
 #pragma unroll
-            for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += m * (nu * Ho[6 * j + q] + sg * ja * J[3 * j + bq]);
+            for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += xk.get(IR::OH + q);
         }
     }
     // friction row (stage 0), unless presolved into the bounds of a_0
@@ -1359,14 +1476,24 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
         }
     }
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
-    ls = log(gp);
+    ls = (ROLE == ROLE_A && !(k == 0 && c.fric_row)) ? 0.0 : log(gp);
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
+}
+
+// (one thread per (instance, stage): both parts back to back, one sincos for the two)
+template <int NX, bool REUSE = false, bool MB = false>
+MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
+    IneqOut<NX> xo;
+    KktPart kp;
+    const Trig tg = psi_trig(c.z[2 + 4]);
+    phase_ineq_assemble<NX, REUSE>(P, c, xo, kp, tg);
+    phase_eval_assemble<NX, REUSE, MB, ROLE_ALL, true, IneqOut<NX>>(P, c, red, xo, kp, tg);
 }
 
 // =========================================================================================================
 // Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
 // =========================================================================================================
-template <int NX, bool MB = false>
+template <int NX, bool MB = false, int ROLE = ROLE_ALL>
 MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
     using D = Dim<NX>;
     if (!c.active) return;
@@ -1399,7 +1526,8 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         double gx[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) gx[i] = c.gxa[i] + mu * c.gxb[i];
-        if (MB) {
+        if (ROLE == ROLE_B) {
+        } else if (MB) {
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
         } else {
@@ -1408,7 +1536,7 @@ MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mul
         }
     }
     c.status = status;
-    if (k == 0) {
+    if (MPC_RA && k == 0) {
         MPC_S(P.SC, SC_MU) = mu;
         MPC_S(P.SC, SC_TAU) = tau;
         MPC_S(P.SC, SC_THETA) = red.theta;

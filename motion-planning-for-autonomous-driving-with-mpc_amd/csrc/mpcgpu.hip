@@ -240,6 +240,121 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
 #undef MPC_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// stage_pair: the same share of an iteration as stage_block<NX, false>, with TWO threads per (instance, stage) -- the model thread
+// (ROLE_A: threads [0, T) of the workgroup) and the barrier thread (ROLE_B: threads [T, 2 T)); T is a multiple of 64, so the role is
+// wave-uniform and each role is its own instruction stream.  Why: a stage thread of stage_block executes ~10 k instructions per
+// iteration at 450+ registers, ONE wavefront per SIMD -- and a SIMD issues at most one instruction per wavefront and 4-cycle turn,
+// whatever its kind (fp64, moves, the 2.7 k scalar instructions of address / exec-mask bookkeeping, LDS, waits).  Half the state per
+// thread fits 256 registers, two wavefronts share a SIMD, and the scalar / LDS / memory instructions of one issue under the fp64
+// instructions of the other (tools/ubench/issue_mix.hip).  The pair meets in the reductions the phases have anyway and hands over
+// once per iteration through LDS, in front of a barrier that is there already: what the inequality rows add to the condensed
+// system, B -> A, before the neighbour exchange (IneqOut of mpc_stage_math.h).
+// LDS (doubles): [reduction scratch (waves x 10 x bx) | bounds table 2 nb | neighbour exchange 2 NX x T | IneqOut (3 NZ + 15) x T]
+// ---------------------------------------------------------------------------------------------------------------
+template <int NX> __host__ __device__ constexpr int pair_rows() { return 2 * NX + 3 * (NX + 2) + 15; }
+template <int NX, bool MB, int ROLE>
+__device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
+                                                double* lds, int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
+    constexpr int NZ = NX + 2;
+    int or_parity = 0;
+    Ctx<NX> c;
+    const int bx = P.bx, t = threadIdx.x, tt = (ROLE == ROLE_B) ? t - T : t;
+    c.k = tt / bx;
+    c.b = (int)b0 + (tt & (bx - 1));
+    c.valid = (c.k <= P.N) && (c.b < P.B);
+    c.active = false;
+    c.status = 0;
+    c.iters = 0;
+#define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    MPC_STAMP(0);
+    {
+        const unsigned long long m = tile_bits >> (b0 & 63u);
+        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
+    }
+    double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
+    const int nb = (P.N + 1) * NZ;
+    double* lds_x = lds_b + 2 * nb;
+    double* lds_k = lds_x + 2 * NX * T;
+    if (!bounds_in_lds)
+        for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
+    c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
+    c.bnd_ub = nb;
+    phase_load_scalars<NX>(P, c);
+    {
+        PreTmp<NX> tmp;
+        phase_preload<NX, MB, ROLE>(P, c, tmp);          // every array load of the item is in flight before the first wait
+        phase_premath<NX, ROLE>(P, c, tmp);
+    }
+    MPC_STAMP(1);
+    if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
+    MPC_STAMP(2);
+    Red1 r1;
+    phase_step_candidates<NX, ROLE>(P, c, r1);
+    MPC_STAMP(3);
+    block_reduce(r1, bx, lds);
+    phase_linesearch_begin<NX>(P, c, r1);
+    MPC_STAMP(4);
+    while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
+        Red2 r2;
+        phase_trial_eval<NX, ROLE>(P, c, r2);
+        block_reduce(r2, bx, lds);
+        phase_linesearch_decide<NX>(P, c, r2);
+    }
+    MPC_STAMP(5);
+    phase_apply_update<NX, MB, ROLE>(P, c);
+    MPC_STAMP(6);
+    // the hand-over of the pair: one LDS column per pair, rows of IneqRows (put by B in front of the barrier, read by A behind it --
+    // one row at a time, so that neither thread holds the 39 values at once)
+    struct LdsCol {
+        double* col; int T;
+        __device__ __forceinline__ void put(int r, double x) { col[r * T] = x; }
+        __device__ __forceinline__ double get(int r) const { return col[r * T]; }
+    } xk{lds_k + tt, T};
+    KktPart kp = kkt_part_neutral();
+    if (ROLE == ROLE_A) {
+        // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { lds_x[i * T + tt] = c.z[2 + i]; lds_x[(NX + i) * T + tt] = c.lam[i]; }
+    } else {
+        phase_ineq_assemble<NX, true, LdsCol>(P, c, xk, kp, psi_trig(c.z[2 + 4]));
+    }
+    lds_barrier();
+    if (ROLE == ROLE_A) {
+        const int tn = tt + bx;
+        if (tn < T) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { c.xn[i] = lds_x[i * T + tn]; c.lamn[i] = lds_x[(NX + i) * T + tn]; }
+        }
+    }
+    MPC_STAMP(7);
+    Red3 r3;
+    phase_eval_assemble<NX, true, MB, ROLE, false, LdsCol>(P, c, r3, xk, kp);
+    MPC_STAMP(8);
+    block_reduce(r3, bx, lds);
+    MPC_STAMP(9);
+    phase_finish<NX, MB, ROLE>(P, c, r3, n_mult, n_z);
+    MPC_STAMP(10);
+    if (ROLE == ROLE_A) {
+        if (live_out != nullptr && t < 64) {
+            const unsigned long long m = __ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0);
+            if (t == 0) *live_out = (uint32_t)m;
+        }
+        if (P.run_counter != nullptr && t < 64) {
+            const int cnt = __popcll(__ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0));
+            if (t == 0 && cnt) atomicAdd(P.run_counter, cnt);
+        }
+    }
+#undef MPC_STAMP
+}
+template <int NX, bool MB>
+__device__ __forceinline__ void stage_pair(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits, double* lds,
+                                           int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
+    // (wave-uniform, and visibly so: a scalar branch, not an exec mask)
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < T) stage_pair_role<NX, MB, ROLE_A>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
+    else stage_pair_role<NX, MB, ROLE_B>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
+}
+
 template <int NX, bool INIT, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -566,8 +681,9 @@ __global__ void k_xcd_census(uint32_t* mask) {
 #endif
 }
 
-template <int NX>
-__global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+// PAIR: the stage workers run two threads per (instance, stage) (stage_pair: 512-thread workgroups, two wavefronts per SIMD)
+template <int NX, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 512 : 256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -689,7 +805,8 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-        stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        if (PAIR) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
+        else stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
@@ -727,8 +844,11 @@ __global__ void __launch_bounds__(256) k_pipeline(const Params P, const PipeArgs
 // dispatcher hands the CU to the next workgroup of the grid.  The rows stay in the tile-major workspace (they are this CU's own
 // and come back from the L2), so the stage phases are bit-for-bit those of the other paths; only the KKT solve rounds differently.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NX>
-__global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
+// PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
+// of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
+// wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
+template <int NX, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 512 : 256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -742,7 +862,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
     struct { int b, k; } c;                      // (the workspace accessors are written in terms of c.b / c.k)
     c.k = t / bx;
     c.b = (int)b0 + (t & (bx - 1));
-    const bool valid = (c.k <= N) && (c.b < P.B);
+    const bool valid = (c.k <= N) && (c.b < P.B);         // (PAIR: false for the barrier threads, t / bx >= T / bx > N)
     // LDS of the sweeps (aliases the stage phases' region): [dump area of the sweeps, 64 doubles per wavefront | one pad record | records]
     const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * nw + RC::SIZE;
     const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * wave;
@@ -875,7 +995,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params P, const int n_mu
         WG_STAMP(14);
         // ---- the stage work of the round
         if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
-        stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
+        if (PAIR) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
+        else stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1685,7 +1806,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1721,6 +1842,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
+    else if (n == "pair") k.pair = value == nullptr ? 1 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
@@ -1746,12 +1868,13 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
+    else if (n == "pair") *out = k.pair;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2086,8 +2209,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
         }
     }
@@ -2189,8 +2314,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     for (int i = 0; i < 8; ++i) { h->pipe_prof[i] = 0; h->res_prof[i] = 0; }
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
+    // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
+    auto wg_pair = [&](int bxw) { return kn.pair != 0 && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
     auto wg_lds = [&](int bxw) {
         const int thr = ((S * bxw + 63) / 64) * 64;
+        if (wg_pair(bxw))
+            return std::max(((size_t)(2 * thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * thr) * sizeof(double),
+                            ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (2 * thr / 64) + Rec<NX>::SIZE) * sizeof(double));
         return std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
                         ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double));
     };
@@ -2198,7 +2328,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Params Pw = P;
         Pw.bx = bxw;
         const int thr = ((S * bxw + 63) / 64) * 64;
-        hipLaunchKernelGGL((k_solve_wg<NX>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
+        if (wg_pair(bxw)) hipLaunchKernelGGL((k_solve_wg<NX, true>), dim3((B + bxw - 1) / bxw), dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
+        else hipLaunchKernelGGL((k_solve_wg<NX, false>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
@@ -2273,6 +2404,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
         int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
         if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
+        // two threads per (instance, stage) in the stage workers (option pair): 512-thread workgroups
+        const size_t lds_pair = ((size_t)(2 * nw) * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * threads) * sizeof(double);
+        const bool pipe_pair = kn.pair != 0 && 2 * threads <= 512 && lds_pair <= lds_max;
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
@@ -2307,7 +2441,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 P.DBG = d_pdbg;
             }
             prof.begin(3, stream);
-            hipLaunchKernelGGL((k_pipeline<NX>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
                 prof.begin(5, stream);
