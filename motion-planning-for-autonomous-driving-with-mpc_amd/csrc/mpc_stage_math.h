@@ -430,6 +430,13 @@ struct Ctx {
 constexpr int ROLE_ALL = 0, ROLE_A = 1, ROLE_B = 2;
 #define MPC_RA (ROLE != ROLE_B)
 #define MPC_RB (ROLE != ROLE_A)
+// Whose are the bound sides of variable i of (u, x)?  The inputs' (i < 2) go with the model thread, the states' with the inequality
+// thread -- the split that balances the pair: four sides each on the reference's bounds, plus the three circle rows on B and the
+// dynamics on A.  VM: compile-time mask of the variables that have a bound at SOME stage (0xFF: not known -- every side is looked up
+// in the bounds table at run time); the kernels of the pair are instantiated for the mask of the reference's bounds, where the sides
+// of x, y, psi (and the progress state) vanish from the code together with their registers.
+template <int ROLE, uint32_t VM>
+MPC_HD constexpr bool side_mine(int i) { return ((VM >> i) & 1u) != 0u && (ROLE == ROLE_ALL || (ROLE == ROLE_A) == (i < 2)); }
 // Rows of the hand-over: 3 i + {0, 1, 2} = (sum z/gap, barrier-gradient factor, -zl + zu) of variable i; behind them the circle rows'
 // contributions to the (x, y, psi) entries of rx / gx_a / gx_b (3 each) and to the Hessian entries (xx, xy, xpsi, yy, ypsi, psipsi).
 // The phases take the carrier as a template parameter: IneqOut (registers: ROLE_ALL, the emulation harness) or the kernels' LDS column
@@ -445,6 +452,7 @@ struct IneqOut {
     double v[IneqRows<NX>::COUNT];
     MPC_HD void put(int r, double x) { v[r] = x; }
     MPC_HD double get(int r) const { return v[r]; }
+    MPC_HD void sync() const {}          // (the LDS carrier of the kernels waits here for the inequality thread's puts)
 };
 // what the inequality rows leave for the KKT-error reduction
 struct KktPart { double dual, prim, cmin, cmax, sz, smult, theta, gp; };
@@ -494,33 +502,35 @@ MPC_HD void ode_eval(const Params& P, const double* x, const double* u, double* 
     if (NX == 6) f[5] = x[3];
 }
 
-// circle distances of the pairs (0,0),(1,1),(2,2) (optimizer.py:395-403), optionally Jacobian wrt (sx,sy,psi)
-// and the 6 distinct Hessian entries per pair: order (00,01,02,11,12,22)
+// circle distance of pair (j, j) (optimizer.py:395-403; j = 0 centre, 1 front, 2 rear circle of the ego vehicle), optionally its
+// Jacobian wrt (sx, sy, psi) -> J3 and the 6 distinct Hessian entries (00,01,02,11,12,22) -> H6
+MPC_HD double circle_eval(const Params& P, const double* obst, int j, double sx, double sy, double sps, double cps, double* J3, double* H6, bool derivs) {
+    const double rho = P.ego_offset;
+    const double sg = (j == 0) ? 0.0 : (j == 1 ? 1.0 : -1.0);
+    const double cx = sx + sg * rho * cps - obst[2 * j];
+    const double cy = sy + sg * rho * sps - obst[2 * j + 1];
+    const double r = sqrt(cx * cx + cy * cy);
+    if (!derivs) return r;
+    const double ir = 1.0 / r;
+    const double ex = cx * ir, ey = cy * ir;
+    const double tx = -sg * rho * sps, ty = sg * rho * cps;
+    J3[0] = ex;
+    J3[1] = ey;
+    J3[2] = ex * tx + ey * ty;
+    if (H6 == nullptr) return r;
+    const double m00 = (1 - ex * ex) * ir, m01 = -ex * ey * ir, m11 = (1 - ey * ey) * ir;
+    const double mt0 = m00 * tx + m01 * ty, mt1 = m01 * tx + m11 * ty;
+    const double nxx = -sg * rho * cps, nyy = -sg * rho * sps;
+    H6[0] = m00; H6[1] = m01; H6[2] = mt0;
+    H6[3] = m11; H6[4] = mt1;
+    H6[5] = tx * mt0 + ty * mt1 + ex * nxx + ey * nyy;
+    return r;
+}
+// all three pairs at once
 MPC_HD void obstacle_eval(const Params& P, const double* obst, double sx, double sy, double sps, double cps,
                           double dist[3], double J[9], double H[18], bool derivs) {
-    const double rho = P.ego_offset;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double sg = (j == 0) ? 0.0 : (j == 1 ? 1.0 : -1.0);
-        const double cx = sx + sg * rho * cps - obst[2 * j];
-        const double cy = sy + sg * rho * sps - obst[2 * j + 1];
-        const double r = sqrt(cx * cx + cy * cy);
-        dist[j] = r;
-        if (!derivs) continue;
-        const double ir = 1.0 / r;
-        const double ex = cx * ir, ey = cy * ir;
-        const double tx = -sg * rho * sps, ty = sg * rho * cps;
-        J[3 * j + 0] = ex;
-        J[3 * j + 1] = ey;
-        J[3 * j + 2] = ex * tx + ey * ty;
-        if (H == nullptr) continue;
-        const double m00 = (1 - ex * ex) * ir, m01 = -ex * ey * ir, m11 = (1 - ey * ey) * ir;
-        const double mt0 = m00 * tx + m01 * ty, mt1 = m01 * tx + m11 * ty;
-        const double nxx = -sg * rho * cps, nyy = -sg * rho * sps;
-        H[6 * j + 0] = m00; H[6 * j + 1] = m01; H[6 * j + 2] = mt0;
-        H[6 * j + 3] = m11; H[6 * j + 4] = mt1;
-        H[6 * j + 5] = tx * mt0 + ty * mt1 + ex * nxx + ey * nyy;
-    }
+    for (int j = 0; j < 3; ++j) dist[j] = circle_eval(P, obst, j, sx, sy, sps, cps, J ? J + 3 * j : nullptr, H ? H + 6 * j : nullptr, derivs);
 }
 
 // friction row optimizer.py:378: sqrt((a^2 + v*(tan(delta)*v/2.578))^2) = |y|; d|y| = sign(y) dy, sign(0) = 0.
@@ -843,7 +853,7 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
 // MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
-template <int NX, bool MB = false, int ROLE = ROLE_ALL>
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
 MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -862,10 +872,11 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         c.zl[i] = 0.0;
         c.zu[i] = 0.0;
         if (i + 1 < NZ) { c.zl[i + 1] = 0.0; c.zu[i + 1] = 0.0; }
-        if (MPC_RB && (((P.lo_mask >> i) & both) || a0)) {
+        const bool mine = side_mine<ROLE, VM>(i) || (i + 1 < NZ && side_mine<ROLE, VM>(i + 1));      // (compile time: whose pair of rows)
+        if (mine && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_KX(ZL, NZ, 0, i);
         }
-        if (MPC_RB && (((P.hi_mask >> i) & both) || a0)) {
+        if (mine && (((P.hi_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_KX(ZU, NZ, 0, i);
         }
     }
@@ -916,14 +927,14 @@ MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     // phase 4 of the previous launch made, bit for bit) rather than stored and re-read -- the kernel is bandwidth bound
     if (MPC_RB) {
         const int oi[3] = {0, 1, 4};
-        double dist[3], J[9];
         const Trig tg = psi_trig(c.z[2 + 4]);
-        obstacle_eval(P, c.obst, c.z[2], c.z[3], tg.sps, tg.cps, dist, J, nullptr, true);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            double ds = dist[j] - c.so[j];
+            double J[3];
+            const double dist = circle_eval(P, c.obst, j, c.z[2], c.z[3], tg.sps, tg.cps, J, nullptr, true);
+            double ds = dist - c.so[j];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) ds += J[3 * j + a] * c.dz[2 + oi[a]];
+            for (int a = 0; a < 3; ++a) ds += J[a] * c.dz[2 + oi[a]];
             c.dso[j] = ds;
         }
     }
@@ -940,7 +951,7 @@ MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     }
 }
 
-template <int NX, int ROLE = ROLE_ALL>
+template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
 MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -960,7 +971,7 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         double gradf = 0.0;
         if (MPC_RA && k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
         double gb = 0.0;
-        if (MPC_RB) {
+        if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
             if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
@@ -1023,7 +1034,7 @@ MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red)
 // =========================================================================================================
 // Phase 2: evaluate constraint violation / barrier objective at the trial point w + alpha dw
 // =========================================================================================================
-template <int NX, int ROLE = ROLE_ALL>
+template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
 MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1032,13 +1043,14 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double al = c.alpha;
     double theta = 0.0, fc = 0.0, gp = 1.0, bad = 0.0;      // gp: product of all gaps; sum of logs = log(gp), one log per thread
+    double zt[NZ];                                          // the trial point (the update phase forms the accepted one again)
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
         const double v = c.z[i] + al * c.dz[i];
-        c.zt[i] = v;
+        zt[i] = v;
         if (isu && k == N) continue;
-        if (MPC_RB) {
+        if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
             if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
@@ -1048,47 +1060,42 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
             else { const double e = v - c.rn[i - 2]; fc += P.Q[i - 2] * e * e; }
         }
     }
-    const Trig tg = psi_trig(c.zt[2 + 4]);                  // (both threads of a pair: the dynamics and the circle centres need it)
+    const Trig tg = psi_trig(zt[2 + 4]);                    // (both threads of a pair: the dynamics and the circle centres need it)
     if (MPC_RA) {
         double f[NX], sps = tg.sps, cps = tg.cps, td;
-        ode_eval<NX, true>(P, c.zt + 2, c.zt, f, sps, cps, td);
+        ode_eval<NX, true>(P, zt + 2, zt, f, sps, cps, td);
         if (k < N) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double xnt = c.xn[i] + al * c.dxn[i];
-                theta += fabs(xnt - (f[i] * P.dt + c.zt[2 + i]));
+                theta += fabs(xnt - (f[i] * P.dt + zt[2 + i]));
             }
         }
         if (k == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) theta += fabs(c.zt[2 + i] - c.r0[i]);
+            for (int i = 0; i < NX; ++i) theta += fabs(zt[2 + i] - c.r0[i]);
         }
     }
     if (MPC_RB) {
-        double dist[3];
-        obstacle_eval(P, c.obst, c.zt[2], c.zt[3], tg.sps, tg.cps, dist, nullptr, nullptr, false);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+            const double dist = circle_eval(P, c.obst, j, zt[2], zt[3], tg.sps, tg.cps, nullptr, nullptr, false);
             const double s = c.so[j] + al * c.dso[j];
-            c.sot[j] = s;
-            theta += m * fabs(dist[j] - s);
+            theta += m * fabs(dist - s);
             if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
             if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
         }
     }
-    c.sft = 0.0;
     if (MPC_RA && k == 0 && c.fric_row) {
         const double s = c.sf + al * c.dsf;
-        c.sft = s;
-        const double dfr = friction_eval(P, c.zt[1], c.zt[2 + 2], c.zt[2 + 3], nullptr, nullptr, false);
+        const double dfr = friction_eval(P, zt[1], zt[2 + 2], zt[2 + 3], nullptr, nullptr, false);
         theta += fabs(dfr - s);
         if (P.has_fl) { const double gap = s - P.fl; if (gap <= 0) bad = 1.0; else gp *= gap; }
         if (P.has_fu) { const double gap = P.fu - s; if (gap <= 0) bad = 1.0; else gp *= gap; }
     }
     red.theta = theta;
     red.fcost = fc;
-    // (the model thread of a pair holds no gap but those of a kept friction row: its product is exactly 1 otherwise)
-    red.logsum = (ROLE == ROLE_A && !(k == 0 && c.fric_row)) ? 0.0 : log(gp);
+    red.logsum = log(gp);
     red.bad = bad;
 }
 
@@ -1127,7 +1134,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX, bool MB = false, int ROLE = ROLE_ALL>
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
 MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1142,8 +1149,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         if (i < 2 && k == N) continue;
-        const double zi = c.z[i], dv = c.dz[i], zn = c.zt[i];
-        if (MPC_RB) {
+        const double zi = c.z[i], dv = c.dz[i], zn = zi + al * dv;       // (the accepted trial point, formed again)
+        if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
             if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
@@ -1157,10 +1164,11 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     for (int i = 0; i < NZ; i += 2) {
         const bool a0 = (i == 0) && (k == 0);
         const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
-        if (MPC_RB && (((P.lo_mask >> i) & both) || a0)) {
+        const bool mine = side_mine<ROLE, VM>(i) || (i + 1 < NZ && side_mine<ROLE, VM>(i + 1));
+        if (mine && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KX(ZL, NZ, 0, i) = c.zl[i];
         }
-        if (MPC_RB && (((P.hi_mask >> i) & both) || a0)) {
+        if (mine && (((P.hi_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_KX(ZU, NZ, 0, i) = c.zu[i];
         }
     }
@@ -1172,7 +1180,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double s = c.so[j], ds = c.dso[j], sn = c.sot[j];
+        const double s = c.so[j], ds = c.dso[j], sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
         if (MPC_RB && P.has_ol) {
             const double ig = c.iglo[j], ign = 1.0 / (sn - P.ol);
@@ -1196,7 +1204,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
     }
     if (MPC_RA && k == 0 && c.fric_row) {
-        const double s = c.sf, ds = c.dsf, sn = c.sft;
+        const double s = c.sf, ds = c.dsf, sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
             const double ig = 1.0 / (s - P.fl);
@@ -1252,7 +1260,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 // every variable bound; the circle rows with their geometry (distances, Jacobians, Hessians at the new iterate) and what they add to the
 // stationarity residual, the condensed gradient and the condensed Hessian -> xo; complementarity extremes, multiplier sums, gap product,
 // the rows' primal and dual residuals -> kp.  tg: sin / cos of the heading of this stage at the new iterate
-template <int NX, bool REUSE = false, class OUT = IneqOut<NX>>
+template <int NX, bool REUSE = false, class OUT = IneqOut<NX>, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
 MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& kp, const Trig& tg) {
     using D = Dim<NX>;
     using IR = IneqRows<NX>;
@@ -1262,6 +1270,7 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
     const int N = P.N, k = c.k, m = P.obst_mult;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
+        if (!side_mine<ROLE, VM>(i)) continue;            // (rows of the other thread's / of absent sides are never read either)
         const bool isu = i < 2;
         double sg = 0.0, gbb = 0.0, rz = 0.0;
         if (!(isu && k == N)) {
@@ -1272,29 +1281,29 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
         }
         xo.put(3 * i + IR::SG, sg); xo.put(3 * i + IR::GBB, gbb); xo.put(3 * i + IR::RZ, rz);
     }
-    double dist[3], J[9], Ho[18];
-    obstacle_eval(P, c.obst, c.z[2], c.z[3], tg.sps, tg.cps, dist, J, Ho, true);
     double orx[3] = {0.0, 0.0, 0.0}, ogxa[3] = {0.0, 0.0, 0.0}, ogxb[3] = {0.0, 0.0, 0.0}, oH[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+        double J[3], Ho[6];
+        const double dist = circle_eval(P, c.obst, j, c.z[2], c.z[3], tg.sps, tg.cps, J, Ho, true);
         const double s = c.so[j], nu = c.nuo[j];
         double sg = 0.0, gbb = 0.0, rs = -nu;
         if (P.has_ol) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
         if (P.has_ou) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
         kp.dual = fmax(kp.dual, fabs(rs));
-        const double res = dist[j] - s;
+        const double res = dist - s;
         kp.theta += m * fabs(res);
         kp.prim = fmax(kp.prim, fabs(res));
         kp.smult += m * fabs(nu);
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double ja = J[3 * j + a];
+            const double ja = J[a];
             orx[a] += m * nu * ja;
             ogxa[a] += ja * (m * sg * res);
             ogxb[a] += ja * (m * gbb);
 #pragma unroll
-            for (int bq = a; bq < 3; ++bq, ++q) oH[q] += m * (nu * Ho[6 * j + q] + sg * ja * J[3 * j + bq]);
+            for (int bq = a; bq < 3; ++bq, ++q) oH[q] += m * (nu * Ho[q] + sg * ja * J[bq]);
         }
     }
 #pragma unroll
@@ -1303,28 +1312,32 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
     for (int q = 0; q < 6; ++q) xo.put(IR::OH + q, oH[q]);
 }
 
-// xk, kp: what phase_ineq_assemble left (ROLE_ALL: this thread's; ROLE_A: xk of the inequality thread of the pair, kp neutral;
-// ROLE_B: its own -- the thread only turns kp into its share of the reduction).  TG: sin / cos of the heading are handed in (tg)
-template <int NX, bool REUSE = false, bool MB = false, int ROLE = ROLE_ALL, bool TG = false, class IN = IneqOut<NX>>
-MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN& xk, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
+// Phase 4 comes in two halves, so that the two threads of a pair work side by side for as long as the arithmetic allows:
+//   phase_eval_model   derivatives of the dynamics and the cost at the new iterate, stationarity residual, condensed Hessian -- everything
+//                      that does not need the inequality rows (ROLE_A also: the bound sides of the inputs, its own) -> EvalTmp
+//   phase_eval_finish  adds what the inequality rows contribute (xk: phase_ineq_assemble of this thread for ROLE_ALL, of the other
+//                      thread of the pair -- through LDS, behind a barrier the kernel passes between the halves -- for ROLE_A), then the
+//                      residual norms and the stage-block stores
+// kp: ROLE_ALL the partial results of phase_ineq_assemble, ROLE_A neutral.  TG: sin / cos of the heading are handed in (tg).
+template <int NX>
+struct EvalTmp {
+    double H[Dim<NX>::NS], rx[NX], ru[2], ruu[2], cn[NX], a[6];
+    double theta, fc, prim, dual, cmin, cmax, smult, sz, gp;
+};
+template <int NX, bool REUSE = false, int ROLE = ROLE_ALL, bool TG = false, uint32_t VM = 0xFFu>
+MPC_HD void phase_eval_model(const Params& P, Ctx<NX>& c, EvalTmp<NX>& t, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
     using D = Dim<NX>;
-    using IR = IneqRows<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
-    red = red_neutral3();
     if (!c.active) return;
-    if (ROLE == ROLE_B) {
-        red.dual_inf = kp.dual; red.prim_inf = kp.prim; red.cmin = kp.cmin; red.cmax = kp.cmax; red.sum_mult = kp.smult; red.sum_z = kp.sz;
-        red.theta = kp.theta; red.logsum = log(kp.gp);
-        return;
-    }
     const int N = P.N, k = c.k, m = P.obst_mult;
     const double dt = P.dt, df = c.df;
     const double* x = c.z + 2;
     const double* u = c.z;
-    double H[NS];
+    double* H = t.H;
 #pragma unroll
     for (int i = 0; i < NS; ++i) H[i] = 0.0;
-    double lamn[NX], lam[NX], f[NX], sps = tg.sps, cps = tg.cps, td, cn[NX];
+    double lamn[NX], lam[NX], f[NX], sps = tg.sps, cps = tg.cps, td;
+    double* cn = t.cn;
     // c.xn / c.lamn (stage k+1 at the new iterate) were exchanged through LDS by the kernel
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1339,7 +1352,9 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
     const double a42 = dt * v * secd2 * il, a43 = dt * td * il;
     double theta = kp.theta, fc = 0.0, ls = 0.0, prim = kp.prim, dual = kp.dual, cmin = kp.cmin, cmax = kp.cmax, smult = kp.smult, sz = kp.sz;
     // rx: stationarity residual of x_k ; start with lambda terms
-    double rx[NX], ru[2] = {0.0, 0.0};
+    double* rx = t.rx;
+    double* ru = t.ru;
+    ru[0] = ru[1] = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         rx[i] = lam[i];
@@ -1348,7 +1363,8 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
         c.gxb[i] = 0.0;
     }
     c.gua[0] = c.gua[1] = c.gub[0] = c.gub[1] = 0.0;
-    double ruu[2] = {0.0, 0.0};
+    double* ruu = t.ruu;
+    ruu[0] = ruu[1] = 0.0;
     if (k < N) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1394,27 +1410,18 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
             prim = fmax(prim, fabs(c0));
         }
     }
-    // variable bounds: what their sides contribute (phase_ineq_assemble)
     double gp = kp.gp;                                         // product of all gaps; sum of logs = log(gp)
+    // (ROLE_A: the bound sides of the inputs are this thread's own)
+    if (ROLE == ROLE_A) {
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        const bool isu = i < 2;
-        if (isu && k == N) continue;
-        const double sg = xk.get(3 * i + IR::SG), gbb = xk.get(3 * i + IR::GBB), rz = xk.get(3 * i + IR::RZ);
-        if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
-        else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
-    }
-    // circle rows: what they add (phase_ineq_assemble)
-    {
-        const int oi[3] = {0, 1, 4};
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            rx[oi[a]] += xk.get(IR::ORX + a);
-            c.gxa[oi[a]] += xk.get(IR::OGXA + a);
-            c.gxb[oi[a]] += xk.get(IR::OGXB + a);
-#pragma unroll
-            for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += xk.get(IR::OH + q);
+        for (int i = 0; i < 2; ++i) {
+            if (!side_mine<ROLE, VM>(i) || k == N) continue;
+            MPC_BOUNDS(k, i, lb, ub);
+            const double zi = c.z[i];
+            double sg = 0.0, gbb = 0.0, rz = 0.0;
+            if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz;
         }
     }
     // friction row (stage 0), unless presolved into the bounds of a_0
@@ -1447,6 +1454,46 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
         MPC_S(P.SC, SC_GFR1) = g[1];
         MPC_S(P.SC, SC_GFR2) = g[2];
     }
+    t.a[0] = a03; t.a[1] = a04; t.a[2] = a13; t.a[3] = a14; t.a[4] = a42; t.a[5] = a43;
+    t.theta = theta; t.fc = fc; t.prim = prim; t.dual = dual; t.cmin = cmin; t.cmax = cmax; t.smult = smult; t.sz = sz; t.gp = gp;
+}
+
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, class IN = IneqOut<NX>, uint32_t VM = 0xFFu>
+MPC_HD void phase_eval_finish(const Params& P, Ctx<NX>& c, Red3& red, const IN& xk, EvalTmp<NX>& t) {
+    using D = Dim<NX>;
+    using IR = IneqRows<NX>;
+    constexpr int NZ = D::NZ;
+    red = red_neutral3();
+    if (!c.active) return;
+    const int N = P.N, k = c.k;
+    double* H = t.H;
+    double* rx = t.rx;
+    double* ru = t.ru;
+    double* ruu = t.ruu;
+    const double* cn = t.cn;
+    double dual = t.dual;
+    const double theta = t.theta, fc = t.fc, prim = t.prim, cmin = t.cmin, cmax = t.cmax, smult = t.smult, sz = t.sz, gp = t.gp;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const bool isu = i < 2;
+        if (!side_mine<(ROLE == ROLE_A ? ROLE_B : ROLE_ALL), VM>(i)) continue;
+        if (isu && k == N) continue;
+        const double sg = xk.get(3 * i + IR::SG), gbb = xk.get(3 * i + IR::GBB), rz = xk.get(3 * i + IR::RZ);
+        if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
+        else { H[D::sidx(i - 2, i - 2)] += sg; c.gxb[i - 2] += gbb; rx[i - 2] += rz; }
+    }
+    {
+        const int oi[3] = {0, 1, 4};
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rx[oi[a]] += xk.get(IR::ORX + a);
+            c.gxa[oi[a]] += xk.get(IR::OGXA + a);
+            c.gxb[oi[a]] += xk.get(IR::OGXB + a);
+#pragma unroll
+            for (int bq = a; bq < 3; ++bq, ++q) H[D::sidx(oi[a], oi[bq])] += xk.get(IR::OH + q);
+        }
+    }
     double nanflag = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1457,7 +1504,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
     // stage blocks that do not depend on the barrier parameter
     {
         static_assert(D::B_A == 0 && D::B_RUU == 6 && D::B_CN % 2 == 0 && D::B_H % 2 == 0, "stage-block runs start on row-pair boundaries");
-        const double head[8] = {a03, a04, a13, a14, a42, a43, ruu[0], ruu[1]};
+        const double head[8] = {t.a[0], t.a[1], t.a[2], t.a[3], t.a[4], t.a[5], ruu[0], ruu[1]};
         double hh[D::NH];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -1476,18 +1523,28 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red, const IN
         }
     }
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
-    ls = (ROLE == ROLE_A && !(k == 0 && c.fric_row)) ? 0.0 : log(gp);
+    const double ls = log(gp);
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
 }
 
-// (one thread per (instance, stage): both parts back to back, one sincos for the two)
+// the inequality thread's share of the KKT-error reduction
+MPC_HD void phase_eval_red_b(bool active, Red3& red, const KktPart& kp) {
+    red = red_neutral3();
+    if (!active) return;
+    red.dual_inf = kp.dual; red.prim_inf = kp.prim; red.cmin = kp.cmin; red.cmax = kp.cmax; red.sum_mult = kp.smult; red.sum_z = kp.sz;
+    red.theta = kp.theta; red.logsum = log(kp.gp);
+}
+
+// (one thread per (instance, stage): the three pieces back to back, one sincos for all)
 template <int NX, bool REUSE = false, bool MB = false>
 MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     IneqOut<NX> xo;
     KktPart kp;
+    EvalTmp<NX> t;
     const Trig tg = psi_trig(c.z[2 + 4]);
     phase_ineq_assemble<NX, REUSE>(P, c, xo, kp, tg);
-    phase_eval_assemble<NX, REUSE, MB, ROLE_ALL, true, IneqOut<NX>>(P, c, red, xo, kp, tg);
+    phase_eval_model<NX, REUSE, ROLE_ALL, true>(P, c, t, kp, tg);
+    phase_eval_finish<NX, MB, ROLE_ALL>(P, c, red, xo, t);
 }
 
 // =========================================================================================================

@@ -253,10 +253,14 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
 // LDS (doubles): [reduction scratch (waves x 10 x bx) | bounds table 2 nb | neighbour exchange 2 NX x T | IneqOut (3 NZ + 15) x T]
 // ---------------------------------------------------------------------------------------------------------------
 template <int NX> __host__ __device__ constexpr int pair_rows() { return 2 * NX + 3 * (NX + 2) + 15; }
+// the variables that carry bounds in the reference's NLP (optimizer.py:421-491: steering rate, acceleration, steering angle, speed):
+// the pair kernels are instantiated for this mask (a handle whose bounds touch other variables runs one thread per stage)
+constexpr uint32_t PAIR_VM = 0x33u;
 template <int NX, bool MB, int ROLE>
 __device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
                                                 double* lds, int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
     constexpr int NZ = NX + 2;
+    constexpr uint32_t VM = PAIR_VM;
     int or_parity = 0;
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x, tt = (ROLE == ROLE_B) ? t - T : t;
@@ -283,53 +287,57 @@ __device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mul
     phase_load_scalars<NX>(P, c);
     {
         PreTmp<NX> tmp;
-        phase_preload<NX, MB, ROLE>(P, c, tmp);          // every array load of the item is in flight before the first wait
+        phase_preload<NX, MB, ROLE, VM>(P, c, tmp);      // every array load of the item is in flight before the first wait
         phase_premath<NX, ROLE>(P, c, tmp);
     }
     MPC_STAMP(1);
     if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
     MPC_STAMP(2);
     Red1 r1;
-    phase_step_candidates<NX, ROLE>(P, c, r1);
+    phase_step_candidates<NX, ROLE, VM>(P, c, r1);
     MPC_STAMP(3);
     block_reduce(r1, bx, lds);
     phase_linesearch_begin<NX>(P, c, r1);
     MPC_STAMP(4);
     while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
         Red2 r2;
-        phase_trial_eval<NX, ROLE>(P, c, r2);
+        phase_trial_eval<NX, ROLE, VM>(P, c, r2);
         block_reduce(r2, bx, lds);
         phase_linesearch_decide<NX>(P, c, r2);
     }
     MPC_STAMP(5);
-    phase_apply_update<NX, MB, ROLE>(P, c);
+    phase_apply_update<NX, MB, ROLE, VM>(P, c);
     MPC_STAMP(6);
-    // the hand-over of the pair: one LDS column per pair, rows of IneqRows (put by B in front of the barrier, read by A behind it --
-    // one row at a time, so that neither thread holds the 39 values at once)
+    // the hand-over of the pair: one LDS column per pair, rows of IneqRows (put by B, read by A behind the second barrier -- one row
+    // at a time, so that neither thread holds the values at once)
     struct LdsCol {
         double* col; int T;
         __device__ __forceinline__ void put(int r, double x) { col[r * T] = x; }
         __device__ __forceinline__ double get(int r) const { return col[r * T]; }
     } xk{lds_k + tt, T};
-    KktPart kp = kkt_part_neutral();
+    Red3 r3;
     if (ROLE == ROLE_A) {
         // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
 #pragma unroll
         for (int i = 0; i < NX; ++i) { lds_x[i * T + tt] = c.z[2 + i]; lds_x[(NX + i) * T + tt] = c.lam[i]; }
-    } else {
-        phase_ineq_assemble<NX, true, LdsCol>(P, c, xk, kp, psi_trig(c.z[2 + 4]));
-    }
-    lds_barrier();
-    if (ROLE == ROLE_A) {
+        lds_barrier();
         const int tn = tt + bx;
         if (tn < T) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) { c.xn[i] = lds_x[i * T + tn]; c.lamn[i] = lds_x[(NX + i) * T + tn]; }
         }
+        MPC_STAMP(7);
+        EvalTmp<NX> et;
+        phase_eval_model<NX, true, ROLE_A, false, VM>(P, c, et, kkt_part_neutral());
+        lds_barrier();                                   // the inequality thread's rows are in LDS
+        phase_eval_finish<NX, MB, ROLE_A, LdsCol, VM>(P, c, r3, xk, et);
+    } else {
+        lds_barrier();
+        KktPart kp;
+        phase_ineq_assemble<NX, true, LdsCol, ROLE_B, VM>(P, c, xk, kp, psi_trig(c.z[2 + 4]));
+        lds_barrier();
+        phase_eval_red_b(c.active, r3, kp);
     }
-    MPC_STAMP(7);
-    Red3 r3;
-    phase_eval_assemble<NX, true, MB, ROLE, false, LdsCol>(P, c, r3, xk, kp);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
@@ -1806,7 +1814,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1842,7 +1850,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
-    else if (n == "pair") k.pair = value == nullptr ? 1 : (int)iv;
+    else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
@@ -2315,7 +2323,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
     // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
-    auto wg_pair = [&](int bxw) { return kn.pair != 0 && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
+    const bool pair_vm_ok = ((P.lo_mask | P.hi_mask) & ~PAIR_VM) == 0u;        // the pair kernels are compiled for the reference's bound structure
+    auto wg_pair = [&](int bxw) { return kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
     auto wg_lds = [&](int bxw) {
         const int thr = ((S * bxw + 63) / 64) * 64;
         if (wg_pair(bxw))
@@ -2406,7 +2415,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
         // two threads per (instance, stage) in the stage workers (option pair): 512-thread workgroups
         const size_t lds_pair = ((size_t)(2 * nw) * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * threads) * sizeof(double);
-        const bool pipe_pair = kn.pair != 0 && 2 * threads <= 512 && lds_pair <= lds_max;
+        const bool pipe_pair = kn.pair != 0 && pair_vm_ok && 2 * threads <= 512 && lds_pair <= lds_max;
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;

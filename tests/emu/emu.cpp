@@ -132,33 +132,40 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
                 eval_finish(true);
                 continue;
             }
-            // ---- the pair: ctx = model threads, ctb = barrier threads
+            // ---- the pair: ctx = model threads (ROLE_A), ctb = inequality threads (ROLE_B); VM: the kernels' compile-time variable mask
+            constexpr uint32_t VM = 0x33u;
             for (int t = 0; t < nthreads; ++t) {
                 PreTmp<NX> tmp;
-                phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX, false, ROLE_A>(P, ctx[t], tmp); phase_premath<NX, ROLE_A>(P, ctx[t], tmp);
-                phase_load_scalars<NX>(P, ctb[t]); phase_preload<NX, false, ROLE_B>(P, ctb[t], tmp); phase_premath<NX, ROLE_B>(P, ctb[t], tmp);
+                phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX, false, ROLE_A, VM>(P, ctx[t], tmp); phase_premath<NX, ROLE_A>(P, ctx[t], tmp);
+                phase_load_scalars<NX>(P, ctb[t]); phase_preload<NX, false, ROLE_B, VM>(P, ctb[t], tmp); phase_premath<NX, ROLE_B>(P, ctb[t], tmp);
                 any |= ctx[t].active;
             }
             if (!any) continue;
-            for (int t = 0; t < nthreads; ++t) { phase_step_candidates<NX, ROLE_A>(P, ctx[t], r1[t]); phase_step_candidates<NX, ROLE_B>(P, ctb[t], r1[nthreads + t]); }
+            for (int t = 0; t < nthreads; ++t) { phase_step_candidates<NX, ROLE_A, VM>(P, ctx[t], r1[t]); phase_step_candidates<NX, ROLE_B, VM>(P, ctb[t], r1[nthreads + t]); }
             reduce2(r1);
             for (int t = 0; t < nthreads; ++t) { phase_linesearch_begin<NX>(P, ctx[t], r1[t]); phase_linesearch_begin<NX>(P, ctb[t], r1[nthreads + t]); }
             for (;;) {
                 bool searching = false;
                 for (int t = 0; t < nthreads; ++t) searching |= (ctx[t].active && ctx[t].searching);
                 if (!searching) break;
-                for (int t = 0; t < nthreads; ++t) { phase_trial_eval<NX, ROLE_A>(P, ctx[t], r2[t]); phase_trial_eval<NX, ROLE_B>(P, ctb[t], r2[nthreads + t]); }
+                for (int t = 0; t < nthreads; ++t) { phase_trial_eval<NX, ROLE_A, VM>(P, ctx[t], r2[t]); phase_trial_eval<NX, ROLE_B, VM>(P, ctb[t], r2[nthreads + t]); }
                 reduce2(r2);
                 for (int t = 0; t < nthreads; ++t) { phase_linesearch_decide<NX>(P, ctx[t], r2[t]); phase_linesearch_decide<NX>(P, ctb[t], r2[nthreads + t]); }
             }
-            for (int t = 0; t < nthreads; ++t) { phase_apply_update<NX, false, ROLE_A>(P, ctx[t]); phase_apply_update<NX, false, ROLE_B>(P, ctb[t]); }
-            for (int t = 0; t < nthreads; ++t) phase_ineq_assemble<NX, true>(P, ctb[t], xk[t], kp[t], psi_trig(ctb[t].z[2 + 4]));      // B -> A (LDS, in front of the exchange barrier)
+            for (int t = 0; t < nthreads; ++t) { phase_apply_update<NX, false, ROLE_A, VM>(P, ctx[t]); phase_apply_update<NX, false, ROLE_B, VM>(P, ctb[t]); }
+            // (barrier: the neighbour exchange of the model threads)
             for (int t = 0; t + bx < nthreads; ++t)
                 for (int i = 0; i < NX; ++i) { ctx[t].xn[i] = ctx[t + bx].z[2 + i]; ctx[t].lamn[i] = ctx[t + bx].lam[i]; }
+            std::vector<EvalTmp<NX>> et(nthreads);
             const KktPart neutral = kkt_part_neutral();
             for (int t = 0; t < nthreads; ++t) {
-                phase_eval_assemble<NX, true, false, ROLE_A, false, IneqOut<NX>>(P, ctx[t], r3[t], xk[t], neutral);
-                phase_eval_assemble<NX, true, false, ROLE_B, false, IneqOut<NX>>(P, ctb[t], r3[nthreads + t], xk[t], kp[t]);
+                phase_eval_model<NX, true, ROLE_A, false, VM>(P, ctx[t], et[t], neutral);
+                phase_ineq_assemble<NX, true, IneqOut<NX>, ROLE_B, VM>(P, ctb[t], xk[t], kp[t], psi_trig(ctb[t].z[2 + 4]));      // B -> A (LDS)
+            }
+            // (barrier)
+            for (int t = 0; t < nthreads; ++t) {
+                phase_eval_finish<NX, false, ROLE_A, IneqOut<NX>, VM>(P, ctx[t], r3[t], xk[t], et[t]);
+                phase_eval_red_b(ctb[t].active, r3[nthreads + t], kp[t]);
             }
             reduce2(r3);
             for (int t = 0; t < nthreads; ++t) { phase_finish<NX, false, ROLE_A>(P, ctx[t], r3[t], hp.n_mult, hp.n_z); phase_finish<NX, false, ROLE_B>(P, ctb[t], r3[nthreads + t], hp.n_mult, hp.n_z); }

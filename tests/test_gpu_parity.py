@@ -727,3 +727,38 @@ def test_wave_per_instance_kernel_options_agree(fam):
         assert np.array_equal(res[0].iters[:64], ro["iters"]) and np.abs(res[0].x[:64] - ro["x"]).max() < TOL_ORACLE
     else:       # nonconvex: the same basin for nearly all, a handful may differ
         assert np.mean(np.abs(res[0].x[:64][both] - ro["x"][both]).max(axis=1) < 1e-6) > 0.9
+
+
+# ---- option pair: two threads per (instance, stage) in the stage phases (measured, not the default: profiles/r04_stage_split.txt) ---------------
+
+@pytest.mark.parametrize("fam,B", [("zamlf_n30_nx6", 4096), ("zamlf_n30_nx6", 200), ("zamlf_n10_nx5", 1000), ("ca", 256)])
+def test_two_threads_per_stage_option(fam, B):
+    """`pair = 1`: the model thread and the inequality thread of every (instance, stage) in different wavefronts (ROLE_A / ROLE_B of
+    mpc_stage_math.h), in the pipeline's stage workers and in k_solve_wg -- against the oracle like the default path, and the rows a
+    second solve returns are the same bits"""
+    if fam == "ca":
+        cfg = CA_CFG
+        x0, p = ca_batch(cfg, B)
+    else:
+        cfg, kw = FAMILIES[fam]
+        x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg)
+    if fam == "ca":
+        set_cfg_bounds(s, cfg)
+    s.set_option("pair", "1")
+    assert s.get_option("pair") == 1
+    r = s.solve(x0, p)
+    r2 = s.solve(x0, p)
+    assert np.array_equal(r.x, r2.x) and np.array_equal(r.iters, r2.iters)
+    sub = slice(0, B, max(1, B // 64))
+    ro = OracleSolver(cfg).solve_batch(x0[sub], p[sub], nthreads=8)
+    if fam == "ca":
+        assert np.all(r.status == 1)
+        nlp = BicycleNLP(cfg)
+        lbg, ubg, _, _ = nlp.bounds()
+        for b in range(0, B, 16):
+            g = nlp.g(r.x[b], p[b])
+            assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6)
+    else:
+        assert np.all(r.status == 1) and r.kkt.max() <= 1e-8
+        assert np.array_equal(r.iters[sub], ro["iters"]) and np.abs(r.x[sub] - ro["x"]).max() < TOL_ORACLE
