@@ -237,8 +237,15 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway; this lowers the limit),
  * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing",
  * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage),
- * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve)
- * (measurement and test aids).  Unknown name -> MPC_ERR_INVALID.                                  */
+ * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve),
+ * "pair" (1: two threads per (instance, stage) in the stage phases; measured slower, profiles/r04_stage_split.txt)
+ * (measurement and test aids);
+ * "friction_lb" -- the lower bound lbg[0] = 0 of the reference's stage-0 friction row sqrt((a_0^2 + v_0^2 tan(delta_0)/2.578)^2)
+ * (MPC_Planner/optimizer.py:378, 424-425): "nlp" / 0 (default) = implied by the absolute value, no barrier -- a solve returns the
+ * optimum of the NLP; "ipopt" / 1 = the row as IPOPT sees it, a slack with both bounds and a log barrier on the lower one too: the
+ * kink of |.| at a_0^2 = -v_0^2 tan(delta_0)/2.578 becomes a wall the slack does not cross and a solve can end AT it, depending on
+ * the warm start -- what the reference's recorded ZAM_Over-1_1 run shows at steps 4 and 13 (tests/test_recorded_residuals.py).
+ * Unknown name -> MPC_ERR_INVALID.                                                                                     */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);
 /* current value of an option (so that a caller that changes one for a moment can put the PREVIOUS value back, not the default) */
 int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value);

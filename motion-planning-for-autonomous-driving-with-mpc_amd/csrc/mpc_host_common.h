@@ -22,6 +22,13 @@ struct HostProblem {
     int has_fl = 0, has_fu = 0, has_ol = 0, has_ou = 0;
     double fl = 0, fu = 0, ol = 0, ou = 0;
     double ol_raw = 0;                  // lower bound of the obstacle rows as the caller gave it (before relaxation)
+    double fl_raw = 0;                  // lbg[0] as the caller gave it
+    // option friction_lb.  0 ("nlp", the default): the lower bound lbg[0] <= 0 of the stage-0 friction row |a_0^2 + c| is implied by
+    // the absolute value and gets no barrier (and the row is presolved into a bound on a_0 wherever that is exact).  1 ("ipopt"): the
+    // row as IPOPT sees it (optimizer.py:378, 424-425) -- a slack with BOTH bounds, log barrier on the lower one too: the kink of |.|
+    // at a_0^2 = -c becomes a wall the slack cannot cross, and a solve can end at it (tests/test_recorded_residuals.py: what the
+    // recorded CasADi runs show at ZAM_Over-1_1 steps 4 and 13)
+    int fric_literal = 0;
     int n_mult = 0, n_z = 0;
     bool bounds_set = false;
     int NZ() const { return desc.nx + 2; }
@@ -29,6 +36,11 @@ struct HostProblem {
     size_t n_g() const { return (size_t)1 + (size_t)desc.nx * (desc.N + 1) + (size_t)9 * (desc.N + 1); }
 };
 
+// (option friction_lb changed after the bounds were set)
+inline void apply_fric_literal(HostProblem& hp, int literal) {
+    hp.fric_literal = literal ? 1 : 0;
+    if (hp.bounds_set) hp.has_fl = std::isfinite(hp.fl_raw) && (hp.fl_raw > 0.0 || hp.fric_literal);
+}
 inline double relax_lo(double lo) { return std::isfinite(lo) ? lo - BOUND_RELAX * std::fmax(1.0, std::fabs(lo)) : -INFINITY; }
 inline double relax_hi(double hi) { return std::isfinite(hi) ? hi + BOUND_RELAX * std::fmax(1.0, std::fabs(hi)) : INFINITY; }
 
@@ -97,7 +109,8 @@ inline int set_bounds(HostProblem& hp, const double* lbx, const double* ubx, con
     for (int i = 0; i < 9 * (N + 1); ++i)
         if (!(lbg[o0 + i] == olo && ubg[o0 + i] == ohi)) { err = "obstacle rows must share one [lbg, ubg] pair"; return MPC_ERR_BOUNDS; }
     if (std::isnan(olo) || std::isnan(ohi) || !(olo < ohi)) { err = "obstacle rows need lbg < ubg"; return MPC_ERR_BOUNDS; }
-    hp.has_fl = std::isfinite(flo) && flo > 0.0;     // |y| >= lo with lo <= 0 is implied by the absolute value
+    hp.fl_raw = flo;
+    hp.has_fl = std::isfinite(flo) && (flo > 0.0 || hp.fric_literal);     // |y| >= lo with lo <= 0 is implied by the absolute value (unless asked for literally)
     hp.has_fu = std::isfinite(fhi);
     hp.fl = relax_lo(flo); hp.fu = relax_hi(fhi);
     hp.has_ol = std::isfinite(olo); hp.has_ou = std::isfinite(ohi);

@@ -1814,7 +1814,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1851,6 +1851,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
+    else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
     return MPC_OK;
@@ -1877,12 +1878,13 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
     else if (n == "pair") *out = k.pair;
+    else if (n == "friction_lb") *out = k.friction_lb;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -1958,6 +1960,7 @@ int mpc_create(mpc_handle** out, const mpc_problem_desc* desc) {
     h->hp.desc = *desc;
     h->device = desc->device;
     knobs_from_env(h->knobs);
+    h->hp.fric_literal = h->knobs.friction_lb ? 1 : 0;
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&h->d_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * mpc_handle::MAX_POLL_IT) != hipSuccess ||
         hipHostMalloc(&h->h_counter, sizeof(int32_t) * mpc_handle::MAX_GROUPS * 2) != hipSuccess ||
@@ -2046,6 +2049,7 @@ int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
     if (!h || !name) return MPC_ERR_INVALID;
     const int rc = set_knob(h->knobs, name, value);
     if (rc) h->err = std::string("unknown option: ") + name;
+    else apply_fric_literal(h->hp, h->knobs.friction_lb);
     return rc;
 }
 

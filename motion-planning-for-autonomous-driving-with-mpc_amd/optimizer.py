@@ -239,6 +239,9 @@ class CasadiOptimizer(Optimizer):
             centers = np.array(self.obstacle_circles_centers_tuple, dtype=np.float64)
             backend = BatchedMPCSolver(self.predict_horizon, 5, dt=self.delta_t, Q=Q, R=R, P=Pt, obstacle_centers=centers,
                                        ego_offset=(disc_distance / 2) / 2, max_iter=100, tol=1e-8, device=self._device)
+            # the lower bound 0 of the stage-0 friction row (optimizer.py:378, 424): "nlp" (default: implied by the absolute value) or
+            # "ipopt" (a barrier on it too, as IPOPT has -- a solve can then end at the kink of |.|; include/mpcgpu.h, option friction_lb)
+            backend.set_option("friction_lb", str(getattr(self.configuration, "friction_lb", "nlp")))
             self._sol = NlpSolverHandle(backend)
         return self._sol, self._f
 

@@ -76,9 +76,11 @@ def _pi(a):
 
 
 def make_desc(cfg: NLPConfig, max_iter=100, tol=1e-8, fixed_iters=0, obst_mult=3, literal_friction_row=False) -> MpcoDesc:
+    # literal_friction_row: True / 1 = the stage-0 friction row stays a row (no presolve); 2 or "ipopt" = as IPOPT sees it, the row's lower
+    # bound lbg[0] = 0 with its log barrier too (the product's option friction_lb = ipopt)
     d = MpcoDesc()
     d.N, d.nx, d.obst_mult, d.max_iter, d.fixed_iters = cfg.N, cfg.nx, obst_mult, max_iter, fixed_iters
-    d.reserved = 1 if literal_friction_row else 0
+    d.reserved = 2 if literal_friction_row in (2, "ipopt") else (1 if literal_friction_row else 0)
     d.dt, d.wheelbase, d.friction_div, d.ego_offset = cfg.dt, cfg.wheelbase, cfg.friction_div, cfg.ego_offset
     for i, q in enumerate(cfg.Qdiag):
         d.Q[i] = q

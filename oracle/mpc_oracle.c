@@ -364,7 +364,9 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
             pb->ubx[k][i] = relax_hi(ubx_in[2 * N + nx * k + i]);
         }
     }
-    pb->has_fl = fin(d->fric_lo) && d->fric_lo > 0.0;      /* |y| >= lo <= 0 is vacuous */
+    /* |y| >= lo <= 0 is vacuous -- unless the row is asked for as IPOPT sees it (reserved == 2: a slack with both bounds, log barrier on
+     * the lower one too; optimizer.py:378, 424-425) */
+    pb->has_fl = fin(d->fric_lo) && (d->fric_lo > 0.0 || d->reserved == 2);
     pb->has_fu = fin(d->fric_hi);
     pb->fl = relax_lo(d->fric_lo); pb->fu = relax_hi(d->fric_hi);
     pb->fric_row = 1;
@@ -839,7 +841,8 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
         }
         /* ---------------- update + multiplier reset */
 #define ZRESET(z, gap) do { const double lo_ = mu / (KAPPA_SIGMA * (gap)), hi_ = KAPPA_SIGMA * mu / (gap); \
-                            if ((z) < lo_) (z) = lo_; if ((z) > hi_) (z) = hi_; } while (0)
+                            if ((z) < lo_) (z) = lo_;                                                        \
+                            if ((z) > hi_) (z) = hi_; } while (0)
         for (int k = 0; k <= N; ++k) {
             for (int i = 0; i < nx; ++i) {
                 it->x[k][i] = tr->x[k][i];

@@ -35,7 +35,8 @@ typedef struct mpco_desc {
     int32_t obst_mult;       /* 3: every distinct circle distance is appended three times (:395-403)   */
     int32_t max_iter;        /* 100 (optimizer.py:556)                                                  */
     int32_t fixed_iters;     /* >0: run exactly this many iterations (benchmark mode)                  */
-    int32_t reserved;        /* 1 = keep the stage-0 friction row literally (no presolve into a bound on a_0)   */
+    int32_t reserved;        /* 1 = keep the stage-0 friction row as a row (no presolve into a bound on a_0); 2 = as IPOPT sees it: a row
+                              * whose slack also carries the lower bound lbg[0] = 0 with its log barrier                          */
     double dt;               /* scenario.dt = 0.1                                                       */
     double wheelbase;        /* 2.5789128  (configuration.py:362-363)                                   */
     double friction_div;     /* 2.578      (optimizer.py:378)                                           */
