@@ -52,6 +52,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 N_HORIZON, NX, NU, BATCH = 30, 6, 2, 4096
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 JSON_OUT = sys.stdout            # main() swaps it for a private copy of file descriptor 1
+HOST_CPUS = 1                    # main() counts the host cpus before the OpenMP runtime pins the main thread
 PUBLISHED_CASADI = "25.1 steps/s (N=10, 1 instance, unknown CPU, graph rebuilt every step; BASELINE.md section 1: 36-41 ms per step)"
 
 
@@ -246,6 +247,10 @@ def main():
     ap.add_argument("--workload", choices=("headline", "mixed"), default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic falls back to the committed figure)")
+    ap.add_argument("--gather", choices=("overlap", "sync"), default="overlap",
+                    help="multi-GPU: the all-gather of a step's result rows runs on RCCL's stream under the next solve (overlap, default) or "
+                         "is waited for inside the step (sync) -- the fallback should the collective starve behind the persistent kernel")
+    ap.add_argument("--detail", default=None, help="write the full (long) result object to this file; it goes to stderr anyway")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed converged-mode steps and their roofline pass (no fixed-20 variant, configurations 2 - 5, side paths): "
                          "under `rocprofv3 --kernel-trace --stats` the averages of k_pipeline<6> / k_solve_wg<6> are then those of the bench line")
@@ -265,6 +270,11 @@ def main():
     JSON_OUT = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    # (the cpu_baseline leg: OpenMP threads of the oracle pinned to cores, close to each other -- an unbound run moved 2.7x between boxes)
+    global HOST_CPUS
+    HOST_CPUS = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)     # (before the OpenMP runtime binds this thread)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import torch
     import torch.distributed as dist
     import mpc_amd
@@ -332,10 +342,14 @@ def main():
     # batch is being solved: two output buffers, the gather of step i is waited for before step i + 2 writes its buffer again, and
     # the last ones inside the timed region (`drain`).  The solver's persistent kernel fills every CU, so the collective's workgroups
     # find room in the straggler phase of the following solve, where most CUs idle.
+    # What travels is ONE block per rank: the rows with their status and iteration count behind them (sharding.pack_rows).
     d_outs = [d_out, torch.empty_like(d_out)] if gather else [d_out]
-    gathered = [torch.empty((world * B, d_out.shape[1]), dtype=d_out.dtype, device=dev) for _ in d_outs] if gather else None
+    PW = sharding.packed_width(d_out.shape[1])
+    packed = [torch.empty((B, PW), dtype=torch.float64, device=dev) for _ in d_outs] if gather else None
+    gathered = [torch.empty((world * B, PW), dtype=torch.float64, device=dev) for _ in d_outs] if gather else None
     works = [None] * len(d_outs)
     n_step = [0]
+    gather_wait = [0.0, 0]                                # seconds the host waited for gathers inside steps (sync mode: all of them), count
 
     def step(solver):
         j = n_step[0] % len(d_outs)
@@ -346,7 +360,15 @@ def main():
         solver.solve_device(B, d_x0.data_ptr(), d_p.data_ptr(), d_outs[j].data_ptr(), d_st.data_ptr(), d_it.data_ptr(),
                             d_kkt.data_ptr(), stream=stream)
         if gather:
-            works[j] = dist.all_gather_into_tensor(gathered[j], d_outs[j], async_op=True)     # (one kernel: no list of outputs to copy into)
+            sharding.pack_rows(d_outs[j], d_st, d_it, out=packed[j])                          # (three strided copies on the solve stream)
+            works[j] = sharding.gather_packed(packed[j], gathered[j], async_op=True)         # (one kernel: no list of outputs to copy into)
+            if args.gather == "sync":
+                tw = time.perf_counter()
+                works[j].wait()
+                torch.cuda.current_stream(dev).synchronize()
+                gather_wait[0] += time.perf_counter() - tw
+                gather_wait[1] += 1
+                works[j] = None
 
     def drain():
         for j in range(len(works)):
@@ -360,8 +382,26 @@ def main():
     value = world * B * args.steps / dt
     med = float(np.median(per))
     st, it, kkt = d_st.cpu().numpy(), d_it.cpu().numpy(), d_kkt.cpu().numpy()
-    converged = float((st == 1).mean())
-    mean_it, max_it = float(it.mean()), int(it.max())
+    # (over ALL ranks' rows; the roofline pass below stays this rank's own launch statistics)
+    allst = sharding.solve_stats_over_ranks(st, it, device=dev) if world > 1 else dict(converged_frac=float((st == 1).mean()), mean_iters=float(it.mean()), max_iters=int(it.max()))
+    converged, mean_it_all, max_it = allst["converged_frac"], allst["mean_iters"], allst["max_iters"]
+    mean_it = float(it.mean())
+    kkt_max = sharding.max_over_ranks(float(kkt.max()), device=dev) if world > 1 else float(kkt.max())
+    # the collective on its own: K gathers with nothing else on the machine, and a check of what arrived
+    gather_info = None
+    if gather:
+        drain()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            sharding.gather_packed(packed[0], gathered[0])
+        barrier()
+        g_alone = (time.perf_counter() - tg) / args.steps
+        gx, gst, git = sharding.unpack_rows(gathered[0][rank * B:(rank + 1) * B], d_out.shape[1])
+        ok = bool(torch.equal(gx, d_outs[0]) or torch.equal(gx, d_outs[-1])) and bool(torch.equal(gst, d_st)) and bool(torch.equal(git, d_it))
+        gather_info = dict(mode=args.gather, gather_ms_alone=(sharding.max_over_ranks(g_alone, device=dev) if world > 1 else g_alone) * 1e3,
+                           bytes_per_rank=B * PW * 8, own_rows_round_trip=ok,
+                           wait_ms_in_step=(gather_wait[0] / gather_wait[1] * 1e3) if gather_wait[1] else None)
 
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch
     ab = algorithmic_bytes(fam.N, fam.nx)
@@ -445,7 +485,7 @@ def main():
         from oracle.binding import OracleSolver
         from oracle.nlp_numpy import NLPConfig
         osol = OracleSolver(NLPConfig(N=fam.N, nx=fam.nx, Q=fam.Q, R=fam.R))
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        avail = HOST_CPUS
         xs, ps = x0[:4096], p[:4096]
         best = None
         for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances; keep the best count
@@ -464,6 +504,12 @@ def main():
         t0 = time.perf_counter()
         osol.solve_batch(xs[:1024], ps[:1024], nthreads=1)
         t_one = time.perf_counter() - t0
+        # one FIXED thread count beside the best of the sweep (comparable between boxes: threads bound to cores, OMP_PROC_BIND=close)
+        n32 = min(32, avail)
+        osol.solve_batch(xs[:256], ps[:256], nthreads=n32)
+        t0 = time.perf_counter()
+        osol.solve_batch(xs, ps, nthreads=n32)
+        t_32 = time.perf_counter() - t0
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as fh:
@@ -473,7 +519,9 @@ def main():
         cpu_baseline = dict(value=reps * len(xs) / t_all, unit="MPC steps/s", cores=cores, kind="port",
                             sample=f"{reps} x {len(xs)} instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
                                    f"OpenMP over instances, all converged={bool((ro['status'] == 1).all())}",
-                            single_thread_value=1024 / t_one, cpu_model=model, host_cpus=avail,
+                            sample_short=f"{reps}x{len(xs)} instances, oracle C port, OpenMP bound to cores",
+                            single_thread_value=1024 / t_one, bound_32_threads_value=len(xs) / t_32, bound_threads=n32,
+                            omp_proc_bind=os.environ.get("OMP_PROC_BIND"), cpu_model=model, host_cpus=avail,
                             casadi_ipopt=casadi_probe(fam, x0, p, wl), published_casadi_ipopt=PUBLISHED_CASADI)
 
     # ---- BASELINE.json configurations 2 - 5 under the same clock (single-GPU run only; a few batches each, ~1 s in total)
@@ -495,11 +543,71 @@ def main():
                                batch_per_gpu=B, horizon=fam.N, nx=fam.nx, nu=2, parallelism="independent instances x%d" % world,
                                mode="converged", gpu=torch.cuda.get_device_name(dev)),
                    ms_per_step_median=med * 1e3, value_median_batch=world * B / med if world == 1 else None,
-                   converged_frac=converged, mean_iters=mean_it, max_iters=max_it, kkt_max=float(kkt.max()),
+                   converged_frac=converged, mean_iters=mean_it_all, max_iters=max_it, kkt_max=kkt_max, gather=gather_info,
                    fixed20=fixed20, roofline=roofline, cpu_baseline=cpu_baseline, configs=configs, other_paths=other_paths)
-        print(json.dumps(out), file=JSON_OUT, flush=True)
+        emit(out, args)
     if gather:
         dist.destroy_process_group()
+
+
+def _g(x, n=5):
+    """a float with n significant digits (None / ints / strings as they are)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(("%%.%dg" % n) % float(x))
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_line(out):
+    """the ONE line of stdout: every contract key, the roofline and cpu_baseline objects and the other configurations, short enough for a
+    2000-character tail (the driver keeps that much) -- the long form with every note goes to stderr / --detail"""
+    r, cb = out["roofline"], out.get("cpu_baseline")
+    line = dict(metric=out["metric"], value=_g(out["value"], 6), unit=out["unit"], n_gpus=out["n_gpus"], steps=out["steps"], warmup=out["warmup"],
+                ms_per_step=_g(out["ms_per_step"]), higher_is_better=True, scaling=out["scaling"], vs_baseline=None, dtype=out["dtype"], data=out["data"],
+                config=dict(workload="N=30 nx=6 nu=2 bicycle lane-following, batch=%d/GPU, tol 1e-8" % out["config"]["batch_per_gpu"], mode="converged",
+                            gpu=out["config"]["gpu"]),
+                converged_frac=_g(out["converged_frac"]), mean_iters=_g(out["mean_iters"]), max_iters=out["max_iters"],
+                roofline=dict(bound=r["bound"], kernel=r["kernel"], achieved=_g(r["achieved"]), peak=r["peak"], unit=r["unit"], frac=_g(r["frac"], 4),
+                              traffic=_g(r["traffic"]), avg_launch_us=_g(r["avg_launch_us"]), bytes_per_launch=_g(r["algorithmic_bytes_per_launch"]),
+                              copy_bw=_g(r.get("measured_copy_bw_gbs"), 4),
+                              kernels={k: [_g(v["avg_us"], 4), _g(v["gbs"], 4), _g(v["frac"], 3)] for k, v in r["kernels"].items()}))
+    if cb:
+        line["cpu_baseline"] = dict(value=_g(cb["value"]), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=cb["sample_short"],
+                                    one_thread=_g(cb["single_thread_value"], 4), bound32=_g(cb.get("bound_32_threads_value"), 4))
+    else:
+        line["cpu_baseline"] = None
+    if out.get("configs"):
+        # [configuration, batch, ms per batch, steps/s, converged, mean iters, max iters, roofline frac of the loop, rescued]
+        line["configs"] = [[c["config"].split(":")[0], c["batch"], _g(c["ms_per_batch"], 4), _g(c["steps_per_s"], 4), _g(c["converged_frac"], 4),
+                            _g(c["mean_iters"], 4), c["max_iters"], _g(c["roofline_frac"], 3), c["rescued"]] if "error" not in c else ["error"]
+                           for c in out["configs"]]
+    if out.get("fixed20"):
+        line["fixed20"] = [_g(out["fixed20"]["value"]), _g(out["fixed20"]["ms_per_step"], 4)]
+    op = out.get("other_paths") or {}
+    side = {}
+    if "closed_loop" in op:
+        side["closed_loop_ego_steps_s"] = _g(op["closed_loop"]["ego_steps_per_s"], 4)
+    if "forces_sqp_step" in op:
+        f = op["forces_sqp_step"]
+        side["forces_sqp"] = [_g(f["solves_per_s"], 4), _g(f["roofline"]["frac"], 3), _g(f["roofline"]["traffic"], 4), _g(f["roofline"]["algorithmic_bytes_per_launch"], 4)]
+    if "forces_closed_loop" in op:
+        side["forces_loop_ego_steps_s"] = _g(op["forces_closed_loop"].get("ego_steps_per_s"), 4)
+    if side:
+        line["other_paths"] = side
+    if out.get("gather"):
+        line["gather"] = {k: _g(v, 4) for k, v in out["gather"].items()}
+    return line
+
+
+def emit(out, args):
+    long_form = json.dumps(out)
+    print("[bench detail] " + long_form, file=sys.stderr, flush=True)
+    if getattr(args, "detail", None):
+        with open(args.detail, "w") as fh:
+            fh.write(long_form + "\n")
+    print(json.dumps(compact_line(out), separators=(",", ":")), file=JSON_OUT, flush=True)
 
 
 def other_configs(torch, wl, local_rank, dev, stream):
@@ -520,10 +628,24 @@ def other_configs(torch, wl, local_rank, dev, stream):
             d["kkt"] = torch.empty(B, dtype=torch.float64, device=dev)
             items.append(d)
 
-        def once():
+        # several handles (configuration 5): concurrently, one host thread and one stream each, the collision-avoidance family first
+        if len(items) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            items.sort(key=lambda d: 0 if "ca" in d["fam"].name else 1)
+            pool = ThreadPoolExecutor(max_workers=len(items))
             for d in items:
-                d["s"].solve_device(d["B"], d["x0"].data_ptr(), d["p"].data_ptr(), d["out"].data_ptr(), d["st"].data_ptr(), d["it"].data_ptr(),
-                                    d["kkt"].data_ptr(), stream=stream)
+                d["stream"] = torch.cuda.Stream(device=dev)
+
+        def solve_one(d):
+            torch.cuda.set_device(dev)
+            d["s"].solve_device(d["B"], d["x0"].data_ptr(), d["p"].data_ptr(), d["out"].data_ptr(), d["st"].data_ptr(), d["it"].data_ptr(),
+                                d["kkt"].data_ptr(), stream=d["stream"].cuda_stream if "stream" in d else stream)
+
+        def once():
+            if len(items) > 1:
+                list(pool.map(solve_one, items))
+            else:
+                solve_one(items[0])
         once()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -534,7 +656,11 @@ def other_configs(torch, wl, local_rank, dev, stream):
         loop_ms = loop_bytes = 0.0
         for d in items:                              # one profiled batch: launch durations of the iteration loop
             d["s"].set_profiling(True)
-        once()
+        if len(items) > 1:                           # (launch durations of the loop: the handles one after the other, nothing else on the machine)
+            for d in items:
+                solve_one(d)
+        else:
+            once()
         torch.cuda.synchronize(dev)
         for d in items:
             ab = algorithmic_bytes(d["fam"].N, d["fam"].nx)
@@ -557,7 +683,7 @@ def other_configs(torch, wl, local_rank, dev, stream):
         run("3: ZAM_Over-1_1 collision avoidance (cold starts through the obstacle), N=30, batch=1024", [(f3,) + tuple(wl.batch(f3, 1024))])
         run("4: USA_Lanker weights, N=50, batch=4096", [(f4,) + tuple(wl.batch(f4, 4096))])
         shard = wl.mixed_shard(0, 8)
-        run("5: mixed scenario sweep, shard 0 of 8 (4096 rows over the three families, one handle each, back to back)",
+        run("5: mixed scenario sweep, shard 0 of 8 (4096 rows over the four families, one handle and one stream each, concurrently)",
             [(wl.FAMILIES[name], x0, p) for name, (rows, x0, p) in shard.items()], reps=3)
     except Exception as e:                               # the headline must not die of a side measurement
         out.append(dict(error=repr(e)))
@@ -630,45 +756,66 @@ def side_paths(torch, mpc_amd, fam, B, local_rank, traffic=True):
 
 
 def run_mixed(args, torch, dist, mpc_amd, sharding, wl, world, rank, local_rank, dev, stream, timed):
-    """BASELINE configuration 5: mixed scenario sweep, 4096 rows per GPU (32 768 over 8), one handle per family on every rank,
-    the three solves back to back, ONE all-gather of the padded result rows at the end of the step"""
+    """BASELINE configuration 5: mixed scenario sweep, 4096 rows per GPU (32 768 over 8), one handle per family on every rank.  The
+    four solves of a step run CONCURRENTLY -- one host thread and one HIP stream per handle, the collision-avoidance family first: its
+    long tail is a latency chain of a few wavefronts, under which the lane-following families fill the machine -- then ONE all-gather
+    of the padded result rows with their status and iteration counts (sharding.pack_rows)."""
+    from concurrent.futures import ThreadPoolExecutor
     per_gpu = wl.MIXED_SHARD
     shard = wl.mixed_shard(rank, world, total=per_gpu * world)
     W = wl.MIXED_ROW_WIDTH
-    d_res = torch.zeros(per_gpu, W, dtype=torch.float64, device=dev)          # result rows in global order, padded to one width
-    gathered = [torch.empty_like(d_res) for _ in range(world)] if world > 1 else None
+    PW = sharding.packed_width(W)
+    d_res = torch.zeros(per_gpu, PW, dtype=torch.float64, device=dev)         # result rows in global order, padded to one width, + status, iters
+    gathered = torch.empty((world * per_gpu, PW), dtype=torch.float64, device=dev) if world > 1 else None
     parts = []
-    for name in wl.MIXED_ORDER:
+    order = sorted(wl.MIXED_ORDER, key=lambda n: 0 if "ca" in n else 1)       # collision avoidance first
+    for name in order:
         rows, x0, p = shard[name]
         fam = wl.FAMILIES[name]
         nB = len(rows)
         parts.append(dict(fam=fam, B=nB, solver=wl.make_solver(fam, device=local_rank), x0=torch.from_numpy(x0).to(dev), p=torch.from_numpy(p).to(dev),
                           out=torch.empty(nB, fam.n_w, dtype=torch.float64, device=dev), st=torch.empty(nB, dtype=torch.int32, device=dev),
-                          it=torch.empty(nB, dtype=torch.int32, device=dev), local=torch.from_numpy(rows - rank * per_gpu).to(dev)))
+                          it=torch.empty(nB, dtype=torch.int32, device=dev), local=torch.from_numpy(rows - rank * per_gpu).to(dev),
+                          stream=torch.cuda.Stream(device=dev)))
+    serial = os.environ.get("MPC_BENCH_MIXED_SERIAL") == "1"                   # (A/B: the four solves back to back on one stream)
+    pool = ThreadPoolExecutor(max_workers=len(parts))
+
+    def solve_part(q):
+        torch.cuda.set_device(dev)
+        q["solver"].solve_device(q["B"], q["x0"].data_ptr(), q["p"].data_ptr(), q["out"].data_ptr(), q["st"].data_ptr(), q["it"].data_ptr(), 0,
+                                 stream=stream if serial else q["stream"].cuda_stream)
 
     def step():
+        if serial:
+            for q in parts:
+                solve_part(q)
+        else:
+            list(pool.map(solve_part, parts))                                # (every solve_device returns after its own stream has drained)
         for q in parts:
-            q["solver"].solve_device(q["B"], q["x0"].data_ptr(), q["p"].data_ptr(), q["out"].data_ptr(), q["st"].data_ptr(), q["it"].data_ptr(), 0,
-                                     stream=stream)
-            d_res[q["local"], : q["fam"].n_w] = q["out"]
+            n_w = q["fam"].n_w
+            d_res[q["local"], :n_w] = q["out"]
+            d_res[q["local"], W] = q["st"].double()
+            d_res[q["local"], W + 1] = q["it"].double()
         if world > 1:
-            dist.all_gather(gathered, d_res)
+            sharding.gather_packed(d_res, gathered)
 
     dt, per = timed(step, args.steps, args.warmup)
     value = world * per_gpu * args.steps / dt
     fams = {}
     for q in parts:
         st, it = q["st"].cpu().numpy(), q["it"].cpu().numpy()
-        fams[q["fam"].name] = dict(rows_per_gpu=q["B"], converged_frac=float((st == 1).mean()), mean_iters=float(it.mean()), max_iters=int(it.max()))
+        a = sharding.solve_stats_over_ranks(st, it, device=dev) if world > 1 else dict(converged_frac=float((st == 1).mean()), mean_iters=float(it.mean()), max_iters=int(it.max()))
+        fams[q["fam"].name] = [q["B"], _g(a["converged_frac"], 4), _g(a["mean_iters"], 4), a["max_iters"], int(q["solver"].last_rescued())]
     if rank == 0:
-        out = dict(metric="MPC steps/sec, mixed scenario sweep (BASELINE configuration 5)", value=value, unit="MPC steps/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, ms_per_step_median=float(np.median(per)) * 1e3,
+        out = dict(metric="MPC steps/sec, mixed scenario sweep (BASELINE configuration 5)", value=_g(value, 6), unit="MPC steps/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=_g(dt / args.steps * 1e3), ms_per_step_median=_g(float(np.median(per)) * 1e3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                   config=dict(workload="mixed scenario sweep: %d rows per GPU dealt row by row over %s (tools/workloads.py), one handle per family, "
-                                        "solved to tol 1e-8" % (per_gpu, ", ".join(wl.MIXED_ORDER)), rows_total=per_gpu * world,
-                               parallelism="contiguous shards x%d, one padded all-gather per step" % world, gpu=torch.cuda.get_device_name(dev)),
-                   families=fams)
-        print(json.dumps(out), file=JSON_OUT, flush=True)
+                   config=dict(workload="mixed scenario sweep: %d rows per GPU dealt row by row over %s, one handle per family, tol 1e-8" % (per_gpu, ", ".join(wl.MIXED_ORDER)),
+                               rows_total=per_gpu * world, parallelism="contiguous shards x%d; four handles on four streams; one packed all-gather per step" % world,
+                               handles="serial" if serial else "concurrent", gpu=torch.cuda.get_device_name(dev)),
+                   families=fams, families_cols="rows/GPU, converged, mean iters, max iters, rescued (rank 0)")
+        print(json.dumps(out, separators=(",", ":")), file=JSON_OUT, flush=True)
+    pool.shutdown()
     if world > 1:
         dist.destroy_process_group()
 

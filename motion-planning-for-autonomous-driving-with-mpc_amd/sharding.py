@@ -63,3 +63,53 @@ def sum_over_ranks(value: float, device=None, group=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())
+
+
+# ---- the gather payload of a step: result rows with their status and iteration count in ONE block ----------------
+def packed_width(n_w: int) -> int:
+    """columns of a packed block: n_w result values, then status and iteration count (int32 values, exact as float64)"""
+    return int(n_w) + 2
+
+
+def pack_rows(x, status, iters, out=None):
+    """[B, n_w] float64 rows + int32 status / iters -> one [B, n_w + 2] float64 block (torch tensors, any device; `out` is reused)"""
+    import torch
+
+    B, n_w = x.shape
+    if out is None:
+        out = torch.empty((B, n_w + 2), dtype=torch.float64, device=x.device)
+    out[:, :n_w].copy_(x)
+    out[:, n_w].copy_(status)
+    out[:, n_w + 1].copy_(iters)
+    return out
+
+
+def unpack_rows(block, n_w: int):
+    """inverse of pack_rows: (x [B, n_w] float64, status [B] int32, iters [B] int32)"""
+    import torch
+
+    return block[:, :n_w], block[:, n_w].round().to(torch.int32), block[:, n_w + 1].round().to(torch.int32)
+
+
+def gather_packed(block, out, group=None, async_op=False):
+    """the one collective of a step: every rank's packed block -> `out` [world * B, n_w + 2] on every rank (all_gather_into_tensor:
+    RCCL on GPUs, gloo in the CPU tests).  Returns the work handle when async_op, else None."""
+    import torch.distributed as dist
+
+    return dist.all_gather_into_tensor(out, block, group=group, async_op=async_op)
+
+
+def solve_stats_over_ranks(status, iters, device=None, group=None):
+    """converged fraction / mean / max of the iteration counts over ALL ranks' rows (each rank passes its own status and iters)"""
+    import torch
+    import torch.distributed as dist
+
+    st = torch.as_tensor(status)
+    it = torch.as_tensor(iters)
+    sums = torch.tensor([float((st == 1).sum()), float(st.numel()), float(it.sum())], dtype=torch.float64, device=device)
+    mx = torch.tensor([float(it.max()) if it.numel() else 0.0], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    n = max(1.0, float(sums[1]))
+    return dict(converged_frac=float(sums[0]) / n, mean_iters=float(sums[2]) / n, max_iters=int(mx.item()), rows=int(sums[1]))

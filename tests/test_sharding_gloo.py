@@ -63,3 +63,40 @@ def test_two_rank_shard_solve_gather(tmp_path):
     assert np.array_equal(g["status"], full["status"]) and np.array_equal(g["iters"], full["iters"])
     assert np.abs(g["x"] - full["x"]).max() < 1e-12          # sharding does not change any instance's result
     assert float(g["tmax"]) == 2.0 and float(g["tsum"]) == B
+
+
+def _worker_packed(rank, world, port, B, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, kw = FAMILIES["zamlf_n10_nx5"]
+    x0, p = synthetic_batch(cfg, world * B, **kw)
+    r = emu_solve(cfg, x0[rank * B:(rank + 1) * B], p[rank * B:(rank + 1) * B])          # weak scaling: B rows per rank, like bench.py
+    blk = sharding.pack_rows(torch.from_numpy(r["x"]), torch.from_numpy(r["status"]), torch.from_numpy(r["iters"]))
+    assert blk.shape == (B, sharding.packed_width(cfg.n_w))
+    out = torch.empty((world * B, blk.shape[1]), dtype=torch.float64)
+    w = sharding.gather_packed(blk, out, async_op=True)                                   # the form bench.py overlaps with the next solve
+    w.wait()
+    out2 = torch.empty_like(out)
+    assert sharding.gather_packed(blk, out2) is None and torch.equal(out, out2)           # ... and the synchronous one
+    stats = sharding.solve_stats_over_ranks(r["status"], r["iters"])
+    if rank == 1:                                                                          # every rank holds the whole result
+        x, st, it = sharding.unpack_rows(out, cfg.n_w)
+        np.savez(os.path.join(outdir, "packed.npz"), x=x.numpy(), status=st.numpy(), iters=it.numpy(), **stats)
+    dist.destroy_process_group()
+
+
+def test_two_rank_packed_gather_carries_status_and_iterations(tmp_path):
+    """SURVEY 8(e): the one collective of a step moves the result rows WITH their status and iteration counts (one padded block per rank);
+    the statistics of the bench line are reduced over the ranks"""
+    B, world = 16, 2
+    mp.spawn(_worker_packed, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(tmp_path / "packed.npz")
+    cfg, kw = FAMILIES["zamlf_n10_nx5"]
+    x0, p = synthetic_batch(cfg, world * B, **kw)
+    full = emu_solve(cfg, x0, p)
+    assert g["x"].shape == (world * B, cfg.n_w) and g["status"].dtype == np.int32
+    assert np.array_equal(g["status"], full["status"]) and np.array_equal(g["iters"], full["iters"])
+    assert np.abs(g["x"] - full["x"]).max() < 1e-12
+    assert int(g["rows"]) == world * B and abs(float(g["mean_iters"]) - full["iters"].mean()) < 1e-12
+    assert int(g["max_iters"]) == int(full["iters"].max()) and float(g["converged_frac"]) == 1.0
