@@ -762,3 +762,50 @@ def test_two_threads_per_stage_option(fam, B):
     else:
         assert np.all(r.status == 1) and r.kkt.max() <= 1e-8
         assert np.array_equal(r.iters[sub], ro["iters"]) and np.abs(r.x[sub] - ro["x"]).max() < TOL_ORACLE
+
+
+# ---- advisor round 3: the hand-off fence of the pipeline and the batch dependence of the hybrid solve ---------------------------------------
+
+@pytest.mark.parametrize("hybrid", ["1", "0"])
+def test_l1_only_acquire_equals_the_agent_scope_acquire(hybrid):
+    """consumer side of a hand-off inside the pipeline: `buffer_inv sc0` (this CU's vector L1 only -- producer and consumer of a tile share
+    an XCD, hence an L2; the default) against the agent-scope acquire of the memory model (option pipe_l2inv = 1).  The same bits over
+    repeated solves of two batch shapes, with and without the hand-over to k_solve_wg: a stale L1 line would show as a changed row."""
+    for fam, B in (("zamlf_n30_nx6", 4096), ("usalf_n50_nx5", 3000)):
+        cfg, kw = FAMILIES[fam]
+        x0, p = synthetic_batch(cfg, B, **kw)
+        s = make_solver(cfg)
+        s.set_option("hybrid", hybrid)
+        s.set_option("pipe_l2inv", "1")
+        ref = s.solve(x0, p)
+        assert s.get_pipeline_profile()["ran"] and np.all(ref.status == 1)
+        for rep in range(12):
+            s.set_option("pipe_l2inv", str(rep & 1))
+            r = s.solve(x0, p)
+            assert np.array_equal(r.x, ref.x) and np.array_equal(r.iters, ref.iters), (fam, rep)
+
+
+def test_hybrid_solve_keeps_the_basin_of_every_collision_avoidance_instance_under_permutation():
+    """the hybrid solve's KKT solver of an iteration depends on how many instances of the 64-instance tile still iterate (DESIGN.md section 4,
+    INTEGRATION.md "Reproducibility"): results depend on the batch composition at the 1e-9 level.  On the nonconvex family that must not
+    move an instance to the other side of the obstacle: a permuted batch returns, row for row, the same status and the same local optimum."""
+    B = 4096
+    x0, p = ca_batch(CA_CFG, B)
+    s = make_solver(CA_CFG)
+    set_cfg_bounds(s, CA_CFG)
+    s.set_option("rescue", "0")                       # (the second chance re-solves failed rows in sub-batches of their own)
+    a = s.solve(x0, p)
+    assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+    perm = np.random.default_rng(5).permutation(B)
+    b = s.solve(x0[perm], p[perm])
+    bx, bst = np.empty_like(b.x), np.empty_like(b.status)
+    bx[perm], bst[perm] = b.x, b.status
+    both = (a.status == 1) & (bst == 1)
+    assert np.mean(a.status == bst) >= 0.995 and both.mean() >= 0.97
+    assert np.abs(a.x[both] - bx[both]).max() < 1e-5          # same basin (the two basins of an instance differ by metres)
+    s.set_option("hybrid", "0")                       # the reproducible mode: bit-exact under permutation
+    c = s.solve(x0, p)
+    d = s.solve(x0[perm], p[perm])
+    dx = np.empty_like(d.x)
+    dx[perm] = d.x
+    assert np.array_equal(c.x, dx)
