@@ -138,7 +138,9 @@ struct WsLayout {
     size_t ielem(size_t row, size_t b) const { return (b >> 6) * itile_elems + mpc_prow((uint32_t)row) + (b & 63) * 2; }
 };
 
-inline WsLayout ws_layout(int N, int nx, size_t Bp) {
+// mailbox: with the instance-major copies k_solve_wg works on (about as large as the tile-major section: a handle that can never run
+// that kernel -- long horizons, a fixed iteration count, hybrid switched off -- does without them and fits twice the rows below 4 GiB)
+inline WsLayout ws_layout(int N, int nx, size_t Bp, bool mailbox = true) {
     const size_t NS = (size_t)nx * (nx + 1) / 2, S = N + 1;
     auto ev = [](size_t r) { return (r + 1) & ~(size_t)1; };                          // MPC_EV: whole row pairs per stage
     const size_t NZ = ev(nx + 2), XS = ev(nx), NBLK = ev((nx + 5) + 10 + 2 * nx), NPK = ev(NS + nx), NKK = 2 * nx + 2;   // Dim<NX>::NBLK: sparse H (NX + 5 entries)
@@ -156,18 +158,19 @@ inline WsLayout ws_layout(int N, int nx, size_t Bp) {
     w.itile_elems = w.irows * 64;
     w.ntiles = Bp / 64;
     w.total = w.ntiles * w.tile_elems;
-    w.MBLK = w.total; w.total += Bp * S * NBLK;
-    w.MPK = w.total; w.total += Bp * S * NPK;
-    w.MDZ = w.total; w.total += Bp * S * NZ;
-    w.MZ = w.total; w.total += Bp * S * NZ;
-    w.MZL = w.total; w.total += Bp * S * NZ;
-    w.MZU = w.total; w.total += Bp * S * NZ;
-    w.MSO = w.total; w.total += Bp * S * 4;
-    w.MNUO = w.total; w.total += Bp * S * 4;
-    w.MZLO = w.total; w.total += Bp * S * 4;
-    w.MZUO = w.total; w.total += Bp * S * 4;
-    w.MLAM = w.total; w.total += Bp * S * XS;
-    w.MREF = w.total; w.total += Bp * S * XS;
+    const size_t mb = mailbox ? Bp * S : 0;
+    w.MBLK = w.total; w.total += mb * NBLK;
+    w.MPK = w.total; w.total += mb * NPK;
+    w.MDZ = w.total; w.total += mb * NZ;
+    w.MZ = w.total; w.total += mb * NZ;
+    w.MZL = w.total; w.total += mb * NZ;
+    w.MZU = w.total; w.total += mb * NZ;
+    w.MSO = w.total; w.total += mb * 4;
+    w.MNUO = w.total; w.total += mb * 4;
+    w.MZLO = w.total; w.total += mb * 4;
+    w.MZUO = w.total; w.total += mb * 4;
+    w.MLAM = w.total; w.total += mb * XS;
+    w.MREF = w.total; w.total += mb * XS;
     w.itotal = w.ntiles * w.itile_elems;
     return w;
 }
@@ -179,9 +182,9 @@ inline int pick_bx(int N, int max_threads) {
 }
 
 inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int bx, double* base, int32_t* ibase,
-                        const double* dLB, const double* dUB) {
+                        const double* dLB, const double* dUB, bool mailbox = true) {
     const mpc_problem_desc& d = hp.desc;
-    const WsLayout w = ws_layout(d.N, d.nx, Bp);
+    const WsLayout w = ws_layout(d.N, d.nx, Bp, mailbox);
     P.B = B; P.Bp = (int32_t)Bp; P.N = d.N; P.nx = d.nx; P.bx = bx;
     P.obst_mult = d.obst_mult; P.max_iter = d.max_iter; P.fixed_iters = d.fixed_iters;
     P.has_fl = hp.has_fl; P.has_fu = hp.has_fu; P.has_ol = hp.has_ol; P.has_ou = hp.has_ou; P.per_inst_obst = 0;

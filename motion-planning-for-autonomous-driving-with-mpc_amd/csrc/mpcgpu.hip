@@ -1768,6 +1768,7 @@ struct mpc_handle {
     int device = 0;
     // device workspace
     size_t cap_Bp = 0;
+    bool ws_mailbox = false;            // the workspace carries the instance-major mailbox section (wants_mailbox at allocation time)
     double* d_ws = nullptr;
     int32_t* d_iws = nullptr;
     double *d_LB = nullptr, *d_UB = nullptr;
@@ -1924,7 +1925,7 @@ struct DevTmp {
 static void free_ws(mpc_handle* h) {
     if (h->d_ws) (void)hipFree(h->d_ws);
     if (h->d_iws) (void)hipFree(h->d_iws);
-    h->d_ws = nullptr; h->d_iws = nullptr; h->cap_Bp = 0;
+    h->d_ws = nullptr; h->d_iws = nullptr; h->cap_Bp = 0; h->ws_mailbox = false;
 }
 static void free_io(mpc_handle* h) {
     void* ptrs[] = {h->d_x0, h->d_p, h->d_xout, h->d_kkt, h->d_obst, h->d_status, h->d_iters};
@@ -2111,10 +2112,19 @@ int mpc_get_profile(const mpc_handle* h, double out[6]) {
 
 }  // extern "C"
 
+// can this handle, as its options stand, ever launch k_solve_wg (the only user of the instance-major mailbox section of the workspace)?
+static bool wants_mailbox(const mpc_handle* h) {
+    const mpc_problem_desc& d = h->hp.desc;
+    const mpc_handle::Knobs& kn = h->knobs;
+    const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
+    return small_wg && d.N + 1 <= 64 && (kn.resident != 0 || (kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled));
+}
 static int ensure_ws(mpc_handle* h, size_t Bp) {
-    if (Bp <= h->cap_Bp) return MPC_OK;
+    const bool mb = wants_mailbox(h);
+    if (Bp <= h->cap_Bp && (!mb || h->ws_mailbox)) return MPC_OK;
+    Bp = std::max(Bp, h->cap_Bp);                      // (grow only: also when all that changes is the mailbox section)
     free_ws(h);
-    const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp);
+    const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp, mb);
     if (w.total * sizeof(double) >= ((size_t)1 << 32)) {
         h->err = "batch too large: the workspace must stay below 4 GiB (32-bit buffer offsets); split the batch";
         return MPC_ERR_INVALID;
@@ -2122,6 +2132,7 @@ static int ensure_ws(mpc_handle* h, size_t Bp) {
     HIP_TRY(h, hipMalloc(&h->d_ws, w.total * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->d_iws, w.itotal * sizeof(int32_t)));
     h->cap_Bp = Bp;
+    h->ws_mailbox = mb;
     return MPC_OK;
 }
 
@@ -2187,11 +2198,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     // workgroup-resident solve with whole 8-instance workgroups (k_solve_wg, option resident): the stage phases of the streaming paths +
     // the wave-per-instance MFMA Riccati, no pipeline at all (the hybrid solve uses the same kernel with one wavefront per workgroup)
-    const bool use_wg = kn.resident != 0 && small_wg && !trace && !kn.stage_timing && kn.groups <= 0;
+    const bool use_wg = kn.resident != 0 && small_wg && h->ws_mailbox && !trace && !kn.stage_timing && kn.groups <= 0;
     Params P;
-    fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB);
+    fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB, h->ws_mailbox);
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
-    const WsLayout w = ws_layout(d.N, d.nx, Bp);
+    const WsLayout w = ws_layout(d.N, d.nx, Bp, h->ws_mailbox);
     Prof prof{h, stream};
     h->async_ok = false;
     if (d_obst) {
@@ -2351,7 +2362,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // instances costs 47 us against 33 us (B = 256: 0.58 -> 0.54 ms).  hybrid_bx = 1 / 2 pins it, 0 chooses.
     int hyb_bx = ((kn.hybrid_bx == 2 || (kn.hybrid_bx == 0 && B > 4 * h->n_cu)) && S * 2 <= 64) ? 2 : 1;
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
-    const bool hyb_ok = kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
+    const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
     if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
     const size_t lds_wg = wg_lds(bx);
@@ -2713,7 +2724,7 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
 // instances one solve can take: the workspace (tile-major section + mailbox arrays, both linear in the number of tiles) is addressed
 // with 32-bit buffer offsets
 static size_t max_rows_per_solve(const mpc_handle* h) {
-    const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64);
+    const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64, wants_mailbox(h));
     size_t max_b = (((size_t)1 << 32) - 1) / (w1.total * sizeof(double)) * 64;
     if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
     return max_b;

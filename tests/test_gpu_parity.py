@@ -809,3 +809,21 @@ def test_hybrid_solve_keeps_the_basin_of_every_collision_avoidance_instance_unde
     dx = np.empty_like(d.x)
     dx[perm] = d.x
     assert np.array_equal(c.x, dx)
+
+
+def test_workspace_gets_its_mailbox_section_only_when_k_solve_wg_can_run():
+    """advisor round 3: the instance-major mailbox arrays (as large as the tile-major section) are allocated for handles that can launch
+    k_solve_wg; switching the hybrid solve on later re-allocates, and either way the results are those of the oracle"""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 300, **kw)
+    ro = OracleSolver(cfg).solve_batch(x0[:32], p[:32], nthreads=8)
+    s = make_solver(cfg)
+    s.set_option("hybrid", "0")                       # before the first solve: no k_solve_wg on this handle, no mailbox
+    r0 = s.solve(x0, p)
+    assert not s.get_resident_profile()["ran"] and np.abs(r0.x[:32] - ro["x"]).max() < TOL_ORACLE
+    s.set_option("hybrid", "1")                       # now the kernel is wanted: the workspace grows its mailbox section
+    r1 = s.solve(x0, p)
+    assert s.get_resident_profile()["ran"] and np.array_equal(r1.iters, r0.iters) and np.abs(r1.x - r0.x).max() < 1e-9
+    s.set_option("hybrid", "0")
+    r2 = s.solve(x0, p)
+    assert np.array_equal(r2.x, r0.x)
