@@ -714,7 +714,15 @@ def test_wave_per_instance_kernel_options_agree(fam):
     for bx in ("1", "2"):
         s.set_option("hybrid_bx", bx)
         res.append(s.solve(x0, p))
-        assert s.get_resident_profile()["ran"] and not s.get_pipeline_profile()["ran"]
+        rp = s.get_resident_profile()
+        assert rp["ran"] and not s.get_pipeline_profile()["ran"]
+        if fam == "ca":
+            # the case the comparison is for: wavefronts whose two instances part ways -- one re-sweeps with an inertia correction
+            # (more sweeps than rounds) or gives up (-7) while its mate goes on
+            st = res[-1].status
+            assert rp["sweeps"] > rp["workgroup_rounds"] and (st == -7).any()
+            if bx == "2":
+                assert ((st[0::2] == -7) != (st[1::2] == -7)).any()
     s.set_option("hybrid", "0")
     s.set_option("resident", "1")
     res.append(s.solve(x0, p))
@@ -827,3 +835,16 @@ def test_workspace_gets_its_mailbox_section_only_when_k_solve_wg_can_run():
     s.set_option("hybrid", "0")
     r2 = s.solve(x0, p)
     assert np.array_equal(r2.x, r0.x)
+
+
+def test_mfma_riccati_unit_test_binary():
+    """tools/ubench/ric_mfma_test (built by __graft_entry__.build): the wave-per-instance MFMA sweeps of mpc_riccati_mfma.h against the scalar
+    recursion on random stage blocks, one and two instances per wavefront, convex and with an indefinite stage (inertia correction, the
+    mate re-swept or not) -- relative errors <= 1e-10, identical sweep counts"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "ric_mfma_test")
+    if not os.path.exists(exe):
+        pytest.fail("tools/ubench/ric_mfma_test is not built: run __graft_entry__.build()")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert "with an indefinite stage" in r.stdout and "mismatching sweep counts 0" in r.stdout

@@ -34,7 +34,7 @@ def main(path):
     for i, (_, n, d) in enumerate(seq):
         if n == "k_solve_wg<6>":
             j = i - 1
-            while j >= 0 and seq[j][1].startswith("__amd_rocclr_"):        # (a 16-byte fill of the statistics words sits between the two)
+            while j >= 0 and seq[j][1].startswith("__amd_rocclr_"):        # (runtime fills / copies between the two, if any, do not split a solve)
                 j -= 1
             prev = seq[j] if j >= 0 else None
             (behind if prev and prev[1] == "k_pipeline<6>" and (not split_pipe or prev[2] <= cut) else alone).append(d)
