@@ -11,23 +11,29 @@ nu = 2 kinematic-bicycle lane-following NLP (BASELINE.json `metric`), synthetic 
 SURVEY.md section 8(d) prescribes (tools/workloads.py), inputs and outputs resident in HBM (mpc_solve_batch_dev).
 Every instance is solved to the reference's IPOPT tolerance (tol 1e-8, max_iter 100): `value` counts converged NLP
 solves per second, whole job.  With N > 1 each rank solves its own B instances on its own GPU (weak scaling, instances
-are independent: no data-path collective) and the result rows of every step are all-gathered over RCCL, on RCCL's own
-stream while the next batch is being solved (the last gathers are waited for inside the timed region).
+are independent: no data-path collective) and ONE packed block per rank -- the result rows of the step with their status and
+iteration counts -- is all-gathered over RCCL, on RCCL's own stream while the next batch is being solved (`--gather overlap`, the
+default; the last gathers are waited for inside the timed region) or inside the step (`--gather sync`); the collective alone is timed
+too (`gather.gather_ms_alone`), and the statistics of the line are reduced over the ranks.
 
 `--gpus N` without a torch.distributed launcher (WORLD_SIZE unset) starts the N ranks itself and FAILS when fewer than N
 devices are visible; it never reports a smaller n_gpus than it was asked for.
 
-`--workload mixed` runs BASELINE configuration 5 instead (mixed scenario sweep: 4096 rows per GPU dealt over the three
-problem families, one handle per family, one padded all-gather at the end).
+`--workload mixed` runs BASELINE configuration 5 instead (mixed scenario sweep: 4096 rows per GPU dealt over the four
+problem families, one handle and one stream per family -- solved concurrently, collision avoidance first --, one packed
+all-gather at the end).
 
-Prints ONE JSON line on rank 0 (contract of the build driver) with extra objects:
+Prints ONE JSON line on rank 0 (contract of the build driver; compact: < 2000 characters, arrays where the long form has
+objects -- the long form goes to stderr as `[bench detail] {...}` and to `--detail FILE`) with extra objects:
   roofline      the iteration loop of a solve = ONE launch of k_pipeline (tiles with many instances iterating) followed by ONE launch
                 of k_solve_wg (the stragglers, one wavefront per two instances): algorithmic bytes of the instance-iterations
                 each performed / its mean launch duration (HIP events on the solve stream, a second, profiled pass over the
                 same K steps); `achieved` = bytes of both / duration of both, against the 8 TB/s HBM peak and against the
                 library's own streaming copy kernel; `kernels` has the two launches one by one; `traffic` = HBM bytes per
                 launch pair from rocprofv3 PMC passes run by this very process (FETCH_SIZE / WRITE_SIZE, gfx950 correction)
-  configs       BASELINE.json configurations 2, 3, 4 and one shard of 5 under the same clock (a few batches each)
+  configs       BASELINE.json configurations 2, 3, 4 and one shard of 5 under the same clock (a few batches each), one array per
+                configuration: [id, batch, ms per batch, steps/s, converged fraction, mean iterations, max iterations,
+                roofline fraction of the iteration loop, instances that took the second chance]
   cpu_baseline  the oracle (oracle/mpc_oracle.c, "port") on the host cores, bounded sample of the same workload;
                 plus a run-time probe for CasADi/IPOPT (the reference's own solver) on the host
 """
