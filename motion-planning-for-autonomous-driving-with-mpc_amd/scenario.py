@@ -215,7 +215,9 @@ def plan_route(scenario, planning_problem, step_resample=1.0, num_vertices_lane_
     (a lane change).  Reference path, as the route planner builds it: every lanelet contributes the portion [a, b] of its centre
     line (resampled to `step_resample`) -- [0, 1] normally, while the m lanelets of a run of lane changes share the stretch,
     [q/m, (q+1)/m] -- minus a few vertices on either side of every hand-over, so that the change of lane becomes a diagonal
-    instead of a jump; then 2 m resampling and one Chaikin refinement."""
+    instead of a jump; then 2 m resampling and FOUR Chaikin refinements (the route planner's own `chaikins_corner_cutting`, whose default
+    is `num_refinements = 4` -- not commonroad_dc's, whose default is 1: pinned by the recorded deviation.txt of the USA_Lanker run, which
+    this path reproduces to 1e-14, tests/test_scenario.py)."""
     lan = scenario.lanelets
     start = _lanelet_of_point(lan, planning_problem.initial_position)
     if planning_problem.goal_lanelets:
@@ -272,7 +274,7 @@ def plan_route(scenario, planning_problem, step_resample=1.0, num_vertices_lane_
             i1 = max(i1 - n_lc, 1)
         part = v[i0:i1]
         path = part if path is None else np.concatenate((path, part), axis=0)
-    return chaikins_corner_cutting(resample_polyline(path, 2.0)), ids
+    return chaikins_corner_cutting(resample_polyline(path, 2.0), refinements=4), ids
 
 
 # ----------------------------------------------------------------------------------------------------------------

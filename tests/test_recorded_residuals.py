@@ -28,9 +28,9 @@ What the data show (oracle and kernels alike):
     row reads a_0^2 >= c - 11.5: the feasible set of a_0 is TWO intervals, |a_0| >= 2.26, and the NLP has a local optimum on each.  IPOPT
     came from a braking warm start and returned -2.24 (noised); the loop's own warm start (its predicted a_1 is positive) leads to +2.26
     whatever the noise sample.  Re-solved from the recorded sign the residual is noise again.
-  * acceleration, USA_Lanker: median -0.054, 1.5 times the 3 sigma / sqrt(n) band -- steps 10..40, the lane-change stretch: the reference
-    path of this scenario is a reconstruction of an absent library's (row f2 is partial: recorded RMSD reproduced to +12 %), and its
-    arc-length distribution over the diagonal shows here.  Bounded at 0.08, not hidden.
+  * USA_Lanker: rounds 2 / 3 saw a bias of -0.054 in the acceleration residuals over the lane-change stretch and needed a widened band; it was
+    the reference PATH, not the solve: the route planner smooths with four Chaikin refinements, not one.  With the path that reproduces the
+    recorded deviation.txt / RMSD.txt to round-off (tests/test_scenario.py) both inputs pass the nominal band.
 
 The FORCES-mode twin (noise on the applied input only, optimizer.py:348-354) for both Hessian modes of the SQP step: see
 test_forcespro_recorded_runs_and_the_hessian_mode."""
@@ -184,8 +184,6 @@ def check_casadi_run(run, backend):
         med = float(np.median(r))
         mad = float(1.4826 * np.median(np.abs(r - med)))
         band = 3 * sigma / np.sqrt(len(r))
-        if (run, c) == ("usa_lf", 1):
-            band = 0.08                                                 # (reconstructed lane-change path, see the module docstring)
         assert abs(med) <= band, (run, name, med, band)
         # (the MAD estimate of sigma from n normal samples has a standard deviation of 1.17 sigma / sqrt(n): a two-sided 2-sd band)
         tol = 2 * 1.17 / np.sqrt(len(r))
@@ -315,8 +313,8 @@ def forces_residuals(run, mode, backend_factory):
 def check_forces(backend_factory):
     """What the recorded forcespro runs say about the SQP step here, for the exact Gauss-Newton Hessian (mode 0, the default) and the
     literal `bfgs_init = 2.5 I` of optimizer.py:234-237 (mode 1):
-      * mode 0 explains the STEERING channel of the lane-following runs up to a factor ~2 of the noise (MAD-sigma 0.18 / 0.25 against 0.1,
-        median within 0.1), mode 1 does not (median -0.36, MAD-sigma up to 0.44): the data pick mode 0 -- round 2's decision rested on
+      * mode 0 explains the STEERING channel of the lane-following runs up to a factor ~2.5 of the noise (MAD-sigma 0.18 / 0.27 against 0.1,
+        median within 0.11; on the exact reference paths of round 4), mode 1 does not (median -0.36, MAD-sigma up to 0.44): the data pick mode 0 -- round 2's decision rested on
         "the closed loop runs away with 2.5 I".
       * NEITHER mode explains the acceleration channel (rms of the residual 6 .. 16 m/s^2 against sigma = 0.1): at the recorded states, a
         few metres behind the reference points, one exact SQP step of the position-tracking cost asks for accelerations the closed binary
@@ -334,7 +332,7 @@ def check_forces(backend_factory):
             mad = 1.4826 * np.median(np.abs(r - med), axis=0)
             stats[(run, mode)] = dict(med=med, mad=mad, rms=np.sqrt((r ** 2).mean(axis=0)))
         a, b = stats[(run, 0)], stats[(run, 1)]
-        assert abs(a["med"][0]) <= 0.12 and a["mad"][0] <= 2.6 * sigma                  # steering: noise-like up to a factor ~2
+        assert abs(a["med"][0]) <= 0.12 and a["mad"][0] <= 2.8 * sigma                  # steering: noise-like up to a factor ~2.5
         assert abs(b["med"][0]) >= 0.3                                                    # the literal Hessian: biased by > 3 sigma
         assert np.all(a["rms"] < b["rms"])                                                # mode 0 is closer on both channels
         assert a["rms"][1] > 20 * sigma                                                   # ... and the acceleration is explained by neither
