@@ -173,7 +173,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
     c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
     c.bnd_ub = nb;
-    if (INIT) lds_barrier();                           // (the iteration kernel passes a barrier before its first use anyway)
+    if (INIT) lds_barrier();
     if (INIT) {
         Red0 r0;
         phase_init_point<NX>(P, c, r0);
@@ -185,7 +185,14 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         phase_preload<NX, MB>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
-        if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
+        // (the bounds table is read from here on: a block that has just copied it passes a barrier -- behind its loads, which are in flight;
+        //  a persistent stage worker that copied it for an earlier item has nothing to wait for)
+        if (!bounds_in_lds) lds_barrier();
+        // Block-wide "any" WITHOUT a barrier: every wavefront of the block holds a stage thread of EVERY instance column (thread t is stage
+        // t / bx of column t % bx, a wavefront covers 64 / bx consecutive stages, and the last wavefront starts at a stage <= N), and all
+        // stage threads of an instance hold the same flags (they come out of the block-wide reductions bit for bit) -- so the vote of one
+        // wavefront is the vote of the block.  Three barriers + LDS round trips less per work item.
+        if (!__any(c.active ? 1 : 0)) return;
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX>(P, c, r1);
@@ -195,7 +202,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         MPC_STAMP(4);
         double* stash = lds_x;                                 // shares the exchange region (each thread touches its own column only)
         if (STASH) stash_xfer<NX, true>(c, stash, blockDim.x, t, P.has_ou != 0);
-        while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
+        while (__any((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
             phase_trial_eval<NX>(P, c, r2);
             block_reduce(r2, bx, lds);
