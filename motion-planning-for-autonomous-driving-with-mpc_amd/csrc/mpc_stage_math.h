@@ -1791,8 +1791,15 @@ MPC_HD void ric_store_stage(const Params& P, uint32_t bb, int k, const double* P
     for (int i = 0; i < D::NS; ++i) pk[i] = Ps[i];
 #pragma unroll
     for (int i = 0; i < NX; ++i) pk[D::NS + i] = pv[i];
+    // (measurement aid, profiles/r04_riccati_chain.txt: -DMPC_RIC_STORE_VARIANT=1 stores the gains only, =2 nothing -- wrong results, the
+    //  time of the sweep without its stores; never defined in a product build)
+#if !defined(MPC_RIC_STORE_VARIANT) || MPC_RIC_STORE_VARIANT < 2
     ws_store_rows<D::NKK>(MPC_ROWS(MPC_UK(P.KK, D::NKK, k, e)), kk);
+#endif
+#if !defined(MPC_RIC_STORE_VARIANT) || MPC_RIC_STORE_VARIANT < 1
     ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, k, e)), pk);
+#endif
+    (void)kk; (void)pk;
 }
 
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
