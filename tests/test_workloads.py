@@ -111,3 +111,27 @@ def test_mixed_sweep_two_ranks_gloo(tmp_path):
         x0, p = wl.instance(fam, g)
         ref = emu_solve(_cfg_of(fam), x0[None], p[None])["x"][0]
         assert np.abs(got[g, : fam.n_w] - ref).max() < 1e-12 and np.all(got[g, fam.n_w:] == 0.0)
+
+
+def test_bench_line_is_compact_and_carries_the_contract():
+    """bench.py prints ONE line that fits the driver's 2000-character tail: every contract key, `roofline` (with the kernels of the loop one by
+    one) and `cpu_baseline` as objects, configurations 2 - 5 and the side paths as arrays (the long form goes to stderr)"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    long_form = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_detail_sample.json")))
+    line = bench.compact_line(long_form)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 2000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("N=30 nx=6") and "model" not in line["config"] and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    assert set(r["kernels"]) == {"k_pipeline", "k_solve_wg"} and all(len(v) == 3 for v in r["kernels"].values())
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert [c[0] for c in line["configs"]] == ["2", "3", "4", "5"] and all(len(c) == 9 for c in line["configs"])
+    assert len(line["fixed20"]) == 2 and "forces_sqp" in line["other_paths"]
