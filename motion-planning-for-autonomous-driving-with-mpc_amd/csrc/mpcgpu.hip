@@ -371,7 +371,7 @@ __device__ __forceinline__ void stage_pair(const Params& P, const int n_mult, co
 }
 
 template <int NX, bool INIT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
     // workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD gets a contiguous run of instance
