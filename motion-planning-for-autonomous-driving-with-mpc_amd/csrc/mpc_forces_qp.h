@@ -71,7 +71,9 @@ enum FqpRow {
 };
 // the rows the recursions hand from stage to stage, and the stage's RK4 Jacobian, live in LDS on the device: [row][thread],
 // the neighbouring stage of the same instance is IB threads away (on the host they are workspace rows like the others)
-enum FqLocal { FL_C = 0, FL_P = 35, FL_PV = 50, FL_DXIN = 55, FL_ROWS = 60 };
+// (round 4: the Jacobian of h -- 30 doubles per stage, constant during a solve and visited by every pass over the inequality rows, ~6 per
+//  interior-point iteration -- lives in LDS too: it was a fifth of the kernel's HBM traffic)
+enum FqLocal { FL_C = 0, FL_P = 35, FL_PV = 50, FL_DXIN = 55, FL_JHS = 60, FL_ROWS = 90 };
 constexpr int FQ_MI = 34;
 
 // Diagonal Hessian of the QP.  mode 0 (default): the exact Hessian of the reference's least-squares cost, 2 diag(R, Q) per
@@ -259,13 +261,13 @@ MPC_HD void fq_each_row(const ForcesQpArgs& A, const FqCtx& c, F f) {
         if (fq_row_on(A, k, 7 + i)) f(7 + i, 1, i, 0, 0, 1.0, 0.0, 0.0);
     }
     {
-        const double a = FQW(k, FQ_JHS + 0), b2 = FQW(k, FQ_JHS + 1), d = FQW(k, FQ_JHS + 2);
+        const double a = FQL(0, JHS, 0), b2 = FQL(0, JHS, 1), d = FQL(0, JHS, 2);
         if (fq_row_on(A, k, 14)) f(14, 3, 1, 4, 5, a, b2, d);
         if (fq_row_on(A, k, 24)) f(24, 3, 1, 4, 5, -a, -b2, -d);
     }
     FQ_UNROLL
     for (int j = 1; j < 10; ++j) {
-        const double a = FQW(k, FQ_JHS + 3 * j), b2 = FQW(k, FQ_JHS + 3 * j + 1), d = FQW(k, FQ_JHS + 3 * j + 2);
+        const double a = FQL(0, JHS, 3 * j), b2 = FQL(0, JHS, 3 * j + 1), d = FQL(0, JHS, 3 * j + 2);
         if (fq_row_on(A, k, 14 + j)) f(14 + j, 3, 2, 3, 6, a, b2, d);
         if (fq_row_on(A, k, 24 + j)) f(24 + j, 3, 2, 3, 6, -a, -b2, -d);
     }
@@ -288,9 +290,9 @@ MPC_HD void fq_build(const ForcesQpArgs& A, FqCtx& c, FqRed& part) {
     double gs = 1.0;
     FQ_UNROLL
     for (int i = 0; i < 7; ++i) { FQW(k, FQ_G + i) = gf[i]; FQW(k, FQ_W + i) = 0.0; gs = fmax(gs, fabs(gf[i])); }
-    FQW(k, FQ_JHS + 0) = jh[1]; FQW(k, FQ_JHS + 1) = jh[4]; FQW(k, FQ_JHS + 2) = jh[5];
+    FQL(0, JHS, 0) = jh[1]; FQL(0, JHS, 1) = jh[4]; FQL(0, JHS, 2) = jh[5];
     FQ_UNROLL
-    for (int j = 1; j < 10; ++j) { FQW(k, FQ_JHS + 3 * j) = jh[j * 7 + 2]; FQW(k, FQ_JHS + 3 * j + 1) = jh[j * 7 + 3]; FQW(k, FQ_JHS + 3 * j + 2) = jh[j * 7 + 6]; }
+    for (int j = 1; j < 10; ++j) { FQL(0, JHS, 3 * j) = jh[j * 7 + 2]; FQL(0, JHS, 3 * j + 1) = jh[j * 7 + 3]; FQL(0, JHS, 3 * j + 2) = jh[j * 7 + 6]; }
     if (!term) {
         FQ_UNROLL
         for (int i = 0; i < 35; ++i) FQL(0, C, i) = jc[i];

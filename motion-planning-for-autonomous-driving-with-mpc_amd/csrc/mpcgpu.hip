@@ -3119,7 +3119,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     const mpc_problem_desc& d = h->hp.desc;
     if (d.nx != 5) { h->err = "the FORCES formulation has 5 states (z = [deltaDot, aLong, x, y, delta, v, psi])"; return MPC_ERR_INVALID; }
     // (k_forces_qp holds all stages of an instance in one workgroup of at most 256 threads, one thread per stage)
-    if (d.N > 256) { h->err = "forces solve: horizons above 256 stages are not supported (one thread per stage, 256 threads per workgroup)"; return MPC_ERR_INVALID; }
+    if (d.N > 192) { h->err = "forces solve: horizons above 192 stages are not supported (one thread per stage, 192 threads per workgroup: their stage rows live in LDS)"; return MPC_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     const int N = d.N;
     const size_t nB = (size_t)B, Bp = (nB + 63) / 64 * 64;
@@ -3140,11 +3140,15 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
     for (int i = 0; i < 7; ++i) { A.lb[i] = lb[i]; A.ub[i] = ub[i]; }
     for (int i = 0; i < 10; ++i) { A.hl[i] = hl[i]; A.hu[i] = hu[i]; }
     A.zbar = d_x0; A.params = d_all_parameters; A.xinit = d_xinit; A.z_out = d_x_out; A.iters = dit; A.status = dflag; A.kkt = dres; A.ws = dws; A.ws_bytes = (uint32_t)((size_t)FQ_ROWS * N * Bp * 8);
+    // instances per workgroup: all N stages of IB instances in one workgroup whose LDS rows ([4 + FL_ROWS][threads] doubles: the RK4 Jacobian,
+    // cost-to-go, hand-over rows and the Jacobian of h) fit a CU: at most 192 threads
+    constexpr int FQ_MAX_THREADS = 192;
     int IB = 1;
-    while (IB * 2 * N <= 256 && IB < 64) IB *= 2;                       // instances per workgroup: all N stages of IB instances in <= 256 threads
+    while (((IB * 2 * N + 63) / 64) * 64 <= FQ_MAX_THREADS && IB < 64) IB *= 2;
     const int threads = ((IB * N + 63) / 64) * 64;
+    if ((size_t)(4 + FL_ROWS) * threads * sizeof(double) > 160 * 1024 - 1024) { h->err = "forces solve: the horizon is too long for the stage rows of one instance in LDS"; return MPC_ERR_INVALID; }
     if (!h->attr_set_fq) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forces_qp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + FL_ROWS) * 256 * sizeof(double))));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_forces_qp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 1024)));
         h->attr_set_fq = true;
     }
     hipLaunchKernelGGL(k_forces_qp, dim3((B + IB - 1) / IB), dim3(threads), (size_t)(4 + FL_ROWS) * threads * sizeof(double), s, A, IB);
