@@ -1220,8 +1220,12 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
 }
 
 template <int NX>
-__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if, uint32_t* fail_count) {
+// zero_p / zero_n: the pipeline's OTHER control block, zeroed here for the next solve (the two blocks alternate: a solve in steady state has
+// no fill of its own in front of its persistent launch)
+__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if, uint32_t* fail_count, uint32_t* zero_p, const uint32_t zero_n) {
     __shared__ double tile[64][65];
+    if (zero_p != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
+        for (uint32_t q = threadIdx.x; q < zero_n; q += 256u) zero_p[q] = 0u;
     if (skip_if != nullptr && *skip_if != 0u) return;        // abandoned pipeline launch: the host starts over, the caller's buffers stay untouched
     const int N = P.N, nw = 2 * N + NX * (N + 1);
     const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
@@ -1784,7 +1788,10 @@ struct mpc_handle {
     double* d_state = nullptr;         // [B,5] plant state of the closed-loop driver
     size_t cap_state = 0;
     size_t tile_mask_cap = 0;
-    uint32_t* d_pipe = nullptr;        // control block of the single-launch pipeline (k_pipeline)
+    uint32_t* d_pipe = nullptr;        // control blocks of the single-launch pipeline (k_pipeline): two halves of pipe_words words that alternate --
+                                       // the output kernel of a solve zeroes the other half for the next one
+    int pipe_flip = 0;
+    size_t pipe_clean[2] = {0, 0};     // leading words of each half known to be zero
     size_t pipe_words = 0;
     uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (24 words)
     bool pipe_disabled = false;        // set when a pipeline launch had to be abandoned (see k_pipeline)
@@ -2390,7 +2397,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         launch_wg(wg_only ? hyb_bx : bx, nullptr, h->d_fail + 2);
         prof.end(stream);
         prof.begin(2, stream);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail, (uint32_t*)nullptr, 0u);
         prof.end(stream);
         h->last_mode = 2;
         if (h->async_loop) {             // closed-loop driver: nothing comes back to the host per step (this path has no abort word)
@@ -2458,12 +2465,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (h->pipe_words < words) {
                 if (h->d_pipe) (void)hipFree(h->d_pipe);
                 h->d_pipe = nullptr; h->pipe_words = 0;
-                HIP_TRY(h, hipMalloc(&h->d_pipe, words * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc(&h->d_pipe, 2 * words * sizeof(uint32_t)));
                 h->pipe_words = words;
+                h->pipe_clean[0] = h->pipe_clean[1] = 0;
             }
             if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 24 * sizeof(uint32_t)));
-            A.ctl = h->d_pipe;
-            HIP_TRY(h, hipMemsetAsync(h->d_pipe, 0, words * sizeof(uint32_t), stream));
+            uint32_t* const ctl = h->d_pipe + (size_t)h->pipe_flip * h->pipe_words;
+            uint32_t* const ctl_next = h->d_pipe + (size_t)(h->pipe_flip ^ 1) * h->pipe_words;
+            A.ctl = ctl;
+            if (h->pipe_clean[h->pipe_flip] < words) HIP_TRY(h, hipMemsetAsync(ctl, 0, words * sizeof(uint32_t), stream));      // (first use, or a larger batch than the last)
+            h->pipe_clean[h->pipe_flip] = 0;
             unsigned long long* d_pdbg = nullptr;
             if (kn.pipe_timing) {
                 HIP_TRY(h, hipMalloc(&t_pdbg.p, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
@@ -2477,7 +2488,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
                 prof.begin(5, stream);
-                launch_wg(hyb_bx, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_pipe + PIPE_WG);
+                launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
                 prof.end(stream);
             }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
@@ -2485,19 +2496,21 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.begin(2, stream);
             // (instances that did not converge are counted into word 14 of the control block, which travels back with the abort word;
             //  an asynchronous closed loop accumulates them over its steps in d_fail instead)
-            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(h->d_pipe + PIPE_ABORT),
-                               h->async_loop ? h->d_fail : h->d_pipe + PIPE_ABORT + 14);
+            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT),
+                               h->async_loop ? h->d_fail : ctl + PIPE_ABORT + 14, ctl_next, (uint32_t)words);
+            h->pipe_clean[h->pipe_flip ^ 1] = words;
+            h->pipe_flip ^= 1;
             prof.end(stream);
             if (h->async_loop) {
                 // closed-loop driver: nothing comes back to the host per step -- a launch that had to be abandoned leaves its mark
                 // in the loop's sticky abort word, the bookkeeping kernels behind it then do nothing and the host replays the loop
-                hipLaunchKernelGGL(k_loop_sticky, dim3(1), dim3(1), 0, stream, (const uint32_t*)(h->d_pipe + PIPE_ABORT), h->d_fail + 1);
+                hipLaunchKernelGGL(k_loop_sticky, dim3(1), dim3(1), 0, stream, (const uint32_t*)(ctl + PIPE_ABORT), h->d_fail + 1);
                 HIP_TRY(h, hipGetLastError());
                 h->async_ok = true;
                 h->last_mode = 1;
                 return MPC_OK;
             }
-            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, h->d_pipe + PIPE_ABORT, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, ctl + PIPE_ABORT, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
             for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
@@ -2655,7 +2668,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Params Pg = P;
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg, (const uint32_t*)nullptr, h->d_fail);
+        hipLaunchKernelGGL((k_egest<NX>), dim3(q.ntl, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, q.st, Pg, (const uint32_t*)nullptr, h->d_fail, (uint32_t*)nullptr, 0u);
         prof.end(q.st);
         if (G > 1) {
             HIP_TRY(h, hipEventRecord(h->ev_join[g], q.st));
