@@ -1064,8 +1064,7 @@ __global__ void __launch_bounds__(128) k_prestart(const Params P) {
 // three short scans x_{k+1} = push_in(x_k + dt f_k) per state, run by the first two stage-threads of every instance from increments
 // parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
 template <int NX>
-__global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__device__ __forceinline__ void prestart_par_block(const Params& P, const uint32_t b0, double* sm) {
     constexpr int NZ = NX + 2;
     const int N = P.N, S = N + 1, bx = P.bx, t = threadIdx.x, bl = t & (bx - 1);
     const int nb = S * NZ, SB = S * bx;
@@ -1078,7 +1077,7 @@ __global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
     double* A0 = IN + 2 * SB;               // [3][bx]      a0lb, a0ub, defect of the guess
     struct { int b, k; } c;
     c.k = t / bx;
-    c.b = (int)((blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx) + bl;
+    c.b = (int)b0 + bl;
     const bool valid = c.k <= N && c.b < P.B;
     const uint32_t bb = (uint32_t)c.b;
     for (int q = t; q < nb; q += (int)blockDim.x) { LBt[q] = MPC_GP(P.LB, q); UBt[q] = MPC_GP(P.UB, q); }
@@ -1173,6 +1172,28 @@ __global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
     if (valid && c.k == 0) prestart_decide<NX>(P, c.b, frow, a0lb, a0ub, A0[2 * bx + bl], th);
 #undef PP_AT
 }
+template <int NX>
+__global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    prestart_par_block<NX>(P, (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx, sm);
+}
+// start-point safeguard + start iterate of a block of bx instances in ONE launch (the two have the same thread mapping; what the first
+// leaves in the workspace -- rollout, per-instance bounds of a_0, the verdict -- comes back from this CU's own write-through L1 / the L2)
+template <int NX>
+__global__ void __launch_bounds__(256, 2) k_start(const Params P, const int n_mult, const int n_z, const int stash_rows) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int or_slots[2][8];
+    uint32_t blk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
+    prestart_par_block<NX>(P, b0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_ingest / k_egest: LDS-tiled transposes between the caller's row-major [B][n_w] buffers (optimizer.py:550 order)
@@ -1829,7 +1850,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1866,6 +1887,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
+    else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
     else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
@@ -1893,13 +1915,14 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
     else if (n == "pair") *out = k.pair;
+    else if (n == "fuse_start") *out = k.fuse_start;
     else if (n == "friction_lb") *out = k.friction_lb;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2243,6 +2266,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (!h->attr_set) {        // per handle: the attribute belongs to the function object of the handle's device
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_start<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -2305,11 +2329,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
         // stage-threads the scans need (otherwise the two-chain kernel)
         const size_t lds_pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx) * sizeof(double);
-        if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
-            hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
-        else
-            hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
-        launch_stage(q, true);
+        if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start) {
+            // (one launch for the safeguard and the start iterate: same blocks, same threads)
+            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_pre, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+        } else {
+            if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
+                hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
+            else
+                hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
+            launch_stage(q, true);
+        }
         prof.end(q.st);
     }
 

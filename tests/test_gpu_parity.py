@@ -848,3 +848,27 @@ def test_mfma_riccati_unit_test_binary():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert "with an indefinite stage" in r.stdout and "mismatching sweep counts 0" in r.stdout
+
+
+@pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n10_nx5", "usalf_n50_nx5", "ca"])
+def test_fused_start_kernel_equals_the_two_launches(fam):
+    """start-point safeguard + start iterate in one launch (k_start, the default) against the two kernels (option fuse_start = 0): the
+    same bits, also from the reference's transposed step-0 guess, where the safeguard replaces the state guess by its rollout"""
+    if fam == "ca":
+        cfg = CA_CFG
+        x0, p = ca_batch(cfg, 300)
+    else:
+        cfg, kw = FAMILIES[fam]
+        x0, p = synthetic_batch(cfg, 300, **kw)
+    x0 = x0.copy()
+    N, nx = cfg.N, cfg.nx
+    x0[::3, 2 * N:] = x0[::3, 2 * N:].reshape(-1, N + 1, nx).transpose(0, 2, 1).reshape(100, -1)     # every third row: states in the transposed layout
+    s = make_solver(cfg)
+    if fam == "ca":
+        set_cfg_bounds(s, cfg)
+    assert s.get_option("fuse_start") == 1
+    a = s.solve(x0, p)
+    s.set_option("fuse_start", "0")
+    b = s.solve(x0, p)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters) and np.array_equal(a.status, b.status)
+    assert (a.status == 1).mean() > 0.9
