@@ -1177,7 +1177,7 @@ __global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     prestart_par_block<NX>(P, (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx, sm);
 }
-// start-point safeguard + start iterate of a block of bx instances in ONE launch (the two have the same thread mapping; what the first
+// ingest + start-point safeguard + start iterate of a block of bx instances in ONE launch (the three have the same thread mapping; what one
 // leaves in the workspace -- rollout, per-instance bounds of a_0, the verdict -- comes back from this CU's own write-through L1 / the L2)
 template <int NX>
 __global__ void __launch_bounds__(256, 2) k_start(const Params P, const int n_mult, const int n_z, const int stash_rows) {
@@ -1186,6 +1186,37 @@ __global__ void __launch_bounds__(256, 2) k_start(const Params P, const int n_mu
     uint32_t blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
+    {
+        // ---- the caller's rows of this block (x0, the X_ref part of p: row-major [B][n_w]) -> LDS -> the tile-major Z / REF rows of the
+        //      workspace: what k_ingest does for a whole batch, here for the block's own bx instances (consecutive rows: coalesced reads)
+        constexpr int NZ = NX + 2;
+        const int N = P.N, nw = 2 * N + NX * (N + 1), bx = P.bx, t = threadIdx.x;
+        double* rx = lds;                        // [bx][nw]
+        double* rp = lds + bx * nw;              // [bx][nw - 2N]   (the U_ref part of p is not used by the NLP, optimizer.py:507-511)
+        const int nrow = ((int)b0 + bx <= P.B) ? bx : (P.B > (int)b0 ? P.B - (int)b0 : 0);
+        for (int q = t; q < nrow * nw; q += (int)blockDim.x) rx[q] = MPC_GP(P.x0, (size_t)b0 * nw + q);
+        const int npx = nw - 2 * N;
+        for (int q = t; q < nrow * npx; q += (int)blockDim.x) rp[q] = MPC_GP(P.p, ((size_t)b0 + q / npx) * nw + 2 * N + q % npx);
+        __syncthreads();
+        struct { int b, k; } c;
+        c.k = t / bx;
+        const int bl = t & (bx - 1);
+        c.b = (int)b0 + bl;
+        if (c.k <= N && c.b < P.B) {
+            double z[NZ], r[NX];
+            const double* xr = rx + bl * nw;
+            z[0] = (c.k < N) ? xr[2 * c.k] : 0.0;
+            z[1] = (c.k < N) ? xr[2 * c.k + 1] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { z[2 + i] = xr[2 * N + NX * c.k + i]; r[i] = rp[bl * npx + NX * c.k + i]; }
+            ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), z);
+            ws_store_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 0, e)), r);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     prestart_par_block<NX>(P, b0, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2325,13 +2356,15 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Pg.tile0 = q.tile0;
         prof.begin(2, q.st);
         const int n_w = 2 * d.N + NX * (d.N + 1);
-        hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
         // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
         // stage-threads the scans need (otherwise the two-chain kernel)
         const size_t lds_pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx) * sizeof(double);
-        if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start) {
-            // (one launch for the safeguard and the start iterate: same blocks, same threads)
-            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_pre, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+        const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
+        const bool fused = lds_pre <= 64 * 1024 && lds_in <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
+        if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
+        if (fused) {
+            // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
+            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(std::max(lds_pre, lds_init), lds_in), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
             if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
                 hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
