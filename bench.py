@@ -493,19 +493,17 @@ def main():
         osol = OracleSolver(NLPConfig(N=fam.N, nx=fam.nx, Q=fam.Q, R=fam.R))
         avail = HOST_CPUS
         xs, ps = x0[:4096], p[:4096]
-        best = None
-        for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances; keep the best count
-            osol.solve_batch(xs, ps, nthreads=cores)                      # warm the thread team of this size (threads are bound to cores:
-            t = 1e30                                                      # the first call with a new count also places them)
-            for _ in range(2):
+        sweep = {}
+        for rnd in range(2):                                              # two passes over the thread counts: the first also places the threads
+            for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances, threads bound to cores
+                osol.solve_batch(xs, ps, nthreads=cores)                  # (a team of a new size is created and placed here)
                 t0 = time.perf_counter()
                 ro = osol.solve_batch(xs, ps, nthreads=cores)
-                t = min(t, time.perf_counter() - t0)
-            if best is None or t < best[1]:
-                best = (cores, t)
-        cores = best[0]
+                t = time.perf_counter() - t0
+                sweep[cores] = min(sweep.get(cores, 1e30), t)
+        cores = min(sweep, key=sweep.get)
         osol.solve_batch(xs, ps, nthreads=cores)                            # (back to the chosen team)
-        reps = max(1, int(round(3.0 / best[1])))                            # ~3 s wall on the chosen thread count
+        reps = max(1, int(round(3.0 / sweep[cores])))                       # ~3 s wall on the chosen thread count
         t0 = time.perf_counter()
         for _ in range(reps):
             ro = osol.solve_batch(xs, ps, nthreads=cores)
@@ -513,14 +511,8 @@ def main():
         t0 = time.perf_counter()
         osol.solve_batch(xs[:1024], ps[:1024], nthreads=1)
         t_one = time.perf_counter() - t0
-        # one FIXED thread count beside the best of the sweep (comparable between boxes: threads bound to cores, OMP_PROC_BIND=close)
         n32 = min(32, avail)
-        osol.solve_batch(xs, ps, nthreads=n32)
-        t_32 = 1e30
-        for _ in range(3):
-            t0 = time.perf_counter()
-            osol.solve_batch(xs, ps, nthreads=n32)
-            t_32 = min(t_32, time.perf_counter() - t0)
+        t_32 = sweep.get(n32, 1e30)
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as fh:
@@ -533,6 +525,7 @@ def main():
                             sample_short=f"{reps}x{len(xs)} instances, oracle C port, OpenMP bound to cores",
                             single_thread_value=1024 / t_one, bound_32_threads_value=len(xs) / t_32, bound_threads=n32,
                             omp_proc_bind=os.environ.get("OMP_PROC_BIND"), cpu_model=model, host_cpus=avail,
+                            sweep_steps_per_s={str(c): len(xs) / t for c, t in sorted(sweep.items())},
                             casadi_ipopt=casadi_probe(fam, x0, p, wl), published_casadi_ipopt=PUBLISHED_CASADI)
 
     # ---- BASELINE.json configurations 2 - 5 under the same clock (single-GPU run only; a few batches each, ~1 s in total)
