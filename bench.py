@@ -279,8 +279,11 @@ def main():
     # (the cpu_baseline leg: OpenMP threads of the oracle pinned to cores, close to each other -- an unbound run moved 2.7x between boxes)
     global HOST_CPUS
     HOST_CPUS = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)     # (before the OpenMP runtime binds this thread)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # (single-rank runs only -- the one place the cpu_baseline leg runs: with a binding policy set, the OpenMP runtime also pins the
+        #  MAIN thread to the first place, and the main threads of eight ranks would share one core)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
     import torch
     import torch.distributed as dist
     import mpc_amd
