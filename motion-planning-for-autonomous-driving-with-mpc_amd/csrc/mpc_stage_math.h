@@ -1536,15 +1536,15 @@ MPC_HD void phase_eval_red_b(bool active, Red3& red, const KktPart& kp) {
 }
 
 // (one thread per (instance, stage): the three pieces back to back, one sincos for all)
-template <int NX, bool REUSE = false, bool MB = false>
+template <int NX, bool REUSE = false, bool MB = false, uint32_t VM = 0xFFu>
 MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
     IneqOut<NX> xo;
     KktPart kp;
     EvalTmp<NX> t;
     const Trig tg = psi_trig(c.z[2 + 4]);
-    phase_ineq_assemble<NX, REUSE>(P, c, xo, kp, tg);
-    phase_eval_model<NX, REUSE, ROLE_ALL, true>(P, c, t, kp, tg);
-    phase_eval_finish<NX, MB, ROLE_ALL>(P, c, red, xo, t);
+    phase_ineq_assemble<NX, REUSE, IneqOut<NX>, ROLE_ALL, VM>(P, c, xo, kp, tg);
+    phase_eval_model<NX, REUSE, ROLE_ALL, true, VM>(P, c, t, kp, tg);
+    phase_eval_finish<NX, MB, ROLE_ALL, IneqOut<NX>, VM>(P, c, red, xo, t);
 }
 
 // =========================================================================================================

@@ -121,12 +121,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int NX> struct Stash {
     __host__ __device__ static constexpr int rows(bool has_ou) { return 4 * (NX + 2) + 2 * 3 + (has_ou ? 2 * 3 : 0) + 3 + 2 * NX; }
 };
-template <int NX, bool OUT>
+template <int NX, bool OUT, uint32_t VM = 0xFFu>
 __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t, bool has_ou) {
     int r = 0;
 #define MPC_ST(v) do { if (OUT) st[r * T + t] = (v); else (v) = st[r * T + t]; ++r; } while (0)
+    // (VM: variables without a bound at any stage keep their compile-time zeros in registers -- nothing to park)
 #pragma unroll
-    for (int i = 0; i < NX + 2; ++i) { MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); MPC_ST(c.igl[i]); MPC_ST(c.igu[i]); }
+    for (int i = 0; i < NX + 2; ++i) { if (!((VM >> i) & 1u)) continue; MPC_ST(c.zl[i]); MPC_ST(c.zu[i]); MPC_ST(c.igl[i]); MPC_ST(c.igu[i]); }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { MPC_ST(c.zlo[j]); MPC_ST(c.iglo[j]); }
     if (has_ou) {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
-template <int NX, bool INIT, int MAXT, bool MB = false>
+template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu>
 __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
                                             uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
@@ -182,7 +183,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        phase_preload<NX, MB>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
+        phase_preload<NX, MB, ROLE_ALL, VM>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         // (the bounds table is read from here on: a block that has just copied it passes a barrier -- behind its loads, which are in flight;
@@ -195,22 +196,22 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         if (!__any(c.active ? 1 : 0)) return;
         MPC_STAMP(2);
         Red1 r1;
-        phase_step_candidates<NX>(P, c, r1);
+        phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
         MPC_STAMP(3);
         block_reduce(r1, bx, lds);
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
         double* stash = lds_x;                                 // shares the exchange region (each thread touches its own column only)
-        if (STASH) stash_xfer<NX, true>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (STASH) stash_xfer<NX, true, VM>(c, stash, blockDim.x, t, P.has_ou != 0);
         while (__any((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
-            phase_trial_eval<NX>(P, c, r2);
+            phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
-        if (STASH) stash_xfer<NX, false>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (STASH) stash_xfer<NX, false, VM>(c, stash, blockDim.x, t, P.has_ou != 0);
         MPC_STAMP(5);
-        phase_apply_update<NX, MB>(P, c);
+        phase_apply_update<NX, MB, ROLE_ALL, VM>(P, c);
         MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
@@ -228,7 +229,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
     }
     MPC_STAMP(7);
     Red3 r3;
-    phase_eval_assemble<NX, !INIT, MB>(P, c, r3);
+    phase_eval_assemble<NX, !INIT, MB, VM>(P, c, r3);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
@@ -697,8 +698,11 @@ __global__ void k_xcd_census(uint32_t* mask) {
 }
 
 // PAIR: the stage workers run two threads per (instance, stage) (stage_pair: 512-thread workgroups, two wavefronts per SIMD)
-template <int NX, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 512 : 256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+// VAR: 0 one thread per (instance, stage), bounds looked up at run time; 1 two threads per (instance, stage) (stage_pair); 2 one thread per
+// stage with the bound structure of the reference compiled in (PAIR_VM: only steering rate, acceleration, steering angle and speed carry
+// bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
+template <int NX, int VAR>
+__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -820,8 +824,8 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) k_pipeline(const Params P, c
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-        if (PAIR) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        if (VAR == 1) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
+        else stage_block<NX, false, 256, false, VAR == 2 ? PAIR_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
@@ -862,8 +866,8 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) k_pipeline(const Params P, c
 // PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
 // of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
 // wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
-template <int NX, bool PAIR>
-__global__ void __launch_bounds__(PAIR ? 512 : 256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
+template <int NX, int VAR>
+__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -1010,8 +1014,8 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) k_solve_wg(const Params P, c
         WG_STAMP(14);
         // ---- the stage work of the round
         if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
-        if (PAIR) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256, true>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
+        if (VAR == 1) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
+        else stage_block<NX, false, 256, true, VAR == 2 ? PAIR_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1881,7 +1885,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1919,6 +1923,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
     else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
     else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
+    else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
     else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
@@ -1947,13 +1952,14 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "hybrid_live") *out = k.hybrid_live;
     else if (n == "pair") *out = k.pair;
     else if (n == "fuse_start") *out = k.fuse_start;
+    else if (n == "bound_mask") *out = k.bound_mask;
     else if (n == "friction_lb") *out = k.friction_lb;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2305,6 +2311,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
         }
     }
@@ -2415,6 +2423,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
     // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
     const bool pair_vm_ok = ((P.lo_mask | P.hi_mask) & ~PAIR_VM) == 0u;        // the pair kernels are compiled for the reference's bound structure
+    // one thread per stage with the reference's bound structure compiled in (option bound_mask, default on): same arithmetic, same bits
+    const bool masked = kn.bound_mask != 0 && pair_vm_ok;
     auto wg_pair = [&](int bxw) { return kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
     auto wg_lds = [&](int bxw) {
         const int thr = ((S * bxw + 63) / 64) * 64;
@@ -2429,6 +2439,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         Pw.bx = bxw;
         const int thr = ((S * bxw + 63) / 64) * 64;
         if (wg_pair(bxw)) hipLaunchKernelGGL((k_solve_wg<NX, true>), dim3((B + bxw - 1) / bxw), dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
+        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
         else hipLaunchKernelGGL((k_solve_wg<NX, false>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
@@ -2546,6 +2557,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             }
             prof.begin(3, stream);
             if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
