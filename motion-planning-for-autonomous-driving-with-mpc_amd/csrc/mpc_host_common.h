@@ -198,10 +198,15 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.dec_s = 0;                      // set after the masks below
     P.tile_mask = nullptr;
     P.lo_mask = P.hi_mask = 0;
+    P.dense_mask = 0xFFFFu;
     for (size_t q = 0; q < hp.LB.size(); ++q) {
-        const int i = (int)(q % (size_t)hp.NZ());
+        const int i = (int)(q % (size_t)hp.NZ()), k = (int)(q / (size_t)hp.NZ());
         if (hp.LB[q] > -1e300) P.lo_mask |= 1u << i;
         if (hp.UB[q] < 1e300) P.hi_mask |= 1u << i;
+        if (!(i < 2 && k == d.N)) {                                  // (the inputs of the terminal stage do not exist)
+            if (!(hp.LB[q] > -1e300)) P.dense_mask &= ~(1u << i);
+            if (!(hp.UB[q] < 1e300)) P.dense_mask &= ~(0x100u << i);
+        }
     }
     P.dec_s = (d.nx == 6 && d.Q[5] == 0.0 && !((P.lo_mask | P.hi_mask) & (1u << 7))) ? 1 : 0;
     P.x0 = nullptr; P.p = nullptr; P.LB = dLB; P.UB = dUB;

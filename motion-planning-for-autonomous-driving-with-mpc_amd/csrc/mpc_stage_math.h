@@ -92,6 +92,7 @@ struct Params {
     unsigned long long* tile_mask;   // [tiles] bit l: instance l of the tile was iterating when the last Riccati launch started (stage workgroups with no such instance leave before touching HBM)
     int32_t* run_counter;        // device counter of this launch: += instances still iterating after it (nullptr: none)
     uint32_t inv_S;              // ceil(2^32 / (N+1)): segment -> (row, stage) split of the LDS prefetch
+    uint32_t dense_mask;         // bit i / bit 8 + i: variable i of (u, x) has its lower / upper bound at every stage it exists at
     uint32_t lo_mask, hi_mask;   // bit i: variable i of (u, x) has a finite lower / upper bound at SOME stage (multiplier rows of the others never move)
     const double* x0;            // [B][n_w] row-major (ABI input)
     const double* p;             // [B][n_w] row-major (ABI input)
@@ -435,6 +436,18 @@ constexpr int ROLE_ALL = 0, ROLE_A = 1, ROLE_B = 2;
 // dynamics on A.  VM: compile-time mask of the variables that have a bound at SOME stage (0xFF: not known -- every side is looked up
 // in the bounds table at run time); the kernels of the pair are instantiated for the mask of the reference's bounds, where the sides
 // of x, y, psi (and the progress state) vanish from the code together with their registers.
+// Upper bits of VM: more of the reference's structure compiled in (the host checks the handle before it picks such an instantiation)
+//   VM_OSPEC  circle-distance rows with a lower bound only, multiplicity 3, one obstacle for the whole batch (optimizer.py:395-403, 426-428)
+//   bits 16-23 / 24-31: variables whose LOWER / UPPER bound is there at every stage the variable exists at (optimizer.py:421-491): no
+//             presence test of that side (the acceleration has an upper bound only -- and a per-instance lower one at stage 0, from the
+//             presolved friction row: its lower side keeps the run-time test)
+constexpr uint32_t VM_OSPEC = 0x100u;
+MPC_HD constexpr uint32_t vm_dense(uint32_t lo, uint32_t hi) { return (lo << 16) | (hi << 24); }
+#define MPC_HAS_OL ((VM & VM_OSPEC) ? true : (P.has_ol != 0))
+#define MPC_HAS_OU ((VM & VM_OSPEC) ? false : (P.has_ou != 0))
+#define MPC_OMULT ((VM & VM_OSPEC) ? 3 : P.obst_mult)
+#define MPC_HAS_LO(lb_) (((VM >> (16 + i)) & 1u) ? true : has_lo(lb_))
+#define MPC_HAS_HI(ub_) (((VM >> (24 + i)) & 1u) ? true : has_hi(ub_))
 template <int ROLE, uint32_t VM>
 MPC_HD constexpr bool side_mine(int i) { return ((VM >> i) & 1u) != 0u && (ROLE == ROLE_ALL || (ROLE == ROLE_A) == (i < 2)); }
 // Rows of the hand-over: 3 i + {0, 1, 2} = (sum z/gap, barrier-gradient factor, -zl + zu) of variable i; behind them the circle rows'
@@ -553,10 +566,10 @@ MPC_HD double friction_eval(const Params& P, double a, double dl, double v, doub
     return fabs(y);
 }
 
-template <int NX>
+template <int NX, bool BATCH_WIDE = false>
 MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c.obst[i] = P.per_inst_obst ? MPC_S(P.OBST, i) : P.obst[i];
+    for (int i = 0; i < 6; ++i) c.obst[i] = (!BATCH_WIDE && P.per_inst_obst) ? (double)MPC_S(P.OBST, i) : P.obst[i];
 }
 
 // =========================================================================================================
@@ -859,7 +872,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
-    if (MPC_RB) load_obst(P, c);
+    if (MPC_RB) load_obst<NX, (VM & 0x100u) != 0u>(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
     if (MB) ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 0, e)), c.dz); else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
@@ -901,8 +914,8 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     if (MPC_RB) {
         ws_load_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
         ws_load_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
-        if (P.has_ol) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
-        if (P.has_ou) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
+        if (MPC_HAS_OL) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
+        if (MPC_HAS_OU) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
     }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
@@ -957,7 +970,7 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
     constexpr int NZ = D::NZ;
     red = red_neutral1();
     if (!c.active) return;
-    const int N = P.N, k = c.k, m = P.obst_mult;
+    const int N = P.N, k = c.k, m = MPC_OMULT;
     const double mu = c.mu, tau = c.tau;
     double dphi = 0.0;
     StepSel sel;
@@ -973,8 +986,8 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         double gb = 0.0;
         if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
-            if (has_lo(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
-            if (has_hi(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
+            if (MPC_HAS_LO(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
+            if (MPC_HAS_HI(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
         }
         dphi += (gradf + gb) * dv;
     }
@@ -983,8 +996,8 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
         const double s = c.so[j], ds = c.dso[j];
         double gb = 0.0;
         c.iglo[j] = c.iguo[j] = 0.0;
-        if (MPC_RB && P.has_ol) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
-        if (MPC_RB && P.has_ou) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
+        if (MPC_RB && MPC_HAS_OL) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
+        if (MPC_RB && MPC_HAS_OU) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
         if (MPC_RB) dphi += m * gb * ds;
     }
     if (MPC_RA && k == 0 && c.fric_row) {
@@ -1040,7 +1053,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
     constexpr int NZ = D::NZ;
     red = red_neutral2();
     if (!(c.active && c.searching)) return;
-    const int N = P.N, k = c.k, m = P.obst_mult;
+    const int N = P.N, k = c.k, m = MPC_OMULT;
     const double al = c.alpha;
     double theta = 0.0, fc = 0.0, gp = 1.0, bad = 0.0;      // gp: product of all gaps; sum of logs = log(gp), one log per thread
     double zt[NZ];                                          // the trial point (the update phase forms the accepted one again)
@@ -1052,8 +1065,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
         if (isu && k == N) continue;
         if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
-            if (has_lo(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
-            if (has_hi(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
+            if (MPC_HAS_LO(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
+            if (MPC_HAS_HI(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
         }
         if (MPC_RA && k < N) {
             if (isu) fc += P.R[i] * v * v;
@@ -1082,8 +1095,8 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
             const double dist = circle_eval(P, c.obst, j, zt[2], zt[3], tg.sps, tg.cps, nullptr, nullptr, false);
             const double s = c.so[j] + al * c.dso[j];
             theta += m * fabs(dist - s);
-            if (P.has_ol) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
-            if (P.has_ou) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+            if (MPC_HAS_OL) { const double gap = s - P.ol; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
+            if (MPC_HAS_OU) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
         }
     }
     if (MPC_RA && k == 0 && c.fric_row) {
@@ -1152,8 +1165,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         const double zi = c.z[i], dv = c.dz[i], zn = zi + al * dv;       // (the accepted trial point, formed again)
         if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
-            if (has_lo(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
-            if (has_hi(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
+            if (MPC_HAS_LO(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
+            if (MPC_HAS_HI(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
         }
         (void)zi;
         c.z[i] = zn;
@@ -1182,13 +1195,13 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
-        if (MPC_RB && P.has_ol) {
+        if (MPC_RB && MPC_HAS_OL) {
             const double ig = c.iglo[j], ign = 1.0 / (sn - P.ol);
             sg += c.zlo[j] * ig; gb -= mu * ig;
             c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
             c.iglo[j] = ign;
         }
-        if (MPC_RB && P.has_ou) {
+        if (MPC_RB && MPC_HAS_OU) {
             const double ig = c.iguo[j], ign = 1.0 / (P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
             c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
@@ -1198,8 +1211,8 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         if (MPC_RB) { c.nuo[j] += al * (gb - c.nuo[j] + sg * ds); c.so[j] = sn; }
     }
     if (MPC_RB) {
-        if (P.has_ol) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
-        if (P.has_ou) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
+        if (MPC_HAS_OL) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
+        if (MPC_HAS_OU) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
         ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
         ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
     }
@@ -1267,7 +1280,7 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
     constexpr int NZ = D::NZ;
     kp = kkt_part_neutral();
     if (!c.active) return;
-    const int N = P.N, k = c.k, m = P.obst_mult;
+    const int N = P.N, k = c.k, m = MPC_OMULT;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         if (!side_mine<ROLE, VM>(i)) continue;            // (rows of the other thread's / of absent sides are never read either)
@@ -1276,8 +1289,8 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
         if (!(isu && k == N)) {
             MPC_BOUNDS(k, i, lb, ub);
             const double zi = c.z[i];
-            if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
-            if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
         }
         xo.put(3 * i + IR::SG, sg); xo.put(3 * i + IR::GBB, gbb); xo.put(3 * i + IR::RZ, rz);
     }
@@ -1288,8 +1301,8 @@ MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& k
         const double dist = circle_eval(P, c.obst, j, c.z[2], c.z[3], tg.sps, tg.cps, J, Ho, true);
         const double s = c.so[j], nu = c.nuo[j];
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_ol) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
-        if (P.has_ou) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (MPC_HAS_OL) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (MPC_HAS_OU) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
         kp.dual = fmax(kp.dual, fabs(rs));
         const double res = dist - s;
         kp.theta += m * fabs(res);
@@ -1329,7 +1342,7 @@ MPC_HD void phase_eval_model(const Params& P, Ctx<NX>& c, EvalTmp<NX>& t, const 
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
     if (!c.active) return;
-    const int N = P.N, k = c.k, m = P.obst_mult;
+    const int N = P.N, k = c.k, m = MPC_OMULT;
     const double dt = P.dt, df = c.df;
     const double* x = c.z + 2;
     const double* u = c.z;
@@ -1419,8 +1432,8 @@ MPC_HD void phase_eval_model(const Params& P, Ctx<NX>& c, EvalTmp<NX>& t, const 
             MPC_BOUNDS(k, i, lb, ub);
             const double zi = c.z[i];
             double sg = 0.0, gbb = 0.0, rz = 0.0;
-            if (has_lo(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-            if (has_hi(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
             ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz;
         }
     }

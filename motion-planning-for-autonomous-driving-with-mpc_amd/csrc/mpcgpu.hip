@@ -141,6 +141,16 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 #undef MPC_ST
 }
 
+// the variables that carry bounds in the reference's NLP (optimizer.py:421-491: steering rate, acceleration, steering angle, speed):
+// the pair kernels are instantiated for this mask (a handle whose bounds touch other variables runs one thread per stage)
+constexpr uint32_t PAIR_VM = 0x33u;
+// variant 2 of k_pipeline / k_solve_wg: that mask, the bounds of its variables at every stage, circle rows with a lower bound only and
+// multiplicity 3, one obstacle per batch -- the structure of every NLP the reference builds
+constexpr uint32_t REF_DENSE_LO = 0x31u, REF_DENSE_HI = 0x33u;      // (no lower bound on the acceleration)
+#ifndef MPC_REF_FLAGS
+#define MPC_REF_FLAGS (VM_OSPEC | vm_dense(REF_DENSE_LO, REF_DENSE_HI))
+#endif
+constexpr uint32_t REF_VM = PAIR_VM | MPC_REF_FLAGS;
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
@@ -149,7 +159,10 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
                                             uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
     int or_parity = 0;
-    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
+    // (the workgroup-resident kernel with the compiled-in bound structure fits the register file without the stash: -650 instructions,
+    //  -490 of them scalar-register reloads, k_solve_wg 304 -> 295 us on the headline batch; neutral in the pipeline's stage workers)
+    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH && !(MB && VM != 0xFFu);
+    const bool has_ou = (VM & VM_OSPEC) ? false : (P.has_ou != 0);     // (what the stash parks)
     Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
@@ -202,14 +215,14 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
         phase_linesearch_begin<NX>(P, c, r1);
         MPC_STAMP(4);
         double* stash = lds_x;                                 // shares the exchange region (each thread touches its own column only)
-        if (STASH) stash_xfer<NX, true, VM>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (STASH) stash_xfer<NX, true, VM>(c, stash, blockDim.x, t, has_ou);
         while (__any((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
             phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
-        if (STASH) stash_xfer<NX, false, VM>(c, stash, blockDim.x, t, P.has_ou != 0);
+        if (STASH) stash_xfer<NX, false, VM>(c, stash, blockDim.x, t, has_ou);
         MPC_STAMP(5);
         phase_apply_update<NX, MB, ROLE_ALL, VM>(P, c);
         MPC_STAMP(6);
@@ -261,9 +274,6 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
 // LDS (doubles): [reduction scratch (waves x 10 x bx) | bounds table 2 nb | neighbour exchange 2 NX x T | IneqOut (3 NZ + 15) x T]
 // ---------------------------------------------------------------------------------------------------------------
 template <int NX> __host__ __device__ constexpr int pair_rows() { return 2 * NX + 3 * (NX + 2) + 15; }
-// the variables that carry bounds in the reference's NLP (optimizer.py:421-491: steering rate, acceleration, steering angle, speed):
-// the pair kernels are instantiated for this mask (a handle whose bounds touch other variables runs one thread per stage)
-constexpr uint32_t PAIR_VM = 0x33u;
 template <int NX, bool MB, int ROLE>
 __device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
                                                 double* lds, int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
@@ -371,7 +381,9 @@ __device__ __forceinline__ void stage_pair(const Params& P, const int n_mult, co
     else stage_pair_role<NX, MB, ROLE_B>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
 }
 
-template <int NX, bool INIT, int MAXT>
+// VM: bound structure compiled into the phases (0xFF: looked up at run time; REF_VM: the reference's -- every path of a handle uses the
+// same instantiation of the phases, so that the pipeline, its fallback of one launch per kernel and the closed loop's replay give the same bits)
+template <int NX, bool INIT, int MAXT, uint32_t VM = 0xFFu>
 __global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -382,7 +394,7 @@ __global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(c
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
     // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
     const unsigned long long bits = (!INIT && P.tile_mask != nullptr) ? P.tile_mask[b0 >> 6] : ~0ull;
-    stage_block<NX, INIT, MAXT>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
+    stage_block<NX, INIT, MAXT, false, VM>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -825,7 +837,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
         if (VAR == 1) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256, false, VAR == 2 ? PAIR_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        else stage_block<NX, false, 256, false, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
@@ -1015,7 +1027,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
         // ---- the stage work of the round
         if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
         if (VAR == 1) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256, true, VAR == 2 ? PAIR_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
+        else stage_block<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2311,6 +2323,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
@@ -2329,6 +2343,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (G < 1) G = 1;
         if (G > mpc_handle::MAX_GROUPS) G = mpc_handle::MAX_GROUPS;
     }
+    const bool pair_vm_ok = ((P.lo_mask | P.hi_mask) & ~PAIR_VM) == 0u;        // the pair kernels are compiled for the reference's bound structure
+    // one thread per stage with the reference's bound structure compiled in (option bound_mask, default on): same arithmetic, same bits
+    const bool masked = kn.bound_mask != 0 && pair_vm_ok && (P.dense_mask & REF_DENSE_LO) == REF_DENSE_LO && ((P.dense_mask >> 8) & REF_DENSE_HI) == REF_DENSE_HI && P.has_ol && !P.has_ou && P.obst_mult == 3 && !P.per_inst_obst;
     struct Group { int tile0, ntl, blk0, nblk, b0, b1; hipStream_t st; bool running; };
     Group grp[mpc_handle::MAX_GROUPS];
     for (int g = 0; g < G; ++g) {
@@ -2351,9 +2368,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (!init && stage_timing && P.DBG) Pg.DBG = P.DBG;
         if (small_wg) {
             if (init) hipLaunchKernelGGL((k_stage<NX, true, 256>), dim3(q.nblk), dim3(threads), lds_init, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (masked) hipLaunchKernelGGL((k_stage<NX, false, 256, REF_VM>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_stage<NX, false, 256>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
             if (init) hipLaunchKernelGGL((k_stage<NX, true, 512>), dim3(q.nblk), dim3(threads), lds_init, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (masked) hipLaunchKernelGGL((k_stage<NX, false, 512, REF_VM>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
@@ -2422,9 +2441,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
     // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
-    const bool pair_vm_ok = ((P.lo_mask | P.hi_mask) & ~PAIR_VM) == 0u;        // the pair kernels are compiled for the reference's bound structure
-    // one thread per stage with the reference's bound structure compiled in (option bound_mask, default on): same arithmetic, same bits
-    const bool masked = kn.bound_mask != 0 && pair_vm_ok;
     auto wg_pair = [&](int bxw) { return kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
     auto wg_lds = [&](int bxw) {
         const int thr = ((S * bxw + 63) / 64) * 64;

@@ -101,6 +101,34 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
         assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+@pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5"])
+def test_compiled_in_bound_structure_against_the_run_time_lookup(fam):
+    """Variant 2 of the kernels (option bound_mask, the default whenever the handle's bounds have the reference's structure: only steering
+    rate, acceleration, steering angle and speed bounded, circle rows with a lower bound only and multiplicity 3) compiles that structure
+    into the stage phases; variant 0 looks every side up at run time.  Same algorithm, different instruction streams (the compiler
+    contracts a few expressions differently): same iteration counts and statuses, |dx| at round-off level, both against the oracle --
+    and the specialised phases give the same bits on every path of a handle (pipeline, hybrid off, one launch per kernel)."""
+    cfg, kw = FAMILIES[fam]
+    x0, p = synthetic_batch(cfg, 700, **kw)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    assert s.get_option("bound_mask") == 1
+    a = s.solve(x0, p)
+    s.set_option("hybrid", "0")
+    a_pipe = s.solve(x0, p)
+    s.set_option("pipeline", "0")
+    a_launch = s.solve(x0, p)
+    assert _same(a_pipe, a_launch)
+    s.set_option("pipeline", "1")
+    s.set_option("hybrid", "1")
+    s.set_option("bound_mask", "0")
+    b = s.solve(x0, p)
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters) and np.all(a.status == 1)
+    assert np.max(np.abs(a.x - b.x)) < 1e-9 and np.max(np.abs(a_pipe.x - b.x)) < 1e-9
+    ro = OracleSolver(cfg).solve_batch(x0[:64], p[:64], nthreads=8)
+    assert np.array_equal(a.iters[:64], ro["iters"]) and np.max(np.abs(a.x[:64] - ro["x"])) < TOL_ORACLE
+
+
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5", "ca", "transposed"])
 def test_stage_parallel_start_point_safeguard_equals_the_two_chain_kernel(fam):
     """k_prestart_par (one thread per instance and stage, three short scans) against k_prestart (two sequential 30-stage chains per
@@ -306,8 +334,12 @@ def test_collision_avoidance_batch():
     for b in np.nonzero(~same)[0][:4]:
         cert = kkt_certificate(nlp, r.x[b], p[b])
         assert cert["stationarity"] <= 1e-6 and cert["feasibility"] <= 1e-6, (b, cert)
+    # the same obstacle handed over per instance: variant 0 of the kernels (bounds and obstacle looked up at run time) against variant 2 --
+    # two instruction streams of one algorithm; bit for bit when the batch-wide solve is put on variant 0 too
     per = s.solve(x0[:32], p[:32], obst=np.tile(CA_CFG.obstacle_centers.ravel(), (32, 1)))
-    assert np.array_equal(per.x, r.x[:32])
+    assert np.all(per.status == 1) and np.max(np.abs(per.x - r.x[:32])) < 1e-6
+    s.set_option("bound_mask", "0")
+    assert np.array_equal(per.x, s.solve(x0[:32], p[:32]).x)
 
 
 def test_fixed_iteration_mode_matches_converged():
