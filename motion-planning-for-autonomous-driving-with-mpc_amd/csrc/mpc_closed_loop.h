@@ -105,7 +105,7 @@ MPC_HD void loop_setup_instance(const LoopArgs& A, int b) {
 }
 
 // after solve i: record, plant step, shift, next warm start and reference
-MPC_HD void loop_advance_instance(const Params& P, const LoopArgs& A, int b, int i) {
+MPC_HD void loop_advance_instance(const PRef& P, const LoopArgs& A, int b, int i) {
     const int N = A.N, nx = A.nx, nw = 2 * N + nx * (N + 1);
     const double* xo = A.x_out + (size_t)b * nw;
     double cur[6], u[2], f[6], s, c, td;

@@ -195,13 +195,13 @@ __device__ __forceinline__ double wv_sum_hi(double v) {
 //   Gt rows come down from rows 2, 3 of the first of them (v_permlane32_swap) already replicated over hi, so Kt = -Lam^-1 Gt is the B
 //   operand of the rank-2 update as it stands and Gt' needs ONE bank move
 template <int NX, int NI>
-__device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
+__device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
                                               int lane, mpc_lds_ptr dump, double (&delta)[NI], bool (&ok)[NI], uint32_t& sweeps) {
     using RC = Rec<NX>;
     using D = Dim<NX>;
     const int N = P.N;
     const double dt = P.dt, dt2 = dt * dt;
-    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = P.rws;
     constexpr uint32_t PKS = MPC_EV(D::NPK) * 8u;                         // bytes per stage of the mailbox PK rows
     const uint32_t pk_arr = (uint32_t)(uintptr_t)P.MPK - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
     const uint32_t pk_lane = m.pk_row >= 0 ? (uint32_t)m.pk_row * 8u + (uint32_t)N * PKS : 0u, pk_inc = m.pk_row >= 0 ? PKS : 0u;
@@ -372,12 +372,12 @@ __device__ __forceinline__ void mfma_backward(const Params& P, const MfmaLane<NX
 // hi by a DPP row rotation.  x0[q]: B-operand register, lane (x, hi, *, 0) = x~_0[4 hi + x] (the affine coordinate 7 holds 1), zero for y != 0.
 // Lanes without an entry to store write row 0 of the unused KK array (no divergent store).
 template <int NX, int NI>
-__device__ __forceinline__ void mfma_forward(const Params& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
+__device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
                                              const double (&x0)[NI], const bool (&ok)[NI]) {
     using D = Dim<NX>;
     using RC = Rec<NX>;
     const int N = P.N;
-    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = P.rws;
     constexpr uint32_t DZS = MPC_EV(D::NZ) * 8u;                           // bytes per stage of the mailbox DZ rows
     const bool st = m.dz_row >= 0;
     const uint32_t dz_arr = (uint32_t)(uintptr_t)P.MDZ - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;

@@ -155,30 +155,38 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mpc_rsrc(const void* base, uin
     return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ int mpc_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane((int)v); }
+// What device code sees as "the parameters": the kernel's by-value Params plus the two buffer descriptors, built ONCE at the top of the
+// kernel.  (Before, every access site rebuilt its descriptor from the base pointer and the size -- values the register allocator had
+// spilled with the rest of their kernel-argument tuple: k_solve_wg reloaded those eight words at 46 places, four v_readlane + three
+// s_mov + one s_and per site.)
+struct DevParams : Params {
+    __amdgpu_buffer_rsrc_t rws, riws;
+    __device__ __forceinline__ explicit DevParams(const Params& q) : Params(q), rws(mpc_rsrc(q.WS, q.ws_bytes)), riws(mpc_rsrc(q.IWS, q.iws_bytes)) {}
+};
+typedef DevParams PRef;
 struct WsRefD {          // element of the double workspace: converts to double (load) / assigns from double (store)
-    const Params& P;
+    const PRef& P;
     uint32_t aoff, uoff, voff;     // array offset (uniform), uniform row offset, per-lane offset; bytes
     __device__ __forceinline__ operator double() const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.WS, P.ws_bytes);
+        const __amdgpu_buffer_rsrc_t r = P.rws;
         const mpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, mpc_uni(aoff + uoff), 0);
         return __builtin_bit_cast(double, v);
     }
     __device__ __forceinline__ double operator=(double x) const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.WS, P.ws_bytes);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, mpc_uni(aoff + uoff), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), P.rws, (int)voff, mpc_uni(aoff + uoff), 0);
         return x;
     }
     __device__ __forceinline__ double operator=(const WsRefD& o) const { return (*this = (double)o); }
 };
 struct WsRefI {          // element of the int32 workspace
-    const Params& P;
+    const PRef& P;
     uint32_t soff, voff;
     __device__ __forceinline__ operator int32_t() const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.IWS, P.iws_bytes);
+        const __amdgpu_buffer_rsrc_t r = P.riws;
         return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, mpc_uni(soff), 0);
     }
     __device__ __forceinline__ int32_t operator=(int32_t x) const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(P.IWS, P.iws_bytes);
+        const __amdgpu_buffer_rsrc_t r = P.riws;
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)x, r, (int)voff, mpc_uni(soff), 0);
         return x;
     }
@@ -186,7 +194,7 @@ struct WsRefI {          // element of the int32 workspace
 // rows e (even) and e + 1 of one instance in ONE 16-byte access; `r` refers to row e
 typedef unsigned int mpc_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ws_load2(const WsRefD& r, double& lo, double& hi) {
-    const __amdgpu_buffer_rsrc_t d = mpc_rsrc(r.P.WS, r.P.ws_bytes);
+    const __amdgpu_buffer_rsrc_t d = r.P.rws;
     const mpc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(d, (int)r.voff, mpc_uni(r.aoff + r.uoff), 0);
     lo = __builtin_bit_cast(double, mpc_v2u{v.x, v.y});
     hi = __builtin_bit_cast(double, mpc_v2u{v.z, v.w});
@@ -198,17 +206,20 @@ __device__ __forceinline__ void ws_load2(const WsRefD& r, double& lo, double& hi
 // older ISA manuals, which exempt the SGPR-soffset form) -- with an SGPR soffset it scheduled `v_add_u32 v18, ...`
 // directly behind `buffer_store_dwordx4 v[18:21], ...`.
 __device__ __forceinline__ void ws_store2(const WsRefD& r, double lo, double hi) {
-    const __amdgpu_buffer_rsrc_t d = mpc_rsrc(r.P.WS, r.P.ws_bytes);
+    const __amdgpu_buffer_rsrc_t d = r.P.rws;
     const mpc_v2u a = __builtin_bit_cast(mpc_v2u, lo), b = __builtin_bit_cast(mpc_v2u, hi);
     __builtin_amdgcn_raw_buffer_store_b128(mpc_v4u{a.x, a.y, b.x, b.y}, d, (int)(r.voff + (uint32_t)mpc_uni(r.aoff + r.uoff)), 0, 0);
 }
 #define MPC_LD2(ref, lo, hi) ws_load2((ref), (lo), (hi))
 #define MPC_ST2(ref, lo, hi) ws_store2((ref), (lo), (hi))
+// keeps two 8-byte stores of neighbouring rows apart (all accesses share ONE descriptor value, so the compiler merges such a pair into
+// a 16-byte store with an SGPR soffset -- the form whose data-register hazard it does not guard; tools/check_store_hazard.py looks for it)
+#define MPC_STORE_FENCE() asm volatile("" ::: "memory")
 // uni: uniform element offset (-> scalar/immediate offset), b: instance, extra: further per-lane elements
-__device__ __forceinline__ WsRefD ws_ref3(const Params& P, const double* arr, uint32_t uni, uint32_t b, uint32_t extra) {
+__device__ __forceinline__ WsRefD ws_ref3(const PRef& P, const double* arr, uint32_t uni, uint32_t b, uint32_t extra) {
     return WsRefD{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.WS, uni * 8u, ((b >> 6) * P.tile_elems + (b & 63u) * 2u + extra) * 8u};
 }
-__device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, uint32_t uni, uint32_t b, uint32_t extra) {
+__device__ __forceinline__ WsRefI ws_ref3(const PRef& P, const int32_t* arr, uint32_t uni, uint32_t b, uint32_t extra) {
     return WsRefI{P, (uint32_t)(uintptr_t)arr - (uint32_t)(uintptr_t)P.IWS + uni * 4u, ((b >> 6) * P.itile_elems + (b & 63u) * 2u + extra) * 4u};
 }
 // accessors: (array, uniform element offset -> SGPR soffset / immediate, per-lane element offset -> VGPR voffset)
@@ -228,6 +239,7 @@ __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, u
 #define MPC_KM(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, ((uint32_t)(dk) * MPC_EV(R) + (uint32_t)(e)) * 8u, \
                                      (((uint32_t)c.b * (uint32_t)(P.N + 1) + (uint32_t)c.k) * MPC_EV(R)) * 8u}
 #else
+typedef Params PRef;
 #define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
@@ -238,6 +250,7 @@ __device__ __forceinline__ WsRefI ws_ref3(const Params& P, const int32_t* arr, u
 // (the two rows of a pair are adjacent doubles)
 #define MPC_LD2(ref, lo, hi) do { const double* p2_ = &(ref); (lo) = p2_[0]; (hi) = p2_[1]; } while (0)
 #define MPC_ST2(ref, lo, hi) do { double* p2_ = &(ref); p2_[0] = (lo); p2_[1] = (hi); } while (0)
+#define MPC_STORE_FENCE() do { } while (0)
 #endif
 //   MPC_KX(ARR, R, dk, e) array ARR of the iterate: the instance-major mailbox copy MARR where the phase is instantiated with MB (the
 //                         workgroup-resident path), the tile-major array otherwise
@@ -567,7 +580,7 @@ MPC_HD double friction_eval(const Params& P, double a, double dl, double v, doub
 }
 
 template <int NX, bool BATCH_WIDE = false>
-MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
+MPC_HD void load_obst(const PRef& P, Ctx<NX>& c) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.obst[i] = (!BATCH_WIDE && P.per_inst_obst) ? (double)MPC_S(P.OBST, i) : P.obst[i];
 }
@@ -583,7 +596,7 @@ MPC_HD void load_obst(const Params& P, Ctx<NX>& c) {
 // =========================================================================================================
 // caller rows -> workspace (what the LDS-tiled k_ingest kernel does on the GPU): Z <- x0 (raw), REF <- X_ref part of p
 template <int NX>
-MPC_HD void ingest_instance(const Params& P, int b) {
+MPC_HD void ingest_instance(const PRef& P, int b) {
     constexpr int NZ = NX + 2;
     const int N = P.N;
     const uint32_t bb = (uint32_t)b;
@@ -607,7 +620,7 @@ MPC_HD void ingest_instance(const Params& P, int b) {
 // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
 // start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
 template <int NX>
-MPC_HD int prestart_a0(const Params& P, int b, double& a0lb, double& a0ub) {
+MPC_HD int prestart_a0(const PRef& P, int b, double& a0lb, double& a0ub) {
     const uint32_t bb = (uint32_t)b;
     a0lb = MPC_GP(P.LB, 1);
     a0ub = MPC_GP(P.UB, 1);
@@ -630,7 +643,7 @@ MPC_HD int prestart_a0(const Params& P, int b, double& a0lb, double& a0ub) {
 //   ROLLOUT = false: returns the dynamics defect of the caller's state guess
 // The loads of stage k+1 are issued before the arithmetic of stage k (the chain is otherwise load-latency bound).
 template <int NX, bool ROLLOUT>
-MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub, mpc_lds_cptr bnd) {
+MPC_HD double prestart_chain(const PRef& P, int b, double a0lb, double a0ub, mpc_lds_cptr bnd) {
     // bnd: LDS copy of the bounds table [LB | UB] on the device (a global load per stage would expose its latency in
     // the dependent chain), nullptr on the host
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -692,7 +705,7 @@ MPC_HD double prestart_chain(const Params& P, int b, double a0lb, double a0ub, m
 #undef PS_UB
 }
 template <int NX>
-MPC_HD void prestart_decide(const Params& P, int b, int frow, double a0lb, double a0ub, double th_g, double th_r) {
+MPC_HD void prestart_decide(const PRef& P, int b, int frow, double a0lb, double a0ub, double th_g, double th_r) {
     const uint32_t bb = (uint32_t)b;
     MPC_U(P.SC, (uint32_t)SC_A0LB) = a0lb;
     MPC_U(P.SC, (uint32_t)SC_A0UB) = a0ub;
@@ -701,7 +714,7 @@ MPC_HD void prestart_decide(const Params& P, int b, int frow, double a0lb, doubl
     MPC_U(P.ISC, (uint32_t)IS_ROLL) = use ? 1 : 0;
 }
 template <int NX>
-MPC_HD void prestart_instance(const Params& P, int b) {
+MPC_HD void prestart_instance(const PRef& P, int b) {
     // the caller's rows were transposed into the workspace by the ingest kernel: Z holds the raw x0, REF holds X_ref
     double a0lb, a0ub;
     const int frow = prestart_a0<NX>(P, b, a0lb, a0ub);
@@ -717,7 +730,7 @@ MPC_HD void prestart_instance(const Params& P, int b) {
 // Phase 0 (init kernel only): build the start iterate from the caller's x0 (IPOPT section 3.6)
 // =========================================================================================================
 template <int NX>
-MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
+MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     red = red_neutral0();
@@ -803,7 +816,7 @@ MPC_HD void phase_init_point(const Params& P, Ctx<NX>& c, Red0& red) {
 }
 
 template <int NX>
-MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
+MPC_HD void phase_init_scalars(const PRef& P, Ctx<NX>& c, const Red0& red) {
     if (!c.valid) return;
     c.df = red.gmax > SCALING_MAX_GRAD ? SCALING_MAX_GRAD / red.gmax : 1.0;
     c.mu = MU_INIT;
@@ -836,7 +849,7 @@ MPC_HD void phase_init_scalars(const Params& P, Ctx<NX>& c, const Red0& red) {
 // Phase 1: load the Newton step, slack/dual steps, fraction-to-the-boundary candidates, d(phi)
 // =========================================================================================================
 template <int NX>
-MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
+MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
     c.status = 0;
     c.active = false;
     if (!c.valid) return;
@@ -867,7 +880,7 @@ MPC_HD void phase_load_scalars(const Params& P, Ctx<NX>& c) {
 // MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
 template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
-MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
+MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
@@ -933,7 +946,7 @@ MPC_HD void phase_preload(const Params& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
 
 // arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam
 template <int NX, int ROLE = ROLE_ALL>
-MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
+MPC_HD void phase_premath(const PRef& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     if (!c.valid) return;
     // slack steps need the circle distances and their Jacobians at the iterate: recomputed here (the same evaluation
@@ -965,7 +978,7 @@ MPC_HD void phase_premath(const Params& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
 }
 
 template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
-MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
+MPC_HD void phase_step_candidates(const PRef& P, Ctx<NX>& c, Red1& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     red = red_neutral1();
@@ -1016,7 +1029,7 @@ MPC_HD void phase_step_candidates(const Params& P, Ctx<NX>& c, Red1& red) {
 
 // after the reduction: start of the filter line search (Waechter & Biegler section 2.3, eq. (23) for alpha_min)
 template <int NX>
-MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red) {
+MPC_HD void phase_linesearch_begin(const PRef& P, Ctx<NX>& c, const Red1& red) {
     c.searching = false;
     c.accepted = false;
     c.ftype = false;
@@ -1048,7 +1061,7 @@ MPC_HD void phase_linesearch_begin(const Params& P, Ctx<NX>& c, const Red1& red)
 // Phase 2: evaluate constraint violation / barrier objective at the trial point w + alpha dw
 // =========================================================================================================
 template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
-MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
+MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     red = red_neutral2();
@@ -1114,7 +1127,7 @@ MPC_HD void phase_trial_eval(const Params& P, Ctx<NX>& c, Red2& red) {
 
 // acceptance test of the trial point against the filter, the switching and the Armijo conditions
 template <int NX>
-MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red) {
+MPC_HD void phase_linesearch_decide(const PRef& P, Ctx<NX>& c, const Red2& red) {
     if (!(c.active && c.searching)) return;
     ++c.ntrial;
     const double th_t = red.theta;
@@ -1148,7 +1161,7 @@ MPC_HD void phase_linesearch_decide(const Params& P, Ctx<NX>& c, const Red2& red
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
 template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
-MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
+MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.active) return;
@@ -1241,13 +1254,15 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
         if (!c.ftype) {
             int nf = c.nfilt;
             if (nf == FILTER_MAX) {
-                for (int q = 1; q < FILTER_MAX; ++q) {
+#pragma unroll 1
+                for (int q = 1; q < FILTER_MAX; ++q) {          // (a cold path: unrolled, its 62 loads in flight set the register count of the kernel)
                     MPC_SD(P.FILT, 2 * (q - 1)) = MPC_SD(P.FILT, 2 * q);
                     MPC_SD(P.FILT, 2 * (q - 1) + 1) = MPC_SD(P.FILT, 2 * q + 1);
                 }
                 --nf;
             }
             MPC_SD(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
+            MPC_STORE_FENCE();       // (the two rows of an entry are one row pair: through the shared descriptor the compiler would merge the stores)
             MPC_SD(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
             MPC_S(P.ISC, IS_NFILT) = nf + 1;
         }
@@ -1274,7 +1289,7 @@ MPC_HD void phase_apply_update(const Params& P, Ctx<NX>& c) {
 // stationarity residual, the condensed gradient and the condensed Hessian -> xo; complementarity extremes, multiplier sums, gap product,
 // the rows' primal and dual residuals -> kp.  tg: sin / cos of the heading of this stage at the new iterate
 template <int NX, bool REUSE = false, class OUT = IneqOut<NX>, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
-MPC_HD void phase_ineq_assemble(const Params& P, Ctx<NX>& c, OUT& xo, KktPart& kp, const Trig& tg) {
+MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp, const Trig& tg) {
     using D = Dim<NX>;
     using IR = IneqRows<NX>;
     constexpr int NZ = D::NZ;
@@ -1338,7 +1353,7 @@ struct EvalTmp {
     double theta, fc, prim, dual, cmin, cmax, smult, sz, gp;
 };
 template <int NX, bool REUSE = false, int ROLE = ROLE_ALL, bool TG = false, uint32_t VM = 0xFFu>
-MPC_HD void phase_eval_model(const Params& P, Ctx<NX>& c, EvalTmp<NX>& t, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
+MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
     if (!c.active) return;
@@ -1472,7 +1487,7 @@ MPC_HD void phase_eval_model(const Params& P, Ctx<NX>& c, EvalTmp<NX>& t, const 
 }
 
 template <int NX, bool MB = false, int ROLE = ROLE_ALL, class IN = IneqOut<NX>, uint32_t VM = 0xFFu>
-MPC_HD void phase_eval_finish(const Params& P, Ctx<NX>& c, Red3& red, const IN& xk, EvalTmp<NX>& t) {
+MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk, EvalTmp<NX>& t) {
     using D = Dim<NX>;
     using IR = IneqRows<NX>;
     constexpr int NZ = D::NZ;
@@ -1550,7 +1565,7 @@ MPC_HD void phase_eval_red_b(bool active, Red3& red, const KktPart& kp) {
 
 // (one thread per (instance, stage): the three pieces back to back, one sincos for all)
 template <int NX, bool REUSE = false, bool MB = false, uint32_t VM = 0xFFu>
-MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
+MPC_HD void phase_eval_assemble(const PRef& P, Ctx<NX>& c, Red3& red) {
     IneqOut<NX> xo;
     KktPart kp;
     EvalTmp<NX> t;
@@ -1564,7 +1579,7 @@ MPC_HD void phase_eval_assemble(const Params& P, Ctx<NX>& c, Red3& red) {
 // Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
 // =========================================================================================================
 template <int NX, bool MB = false, int ROLE = ROLE_ALL>
-MPC_HD void phase_finish(const Params& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
+MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
     using D = Dim<NX>;
     if (!c.active) return;
     const int k = c.k;
@@ -1635,7 +1650,7 @@ struct RicStage {
 };
 
 template <int NX>
-MPC_HD void ric_load(const Params& P, int b, int k, RicStage<NX>& s) {
+MPC_HD void ric_load(const PRef& P, int b, int k, RicStage<NX>& s) {
     using D = Dim<NX>;
     const uint32_t bb = (uint32_t)b;
 #define RL(row) MPC_UK(P.BLK, D::NBLK, k, (row))
@@ -1678,7 +1693,7 @@ struct RicGain {
 // column of the cost-to-go are identically zero as long as no inertia correction is added -- so the recursion runs on NE
 // states and writes explicit zeros where the six-state layout has entries of s.
 template <int NX, int NE = NX, bool SYM = true>
-MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g,
+MPC_HD bool ric_matrix_step(const PRef& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g,
                             bool sym_gk = false) {
     using D = Dim<NX>;
     const double dt = P.dt;
@@ -1760,7 +1775,7 @@ MPC_HD bool ric_matrix_step(const Params& P, int k, const RicStage<NX>& s, doubl
 
 // Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
 template <int NX, int NE = NX>
-MPC_HD void ric_vector_step(const Params& P, const RicStage<NX>& s, const double* Pn, RicGain<NX>& g, double* pv) {
+MPC_HD void ric_vector_step(const PRef& P, const RicStage<NX>& s, const double* Pn, RicGain<NX>& g, double* pv) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const double dt = P.dt;
@@ -1793,7 +1808,7 @@ MPC_HD void ric_vector_step(const Params& P, const RicStage<NX>& s, const double
 
 // rows of stage k: gains [K0 | K1 | kff] -> KK, cost-to-go [P_k upper triangle | p_k] -> PK
 template <int NX>
-MPC_HD void ric_store_stage(const Params& P, uint32_t bb, int k, const double* Ps, const double* pv, const RicGain<NX>& g) {
+MPC_HD void ric_store_stage(const PRef& P, uint32_t bb, int k, const double* Ps, const double* pv, const RicGain<NX>& g) {
     using D = Dim<NX>;
     double kk[D::NKK], pk[D::NPK];
 #pragma unroll
@@ -1817,7 +1832,7 @@ MPC_HD void ric_store_stage(const Params& P, uint32_t bb, int k, const double* P
 
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
 template <int NX, int NE = NX, bool SYM = true>
-MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
+MPC_HD bool riccati_backward_step(const PRef& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0,
                                   double hux1, double* Ps, double* pv, bool sym_gk = false) {
     constexpr int NS = Dim<NX>::NS;
     double Pn[NS];
@@ -1833,7 +1848,7 @@ MPC_HD bool riccati_backward_step(const Params& P, uint32_t bb, int k, const Ric
 // the step with the decoupled-state shortcut where it applies: six states, flagged by the host, and no inertia correction in
 // this sweep (delta_w would put a nonzero entry on the diagonal of the decoupled state)
 template <int NX>
-MPC_HD bool ric_bwd_any(const Params& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
+MPC_HD bool ric_bwd_any(const PRef& P, uint32_t bb, int k, const RicStage<NX>& s, double delta, double hux0, double hux1,
                         double* Ps, double* pv, bool sym_gk = false) {
     // (measured on MI355X: the five-state recursion -- 301 instead of 402 instructions per stage -- does not shorten the
     //  stage, 40.4 vs 39.8 us per launch, so the GPU kernel runs the general step; the emulation harness keeps exercising
@@ -1848,7 +1863,7 @@ struct FwdStage {
     double K0[NX], K1[NX], kf0, kf1, a[6], cn[NX];
 };
 template <int NX>
-MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
+MPC_HD void fwd_load(const PRef& P, uint32_t bb, int k, FwdStage<NX>& f) {
     using D = Dim<NX>;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
@@ -1864,7 +1879,7 @@ MPC_HD void fwd_load(const Params& P, uint32_t bb, int k, FwdStage<NX>& f) {
 
 // one step of the forward sweep: du_k = K dx_k + kff, dx_{k+1} = A dx_k + B du_k - c_{k+1}; stores (du_k, dx_k)
 template <int NX>
-MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
+MPC_HD void riccati_forward_step(const PRef& P, uint32_t bb, int k, const FwdStage<NX>& f, double* dx) {
     using D = Dim<NX>;
     const double dt = P.dt;
     double du0 = f.kf0, du1 = f.kf1;
@@ -1892,7 +1907,7 @@ MPC_HD void riccati_forward_step(const Params& P, uint32_t bb, int k, const FwdS
 }
 
 template <int NX>
-MPC_HD void riccati_instance(const Params& P, int b) {
+MPC_HD void riccati_instance(const PRef& P, int b) {
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const int N = P.N;
@@ -1967,7 +1982,7 @@ MPC_HD void riccati_instance(const Params& P, int b) {
 // output: SoA iterate -> caller's row-major x_out + per-instance status
 // =========================================================================================================
 template <int NX>
-MPC_HD void output_instance(const Params& P, int b) {
+MPC_HD void output_instance(const PRef& P, int b) {
     using D = Dim<NX>;
     const int N = P.N;
     const uint32_t Bp = (uint32_t)P.Bp, bb = (uint32_t)b;

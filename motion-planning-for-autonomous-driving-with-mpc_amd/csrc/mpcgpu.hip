@@ -155,7 +155,7 @@ constexpr uint32_t REF_VM = PAIR_VM | MPC_REF_FLAGS;
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
 template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu>
-__device__ __forceinline__ void stage_block(const Params& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
+__device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
                                             const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
                                             uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
     int or_parity = 0;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void stage_block(const Params& P, const int n_mult, c
 // ---------------------------------------------------------------------------------------------------------------
 template <int NX> __host__ __device__ constexpr int pair_rows() { return 2 * NX + 3 * (NX + 2) + 15; }
 template <int NX, bool MB, int ROLE>
-__device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
+__device__ __forceinline__ void stage_pair_role(const PRef& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
                                                 double* lds, int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
     constexpr int NZ = NX + 2;
     constexpr uint32_t VM = PAIR_VM;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void stage_pair_role(const Params& P, const int n_mul
 #undef MPC_STAMP
 }
 template <int NX, bool MB>
-__device__ __forceinline__ void stage_pair(const Params& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits, double* lds,
+__device__ __forceinline__ void stage_pair(const PRef& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits, double* lds,
                                            int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
     // (wave-uniform, and visibly so: a scalar branch, not an exec mask)
     if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < T) stage_pair_role<NX, MB, ROLE_A>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
@@ -384,7 +384,8 @@ __device__ __forceinline__ void stage_pair(const Params& P, const int n_mult, co
 // VM: bound structure compiled into the phases (0xFF: looked up at run time; REF_VM: the reference's -- every path of a handle uses the
 // same instantiation of the phases, so that the pipeline, its fallback of one launch per kernel and the closed loop's replay give the same bits)
 template <int NX, bool INIT, int MAXT, uint32_t VM = 0xFFu>
-__global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(const Params P, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(const Params Pk, const int n_mult, const int n_z, const int stash_rows) {
+    const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
     // workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD gets a contiguous run of instance
@@ -427,7 +428,7 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
 // instance of the tile is iterating, nothing was touched)
 template <int NX>
-__device__ __forceinline__ unsigned long long riccati_tile(const Params& P, const uint32_t tile, char* smem, const bool stamp = true, const int handover_live = 0) {
+__device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const uint32_t tile, char* smem, const bool stamp = true, const int handover_live = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins (buffer->LDS DMA, readfirstlane)
     using D = Dim<NX>;
     constexpr int NS = D::NS;
@@ -453,7 +454,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
     if (__popcll(act_mask) <= handover_live) return 0ull;
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
-    const __amdgpu_buffer_rsrc_t rsrc = mpc_rsrc(P.WS, P.ws_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = P.rws;
     const uint32_t tile_off = tile * P.tile_elems * 8u;
     const uint32_t blk_base = (uint32_t)(uintptr_t)P.BLK - (uint32_t)(uintptr_t)P.WS + tile_off;
     const uint32_t kk_base = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS + tile_off;
@@ -625,7 +626,8 @@ __device__ __forceinline__ unsigned long long riccati_tile(const Params& P, cons
 }
 
 template <int NX>
-__global__ void __launch_bounds__(192) k_riccati(const Params P) {
+__global__ void __launch_bounds__(192) k_riccati(const Params Pk) {
+    const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t tile = blockIdx.x + (uint32_t)P.tile0;
     const unsigned long long act_mask = riccati_tile<NX>(P, tile, smem);
@@ -714,7 +716,8 @@ __global__ void k_xcd_census(uint32_t* mask) {
 // stage with the bound structure of the reference compiled in (PAIR_VM: only steering rate, acceleration, steering angle and speed carry
 // bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
 template <int NX, int VAR>
-__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params P, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params Pk, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+    const PRef P(Pk);
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -879,7 +882,8 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 // of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
 // wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
 template <int NX, int VAR>
-__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params P, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
+__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
+    const PRef P(Pk);
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -1053,7 +1057,8 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
 // start-point safeguard: one tile of 64 instances per workgroup, two wavefronts -- wave 0 rolls the control guess out,
 // wave 1 measures the dynamics defect of the caller's state guess (both are 30-stage dependent chains of sin/cos/tan)
 template <int NX>
-__global__ void __launch_bounds__(128) k_prestart(const Params P) {
+__global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
+    const PRef P(Pk);
     __shared__ double th_guess[64];
     extern __shared__ __attribute__((aligned(16))) double bnd_tab[];            // [LB | UB], (N+1)*NZ doubles each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1080,7 +1085,7 @@ __global__ void __launch_bounds__(128) k_prestart(const Params P) {
 // three short scans x_{k+1} = push_in(x_k + dt f_k) per state, run by the first two stage-threads of every instance from increments
 // parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
 template <int NX>
-__device__ __forceinline__ void prestart_par_block(const Params& P, const uint32_t b0, double* sm) {
+__device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm) {
     constexpr int NZ = NX + 2;
     const int N = P.N, S = N + 1, bx = P.bx, t = threadIdx.x, bl = t & (bx - 1);
     const int nb = S * NZ, SB = S * bx;
@@ -1189,14 +1194,16 @@ __device__ __forceinline__ void prestart_par_block(const Params& P, const uint32
 #undef PP_AT
 }
 template <int NX>
-__global__ void __launch_bounds__(1024) k_prestart_par(const Params P) {
+__global__ void __launch_bounds__(1024) k_prestart_par(const Params Pk) {
+    const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     prestart_par_block<NX>(P, (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx, sm);
 }
 // ingest + start-point safeguard + start iterate of a block of bx instances in ONE launch (the three have the same thread mapping; what one
 // leaves in the workspace -- rollout, per-instance bounds of a_0, the verdict -- comes back from this CU's own write-through L1 / the L2)
 template <int NX>
-__global__ void __launch_bounds__(256, 2) k_start(const Params P, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(256, 2) k_start(const Params Pk, const int n_mult, const int n_z, const int stash_rows) {
+    const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
     uint32_t blk = blockIdx.x;
@@ -1258,7 +1265,8 @@ __device__ __forceinline__ uint32_t zrow_of_col(int col, int N) {          // de
 
 // grid = (tiles, 64-column chunks): every workgroup moves one 64 x 64 block, so a batch of 64 tiles is ~450 workgroups
 template <int NX>
-__global__ void __launch_bounds__(256) k_ingest(const Params P) {
+__global__ void __launch_bounds__(256) k_ingest(const Params Pk) {
+    const PRef P(Pk);
     __shared__ double tile[64][65];
     const int N = P.N, nw = 2 * N + NX * (N + 1);
     const uint32_t tl = blockIdx.x + (uint32_t)P.tile0, t0 = tl * 64u;
@@ -1290,7 +1298,8 @@ __global__ void __launch_bounds__(256) k_ingest(const Params P) {
 template <int NX>
 // zero_p / zero_n: the pipeline's OTHER control block, zeroed here for the next solve (the two blocks alternate: a solve in steady state has
 // no fill of its own in front of its persistent launch)
-__global__ void __launch_bounds__(256) k_egest(const Params P, const uint32_t* skip_if, uint32_t* fail_count, uint32_t* zero_p, const uint32_t zero_n) {
+__global__ void __launch_bounds__(256) k_egest(const Params Pk, const uint32_t* skip_if, uint32_t* fail_count, uint32_t* zero_p, const uint32_t zero_n) {
+    const PRef P(Pk);
     __shared__ double tile[64][65];
     if (zero_p != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
         for (uint32_t q = threadIdx.x; q < zero_n; q += 256u) zero_p[q] = 0u;
@@ -1693,7 +1702,8 @@ __global__ void k_loop_setup(const LoopArgs A) {
 // instance, laid out for coalesced rows -- one workgroup per instance, the threads run over the n_w columns of the three
 // row-major rows (solution in, warm start and parameter vector out); thread 0 records the step and integrates the plant.
 // Same values bit for bit (the columns are copies, the plant step and the noise samples are the same code).
-__global__ void __launch_bounds__(128) k_loop_advance(const Params P, const LoopArgs A, const int i) {
+__global__ void __launch_bounds__(128) k_loop_advance(const Params Pk, const LoopArgs A, const int i) {
+    const PRef P(Pk);
     __shared__ double cur_s[6];
     if (A.abort_flag != nullptr && *A.abort_flag != 0u) return;       // a solve of this loop was abandoned: the host replays the loop
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
@@ -1808,7 +1818,8 @@ __global__ void k_rescue_scatter(const int32_t* idx, int nw, const int32_t* st, 
 }
 
 template <int NX>
-__global__ void k_plant_step(const Params P, const double* x, const double* u, double* xn, int B, int integrator) {
+__global__ void k_plant_step(const Params Pk, const double* x, const double* u, double* xn, int B, int integrator) {
+    const PRef P(Pk);
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double xs[NX], us[2], f[NX], s, c, td;
