@@ -80,7 +80,9 @@ enum ScRow {
     SC_A0LB, SC_A0UB,            // per-instance bounds of a_0 (stage-0 friction row presolved into a bound)
     SC_COUNT
 };
-enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW, IS_COUNT };
+enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW,
+             IS_RLEV, IS_ITACC,           // second chance inside k_solve_wg: level index (| 0x100: a level of this pass has converged), iterations of the attempts so far
+             IS_COUNT };
 struct Params {
     int32_t B, Bp, N, nx, bx;    // instances, padded instances (multiple of 64), horizon, states, instances/block
     int32_t obst_mult, max_iter, fixed_iters;

@@ -881,14 +881,30 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 // PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
 // of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
 // wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
-template <int NX, int VAR>
-__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if) {
-    const PRef P(Pk);
+// RESC: the SECOND CHANCE of an instance that stalls (status 0 / -7: what rescue_dev does on the host, see there) starts inside the running
+// launch, in the wavefront that owns the instance -- one instance per workgroup (bx = 1), so the level's lower bound of the circle rows and
+// its tolerance are the workgroup's own copies of P.ol / P.tol.  An instance that stalls at iteration 4 ... 32 does not wait for the
+// slowest of the batch before it is looked at again, and its levels need no launches, no compaction and no host round trip.  Schedule and
+// semantics are rescue_dev's: pass 1 = levels {0, 1} x the true bound, pass 2 = {0, 0.4, 0.7, 0.9, 1}; a level starts from the last
+// level of its pass that converged (else from the caller's x0); levels below the last stop at 1e-4; the last level IS the original NLP.
+struct WgRescue { double ol_raw, relax; int32_t on; };
+constexpr int RESC_LEVELS = 8;          // index q of IS_RLEV: 0 = the first attempt, 1-2 pass 1, 3-7 pass 2
+__device__ __forceinline__ double resc_fraction(int q) { return q == 2 || q == 7 ? 1.0 : q == 4 ? 0.4 : q == 5 ? 0.7 : q == 6 ? 0.9 : 0.0; }
+__device__ __forceinline__ bool resc_last(int q) { return q == 2 || q == 7; }
+template <int NX> __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm);
+
+template <int NX, int VAR, bool RESC = false>
+__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
+                                                                   const WgRescue resc) {
+    PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
     __shared__ uint32_t sh_mask;
+    __shared__ int sh_next[2];
     if (skip_if != nullptr && *skip_if != 0u) return;          // the pipeline launch in front of this one was abandoned: the host starts over
+    const double tol0 = P.tol;
+    bool fresh = true;                            // the instance's rows are tile-major (start iterate / hand-over from the pipeline): take them over
     using D = Dim<NX>;
     using RC = Rec<NX>;
     const int bx = P.bx, t = threadIdx.x, N = P.N;
@@ -903,6 +919,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
     const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * wave;
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
+    if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
         //      left the mask in sh_mask (an instance the sweeps gave up on is inactive there: phase_load_scalars reads its status)
@@ -914,14 +931,92 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
         }
         lds_barrier();
         const uint32_t mask = sh_mask;
-        if (mask == 0u) break;
+        if (mask == 0u) {
+            if (!RESC || !resc.on) break;
+            // ---- the instance of this workgroup has stopped: is a (further) level of the second chance due?
+            if (t == 0) {
+                const int bb = (int)b0;
+                int next = -1, carry = 0;
+                if (bb < P.B) {
+                    const int st = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb), it = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb);
+                    const int lev = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb);
+                    const int q = lev & 0xFF;
+                    int has_xs = lev >> 8;
+                    const int acc = (q == 0 ? 0 : (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITACC, bb)) + it;
+                    if (q == 0) {
+                        if (st == 0 || st == -7) { next = 1; if (stats != nullptr) atomicAdd(stats + 4, 1u); }
+                    } else {
+                        if (st == 1) { carry = 1; has_xs = 1; }
+                        if (!resc_last(q)) next = q + 1;
+                        else if (st != 1 && q == 2) { next = 3; has_xs = 0; }          // pass 2 starts over from the caller's x0
+                    }
+                    if (next >= 0) {
+                        MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb) = next | (has_xs << 8);
+                        MPC_UB(P.ISC, (uint32_t)IS_ITACC, bb) = acc;
+                    } else if (q != 0) {
+                        MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb) = acc;                   // (what the caller is told: all attempts together)
+                    }
+                    next = next < 0 ? -1 : (next | (has_xs << 8));
+                }
+                sh_next[0] = next;
+                sh_next[1] = carry;
+            }
+            lds_barrier();
+            const int nx_lev = sh_next[0], carry = sh_next[1];
+            lds_barrier();
+            if (nx_lev < 0) break;
+            const int q = nx_lev & 0xFF;
+            const bool from_xs = (nx_lev >> 8) != 0;
+            // the level's problem: lower bound of the circle rows (relaxed like mpc_set_bounds relaxes it), tolerance
+            {
+                const double lo = resc_fraction(q) * resc.ol_raw;
+                P.ol = lo - resc.relax * fmax(1.0, fabs(lo));
+                P.tol = resc_last(q) ? tol0 : fmax(tol0, 1e-4);
+            }
+            if (valid) {
+                constexpr int NZ = D::NZ;
+                double v[MPC_EV(NZ)];
+                // (the scratch of the warm start: the tile-major rows of the cost-to-go, which this kernel does not use)
+                if (carry) {
+                    ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
+                    ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
+                }
+                if (from_xs) {
+                    if (!carry) ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
+                } else {
+                    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+                    const double* xr = P.x0 + (size_t)c.b * nw;
+                    v[0] = (c.k < N) ? MPC_GP(xr, 2 * c.k) : 0.0;
+                    v[1] = (c.k < N) ? MPC_GP(xr, 2 * c.k + 1) : 0.0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) v[2 + i] = MPC_GP(xr, 2 * N + NX * c.k + i);
+                }
+                ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prestart_par_block<NX>(P, b0, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots, false, &sh_mask);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fresh = true;
+            continue;
+        }
         ++rounds;
         inst_rounds += (uint32_t)__popc(mask);
         WG_STAMP(12);
         // ---- taking the instances over: the iterate, its multipliers and the reference move from the tile-major arrays (where the
         //      pipeline / the start-iterate kernel left them) into the instance-major mailbox arrays the rounds below work on -- one
         //      wavefront reads all stages of its one or two instances, and only there are the pieces of a thread contiguous
-        if (rounds == 1u && valid) {
+        if (fresh && valid) {
             constexpr bool MB = true;
             auto move = [&](auto cnt, auto from, auto to) {
                 constexpr int CNT = decltype(cnt)::value;
@@ -946,7 +1041,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
             double blk[MPC_EV(D::NBLK)];
             // (the blocks this launch starts from were written tile-major by the start-iterate kernel or the pipeline; its own rounds
             //  write the instance-major mailbox: 272 contiguous bytes per thread instead of 17 pieces in 17 lines)
-            if (rounds == 1u) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
+            if (fresh) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
             else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), blk);
             double hx0 = 0.0, hx1 = 0.0;
             if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
@@ -960,6 +1055,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
             r[RC::HX + 1] = hx1;
         }
         lds_barrier();
+        fresh = false;
         WG_STAMP(13);
         // (per-lane operand offsets of the sweeps: rebuilt every round from a lane id the compiler cannot see through, so that they are
         //  not hoisted out of the loop and kept in registers across stage_block)
@@ -1902,13 +1998,15 @@ struct mpc_handle {
     uint32_t* h_fail = nullptr;         // pinned copy
     int loop_replayed = 0;              // the last closed loop had to be replayed with host synchronisation per step
     int rescued_last = 0;               // instances the last solve handed to the second chance (rescue_dev)
+    bool in_rescue = false;             // rescue_dev is solving its levels: they get no second chance of their own
+    bool resc_in_kernel = false;        // the last solve ran k_solve_wg with the second chance inside (RESC): rescue_dev has nothing to add
     bool attr_set_fq = false;
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -1947,6 +2045,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
     else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
     else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
+    else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
     else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else return MPC_ERR_INVALID;
@@ -1976,13 +2075,14 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "pair") *out = k.pair;
     else if (n == "fuse_start") *out = k.fuse_start;
     else if (n == "bound_mask") *out = k.bound_mask;
+    else if (n == "rescue_wg") *out = k.rescue_wg;
     else if (n == "friction_lb") *out = k.friction_lb;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2338,6 +2438,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             h->attr_set = true;
         }
     }
@@ -2458,16 +2560,29 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (wg_pair(bxw))
             return std::max(((size_t)(2 * thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * thr) * sizeof(double),
                             ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (2 * thr / 64) + Rec<NX>::SIZE) * sizeof(double));
-        return std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
-                        ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double));
+        // (RESC: the start-point safeguard of a restart -- bounds table, rollout / defect rows, scan increments, three words per column)
+        const size_t pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bxw + (size_t)3 * bxw) * sizeof(double);
+        return std::max(std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
+                                 ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double)), bxw == 1 ? pre : (size_t)0);
     };
+    // the second chance inside the launch (k_solve_wg<.., RESC>): one instance per workgroup, the conditions of rescue_dev
+    const bool resc_cond = kn.rescue && kn.rescue_wg && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
+    auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1 && !wg_pair(bxw); };
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
         Params Pw = P;
         Pw.bx = bxw;
         const int thr = ((S * bxw + 63) / 64) * 64;
-        if (wg_pair(bxw)) hipLaunchKernelGGL((k_solve_wg<NX, true>), dim3((B + bxw - 1) / bxw), dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
-        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
-        else hipLaunchKernelGGL((k_solve_wg<NX, false>), dim3((B + bxw - 1) / bxw), dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if);
+        WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
+        const dim3 grid((B + bxw - 1) / bxw);
+        if (wg_pair(bxw)) hipLaunchKernelGGL((k_solve_wg<NX, true>), grid, dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+        else if (wg_resc(bxw)) {
+            rs.on = 1;
+            h->resc_in_kernel = true;
+            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+        }
+        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
@@ -2484,8 +2599,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     if ((use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
         // (one fill: outside an asynchronous closed loop word 1, its sticky abort word, means nothing)
-        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 6 * sizeof(uint32_t), stream));
-        else HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 4 * sizeof(uint32_t), stream));
+        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 7 * sizeof(uint32_t), stream));
+        else HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 5 * sizeof(uint32_t), stream));
         const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
@@ -2505,8 +2620,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             h->async_ok = true;
             return MPC_OK;
         }
-        HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, wait_stream(h, stream));
+        if (h->resc_in_kernel) h->rescued_last = (int)h->h_fail[6];
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
             std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
             HIP_TRY(h, hipMemcpy(hd.data(), P.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2828,7 +2944,9 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
         for (int q = 0; q < nfr && rc == MPC_OK; ++q) {
             h->hp.ol = relax_lo(fr[q] * h->hp.ol_raw);
             h->hp.desc.tol = (q + 1 < nfr) ? std::max(tol_keep, 1e-4) : tol_keep;      // intermediate levels only produce warm starts
+            h->in_rescue = true;
             rc = solve_dev_any(h, n, xs, ps, d_obst ? os : nullptr, out, st, it, kk, stream, nullptr, 0, nullptr);
+            h->in_rescue = false;
             if (rc == MPC_OK) hipLaunchKernelGGL(k_rescue_carry, dim3(n), dim3(128), 0, stream, (int)nw, st, it, out, xs, acc);
         }
         h->hp.ol = ol_keep;
@@ -2884,8 +3002,11 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
             return MPC_OK;
         }
     }
+    h->resc_in_kernel = false;
     const int rc = solve_dev_any(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
-    if (rc != MPC_OK || !rescue || h->h_fail[0] == 0u) return rc;       // (converged mode: the solve has synchronised the stream)
+    // (converged mode: the solve has synchronised the stream; a launch of k_solve_wg with the second chance inside has given every stalled
+    //  instance its levels already)
+    if (rc != MPC_OK || !rescue || h->h_fail[0] == 0u || h->resc_in_kernel) return rc;
     double prof_keep[6], pipe_keep[8];
     const int mode_keep = h->last_mode;
     memcpy(prof_keep, h->prof, sizeof prof_keep);

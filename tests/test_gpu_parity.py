@@ -342,6 +342,35 @@ def test_collision_avoidance_batch():
     assert np.array_equal(per.x, s.solve(x0[:32], p[:32]).x)
 
 
+def test_second_chance_inside_the_launch_equals_the_one_behind_it():
+    """k_solve_wg<.., RESC> (option rescue_wg, default on; one instance per workgroup) starts the obstacle-radius homotopy of a stalled
+    instance inside the running launch; rescue_dev does the same on the host once the launch is over (sub-batch, one solve per level).
+    Same schedule, same warm starts, same arithmetic: every row, status and accumulated iteration count is the same bit for bit, the same
+    instances are rescued -- and the result certifies against the NLP alone"""
+    from helpers import kkt_certificate
+    B = 1024
+    x0, p = ca_batch(CA_CFG, B)
+    s = make_solver(CA_CFG)
+    set_cfg_bounds(s, CA_CFG)
+    assert s.get_option("rescue_wg") == 1
+    a = s.solve(x0, p)
+    na = s.last_rescued()
+    s.set_option("rescue_wg", "0")
+    b = s.solve(x0, p)
+    nb = s.last_rescued()
+    assert na == nb and na > 0 and np.all(a.status == 1)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+    s.set_option("rescue", "0")
+    plain = s.solve(x0, p)
+    stalled = np.flatnonzero(plain.status != 1)
+    assert len(stalled) == na
+    nlp = BicycleNLP(CA_CFG)
+    for i in stalled[:4]:
+        cert = kkt_certificate(nlp, a.x[i], p[i])
+        assert cert["stationarity"] <= 1e-6 and cert["feasibility"] <= 1e-6, (i, cert)
+        assert a.iters[i] > plain.iters[i]              # (all attempts together)
+
+
 def test_fixed_iteration_mode_matches_converged():
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 512, **kw)
