@@ -324,6 +324,107 @@ MPC_HD void red_combine(Red3& a, const Red3& b) {
     a.nan = fmax(a.nan, b.nan);
 }
 
+
+// ---- elementary functions of the phases, in one place -------------------------------------------------------------------------------
+// A stage thread spends ~2 400 of its ~8 100 instructions per iteration inside the math library's division, pow, sincos, tan, log and sqrt
+// (counted by stubbing each out, MPC_XP) -- at one wavefront per SIMD every instruction is an issue slot.  The device versions below
+// are accurate to 1-2 ulp on the ranges the phases call them with (the host versions are libm: the emulation harness and the oracle
+// agree with the kernels to round-off, never bit for bit -- as before, the device library is not libm either).
+#ifndef MPC_XP
+#define MPC_XP 0          // (experiments: bit q set = function q replaced by a stub, to COUNT what it costs -- never in a product build)
+#endif
+#ifndef MPC_FAST_MATH
+#define MPC_FAST_MATH 1   // 0: the device library's division / sincos / tan and the literal pow of the switching condition
+#endif
+// 1 / x for a positive, normal x (gaps to bounds, circle distances, cos of the steering angle): hardware estimate + two Newton steps
+// (5 instructions; the IEEE division sequence is 11)
+MPC_HD double mpc_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 1)
+    return __builtin_amdgcn_rcp(x);
+#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
+MPC_HD double mpc_pow(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 2)
+    return x * y;
+#else
+    return pow(x, y);
+#endif
+}
+// sin and cos of a heading / steering angle: Cody-Waite reduction by pi/2 in three parts (exact products by fma: good to 1 ulp for
+// |x| < ~1e5), then the two minimax kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos); ~35 instructions
+// against ~200 of the library's sincos, which carries the Payne-Hanek reduction for huge arguments (no fallback to it: its code next to
+// this one costs 40 registers; the reduction stays exact in its products for any finite x, the quadrant is meaningless beyond 2^31 pi/2 --
+// a heading of that size is a diverged iterate, and the values stay finite).
+MPC_HD void mpc_sincos(double x, double& s, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 4)
+    s = x; c = 1.0 - 0.5 * x * x;
+#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-fn, 1.57079632679489655800e+00, x);           // pi/2 = hi + mid + lo
+    r = fma(-fn, 6.12323399573676603587e-17, r);
+    r = fma(-fn, -1.49738490485916983294e-33, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                           -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double sn = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                           2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)fn;
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, &s, &c);
+#else
+    s = sin(x); c = cos(x);
+#endif
+}
+// tan of a steering angle (|x| well inside pi/2: the variable is bounded): sin / cos from the reduction above
+MPC_HD double mpc_tan(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 8)
+    return x + x * x * x * (1.0 / 3.0);
+#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+    double sn, cs;
+    mpc_sincos(x, sn, cs);
+    double t = sn * mpc_rcp(cs);
+    asm volatile("" : "+v"(t));       // (opaque: left visible, the product is contracted into whatever adds to it -- in one kernel and not in another)
+    return t;
+#else
+    return tan(x);
+#endif
+}
+MPC_HD double mpc_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 16)
+    return x - 1.0;
+#else
+    return log(x);
+#endif
+}
+MPC_HD double mpc_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 32)
+    return __builtin_amdgcn_sqrt(x);
+#else
+    return sqrt(x);
+#endif
+}
+// theta^s_theta / (-dphi)^s_phi of the switching condition and of alpha_min (Waechter & Biegler eq. (19), (23)): one exp of two logs on
+// the device (the two pow cost ~420 instructions); 0 for theta = 0
+MPC_HD double mpc_switch_ratio(double theta, double mdphi) {
+#if defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH && !(MPC_XP & 2)
+    return exp(S_THETA * log(theta) - S_PHI * log(mdphi));
+#else
+    return mpc_pow(theta, S_THETA) / mpc_pow(mdphi, S_PHI);
+#endif
+}
+
 // ---- small helpers -----------------------------------------------------------------------------------------
 MPC_HD bool has_lo(double lb) { return lb > -BIG; }
 MPC_HD bool has_hi(double ub) { return ub < BIG; }
@@ -356,7 +457,7 @@ MPC_HD double sel_dual(const StepSel& s, double tau) { return -tau * s.dn / s.dd
 // multiplier step of one bound side and its fraction-to-the-boundary candidates.  gap > 0 is the distance to the
 // bound, dg its change along the step, z its multiplier; ig returns 1/gap (kept by the caller for the update phase)
 MPC_HD double side_step(double gap, double z, double dg, double mu, StepSel& s, double& ig) {
-    ig = 1.0 / gap;
+    ig = mpc_rcp(gap);
     const double dz = (mu - z * dg) * ig - z;               // mu/gap - z - (z/gap) dg
     if (dg < 0 && gap * s.pd > s.pg * dg) { s.pg = gap; s.pd = dg; }       // gap/(-dg) < pg/(-pd)
     if (dz < 0 && z * s.dd > s.dn * dz) { s.dn = z; s.dd = dz; }          // z/(-dz) < dn/(-dd)
@@ -411,7 +512,7 @@ struct Ctx {
     double dlam[NX];                 // step of the equality multipliers, -(P_k dx_k + p_k) - lambda_k
     double r0[NX];                   // r_0 (k == 0)
     double dfric0, gfr0[3];          // friction row value / gradient at the current iterate (k == 0, row kept)
-    double pw_theta, pw_dphi;        // theta^s_theta, (-dphi)^s_phi of the switching condition (cached per line search)
+    double pw_theta;                 // theta^s_theta / (-dphi)^s_phi of the switching condition (cached per line search)
     double rn[NX];                   // r_{k+1} (k < N)
     double so[3], dso[3];
     double sf, dsf;                  // friction slack (k == 0)
@@ -488,11 +589,7 @@ MPC_HD KktPart kkt_part_neutral() { return KktPart{0.0, 0.0, BIG, -BIG, 0.0, 0.0
 struct Trig { double sps, cps; };
 MPC_HD Trig psi_trig(double psi) {
     Trig t;
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincos(psi, &t.sps, &t.cps);
-#else
-    t.sps = sin(psi); t.cps = cos(psi);
-#endif
+    mpc_sincos(psi, t.sps, t.cps);
     return t;
 }
 
@@ -515,13 +612,9 @@ MPC_HD Trig psi_trig(double psi) {
 template <int NX, bool TG = false>
 MPC_HD void ode_eval(const Params& P, const double* x, const double* u, double* f, double& sps, double& cps, double& td) {
     if (!TG) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        sincos(x[4], &sps, &cps);
-#else
-        sps = sin(x[4]); cps = cos(x[4]);
-#endif
+        mpc_sincos(x[4], sps, cps);
     }
-    td = tan(x[2]);
+    td = mpc_tan(x[2]);
     f[0] = x[3] * cps;
     f[1] = x[3] * sps;
     f[2] = u[0];
@@ -537,9 +630,9 @@ MPC_HD double circle_eval(const Params& P, const double* obst, int j, double sx,
     const double sg = (j == 0) ? 0.0 : (j == 1 ? 1.0 : -1.0);
     const double cx = sx + sg * rho * cps - obst[2 * j];
     const double cy = sy + sg * rho * sps - obst[2 * j + 1];
-    const double r = sqrt(cx * cx + cy * cy);
+    const double r = mpc_sqrt(cx * cx + cy * cy);
     if (!derivs) return r;
-    const double ir = 1.0 / r;
+    const double ir = mpc_rcp(r);
     const double ex = cx * ir, ey = cy * ir;
     const double tx = -sg * rho * sps, ty = sg * rho * cps;
     J3[0] = ex;
@@ -568,7 +661,7 @@ MPC_HD double friction_eval(const Params& P, double a, double dl, double v, doub
     const double td = tan(dl);
     const double y = a * a + v * (td * v / kap);
     if (derivs) {
-        const double cd = cos(dl), icd2 = 1.0 / (cd * cd);
+        const double cd = cos(dl), icd2 = mpc_rcp(cd * cd);
         const double sg = (y > 0.0) ? 1.0 : ((y < 0.0) ? -1.0 : 0.0);
         g[0] = sg * 2 * a;
         g[1] = sg * v * v * icd2 / kap;
@@ -777,11 +870,7 @@ MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
     }
     // slacks: s = d(w0) pushed inside its bounds
     double sps, cps;
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincos(c.z[2 + 4], &sps, &cps);
-#else
-    sps = sin(c.z[2 + 4]); cps = cos(c.z[2 + 4]);
-#endif
+    mpc_sincos(c.z[2 + 4], sps, cps);
     double dist[3];
     obstacle_eval(P, c.obst, c.z[2], c.z[3], sps, cps, dist, nullptr, nullptr, false);
     const double ol = P.has_ol ? P.ol : -INFINITY, ou = P.has_ou ? P.ou : INFINITY;
@@ -1041,14 +1130,10 @@ MPC_HD void phase_linesearch_begin(const PRef& P, Ctx<NX>& c, const Red1& red) {
     c.a_du = red.a_du;
     c.dphi = red.dphi;
     double a_min;
-    c.pw_theta = 0.0;
-    c.pw_dphi = 0.0;
-    if (c.dphi < 0 && c.theta <= c.thmin) {          // the only case in which the switching condition can hold
-        c.pw_theta = pow(c.theta, S_THETA);
-        c.pw_dphi = pow(-c.dphi, S_PHI);
-    }
+    c.pw_theta = 0.0;          // theta^s_theta / (-dphi)^s_phi
+    if (c.dphi < 0 && c.theta <= c.thmin) c.pw_theta = mpc_switch_ratio(c.theta, -c.dphi);          // the only case in which the switching condition can hold
     if (c.dphi < 0 && c.theta <= c.thmin)
-        a_min = fmin(fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi)), LS_DELTA * c.pw_theta / c.pw_dphi);
+        a_min = fmin(fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi)), LS_DELTA * c.pw_theta);
     else if (c.dphi < 0)
         a_min = fmin(GAMMA_THETA, GAMMA_PHI * c.theta / (-c.dphi));
     else
@@ -1123,7 +1208,7 @@ MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
     }
     red.theta = theta;
     red.fcost = fc;
-    red.logsum = log(gp);
+    red.logsum = mpc_log(gp);
     red.bad = bad;
 }
 
@@ -1143,7 +1228,7 @@ MPC_HD void phase_linesearch_decide(const PRef& P, Ctx<NX>& c, const Red2& red) 
         c.accepted = true;
         c.ftype = true;
     } else if (good) {
-        const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha * c.pw_dphi > LS_DELTA * c.pw_theta;
+        const bool sw = c.theta <= c.thmin && c.dphi < 0 && c.alpha > LS_DELTA * c.pw_theta;
         if (sw) {
             if (cmp_le(ph_t - c.phi, ETA_PHI * c.alpha * c.dphi, c.phi)) { c.accepted = true; c.ftype = true; }
         } else if (cmp_le(fmax(th_t, THETA_FLOOR), fmax((1 - GAMMA_THETA) * c.theta, THETA_FLOOR), c.theta) ||
@@ -1180,8 +1265,8 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         const double zi = c.z[i], dv = c.dz[i], zn = zi + al * dv;       // (the accepted trial point, formed again)
         if (side_mine<ROLE, VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
-            if (MPC_HAS_LO(lb)) { const double ign = 1.0 / (zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
-            if (MPC_HAS_HI(ub)) { const double ign = 1.0 / (ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
+            if (MPC_HAS_LO(lb)) { const double ign = mpc_rcp(zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
+            if (MPC_HAS_HI(ub)) { const double ign = mpc_rcp(ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
         }
         (void)zi;
         c.z[i] = zn;
@@ -1211,13 +1296,13 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         const double s = c.so[j], ds = c.dso[j], sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
         if (MPC_RB && MPC_HAS_OL) {
-            const double ig = c.iglo[j], ign = 1.0 / (sn - P.ol);
+            const double ig = c.iglo[j], ign = mpc_rcp(sn - P.ol);
             sg += c.zlo[j] * ig; gb -= mu * ig;
             c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
             c.iglo[j] = ign;
         }
         if (MPC_RB && MPC_HAS_OU) {
-            const double ig = c.iguo[j], ign = 1.0 / (P.ou - sn);
+            const double ig = c.iguo[j], ign = mpc_rcp(P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
             c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
             c.iguo[j] = ign;
@@ -1235,15 +1320,15 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         const double s = c.sf, ds = c.dsf, sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
-            const double ig = 1.0 / (s - P.fl);
+            const double ig = mpc_rcp(s - P.fl);
             sg += c.zlf * ig; gb -= mu * ig;
-            c.zlf = side_update(ig, c.zlf, ds, mu, ad, 1.0 / (sn - P.fl));
+            c.zlf = side_update(ig, c.zlf, ds, mu, ad, mpc_rcp(sn - P.fl));
             MPC_S(P.SC, SC_ZLF) = c.zlf;
         }
         if (P.has_fu) {
-            const double ig = 1.0 / (P.fu - s);
+            const double ig = mpc_rcp(P.fu - s);
             sg += c.zuf * ig; gb += mu * ig;
-            c.zuf = side_update(ig, c.zuf, -ds, mu, ad, 1.0 / (P.fu - sn));
+            c.zuf = side_update(ig, c.zuf, -ds, mu, ad, mpc_rcp(P.fu - sn));
             MPC_S(P.SC, SC_ZUF) = c.zuf;
         }
         c.nuf += al * (gb - c.nuf + sg * ds);
@@ -1306,8 +1391,8 @@ MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp,
         if (!(isu && k == N)) {
             MPC_BOUNDS(k, i, lb, ub);
             const double zi = c.z[i];
-            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
-            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : mpc_rcp(zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
+            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : mpc_rcp(ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, kp.cmin, kp.cmax, kp.sz, kp.gp);
         }
         xo.put(3 * i + IR::SG, sg); xo.put(3 * i + IR::GBB, gbb); xo.put(3 * i + IR::RZ, rz);
     }
@@ -1318,8 +1403,8 @@ MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp,
         const double dist = circle_eval(P, c.obst, j, c.z[2], c.z[3], tg.sps, tg.cps, J, Ho, true);
         const double s = c.so[j], nu = c.nuo[j];
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (MPC_HAS_OL) side_kkt(s - P.ol, REUSE ? c.iglo[j] : 1.0 / (s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
-        if (MPC_HAS_OU) side_kkt(P.ou - s, REUSE ? c.iguo[j] : 1.0 / (P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (MPC_HAS_OL) side_kkt(s - P.ol, REUSE ? c.iglo[j] : mpc_rcp(s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (MPC_HAS_OU) side_kkt(P.ou - s, REUSE ? c.iguo[j] : mpc_rcp(P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
         kp.dual = fmax(kp.dual, fabs(rs));
         const double res = dist - s;
         kp.theta += m * fabs(res);
@@ -1449,8 +1534,8 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
             MPC_BOUNDS(k, i, lb, ub);
             const double zi = c.z[i];
             double sg = 0.0, gbb = 0.0, rz = 0.0;
-            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : 1.0 / (zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : 1.0 / (ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : mpc_rcp(zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
+            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : mpc_rcp(ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
             ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz;
         }
     }
@@ -1460,8 +1545,8 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
         const double s = c.sf, nu = c.nuf;
         double sg = 0.0, gbb = 0.0, rs = -nu;
-        if (P.has_fl) side_kkt(s - P.fl, 1.0 / (s - P.fl), c.zlf, 1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
-        if (P.has_fu) side_kkt(P.fu - s, 1.0 / (P.fu - s), c.zuf, -1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_fl) side_kkt(s - P.fl, mpc_rcp(s - P.fl), c.zlf, 1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
+        if (P.has_fu) side_kkt(P.fu - s, mpc_rcp(P.fu - s), c.zuf, -1.0, 1, sg, gbb, rs, cmin, cmax, sz, gp);
         dual = fmax(dual, fabs(rs));
         const double res = dfr - s;
         theta += fabs(res);
@@ -1553,7 +1638,7 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
         }
     }
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
-    const double ls = log(gp);
+    const double ls = mpc_log(gp);
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
 }
 
@@ -1562,7 +1647,7 @@ MPC_HD void phase_eval_red_b(bool active, Red3& red, const KktPart& kp) {
     red = red_neutral3();
     if (!active) return;
     red.dual_inf = kp.dual; red.prim_inf = kp.prim; red.cmin = kp.cmin; red.cmax = kp.cmax; red.sum_mult = kp.smult; red.sum_z = kp.sz;
-    red.theta = kp.theta; red.logsum = log(kp.gp);
+    red.theta = kp.theta; red.logsum = mpc_log(kp.gp);
 }
 
 // (one thread per (instance, stage): the three pieces back to back, one sincos for all)

@@ -1258,14 +1258,14 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     scan(2, 3, 2);                                            // delta, v from the controls
     if (valid && c.k < N) {
         const double dl = PP_AT(XR, 2, c.k), v = PP_AT(XR, 3, c.k);
-        PP_AT(IN, 0, c.k) = v / P.wheelbase * tan(dl);
+        PP_AT(IN, 0, c.k) = v / P.wheelbase * mpc_tan(dl);            // (the functions of ode_eval: same bits as the two-chain kernel)
         PP_AT(IN, 1, c.k) = v;
     }
     __syncthreads();
     scan(4, 5, NX == 6 ? 2 : 1);                              // psi (and the progress state)
     if (valid && c.k < N) {
         double sp, cp;
-        sincos(PP_AT(XR, 4, c.k), &sp, &cp);
+        mpc_sincos(PP_AT(XR, 4, c.k), sp, cp);
         const double v = PP_AT(XR, 3, c.k);
         PP_AT(IN, 0, c.k) = v * cp;
         PP_AT(IN, 1, c.k) = v * sp;
