@@ -112,7 +112,9 @@ MPC_HD bool fq_row_on(const ForcesQpArgs& A, int k, int q) {
 #define FQ_UNROLL
 #endif
 MPC_HD void forces_ode_eval(const double* x, const double* u, double l, double* f, double* F4, double& F42, double& F43) {
-    const double sn = sin(x[4]), cs = cos(x[4]), td = tan(x[2]);
+    double sn, cs;
+    mpc_sincos(x[4], sn, cs);
+    const double td = mpc_tan(x[2]);
     f[0] = x[3] * cs; f[1] = x[3] * sn; f[2] = u[0]; f[3] = u[1]; f[4] = x[3] / l * td;
     F4[0] = cs; F4[1] = -x[3] * sn; F4[2] = sn; F4[3] = x[3] * cs;
     F42 = x[3] / l * (1.0 + td * td);
@@ -180,13 +182,14 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
     if (h != nullptr) {
         FQ_UNROLL
         for (int i = 0; i < 70; ++i) jh[i] = 0.0;
-        const double td = tan(z[4]);
+        const double td = mpc_tan(z[4]);
         const double q = z[5] * z[5] * td / A.wb;                 // v * psi_dot
         h[0] = z[1] * z[1] + q * q;
         jh[1] = 2.0 * z[1];
         jh[4] = 2.0 * q * z[5] * z[5] * (1.0 + td * td) / A.wb;
         jh[5] = 2.0 * q * 2.0 * z[5] * td / A.wb;
-        const double sn = sin(z[6]), cs = cos(z[6]);
+        double sn, cs;
+        mpc_sincos(z[6], sn, cs);
         FQ_UNROLL
         for (int e = 0; e < 3; ++e) {
             const double sg = (e == 0) ? 0.0 : (e == 1 ? 1.0 : -1.0);
@@ -209,21 +212,22 @@ MPC_HD void forces_stage_functions(const ForcesQpArgs& A, const double* z, const
 // plain 64-bit pointers the compiler precomputed one address per row (224 pairs of registers), spilled them all to scratch before the
 // iteration loop and reloaded one before every access: 448 scratch stores and a scratch load in front of each of ~1 200 global accesses.
 #if defined(__HIP_DEVICE_COMPILE__)
+// (the descriptor is built ONCE, by the kernel, into the thread state: rebuilt at each of the ~400 access sites it cost three s_mov and an
+//  s_and per site, a quarter of the kernel's scalar instructions.  Rows are Bp * 8 bytes apart: no two 8-byte stores are neighbours, so
+//  the shared descriptor gives the compiler nothing to merge into the unguarded 16-byte form, see ws_store2)
 struct FqWsRef {
-    const ForcesQpArgs& A;
+    const __amdgpu_buffer_rsrc_t& rs;
     uint32_t voff, soff;
     __device__ __forceinline__ operator double() const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(A.ws, A.ws_bytes);
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, mpc_uni(soff), 0));
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, mpc_uni(soff), 0));
     }
     __device__ __forceinline__ double operator=(double x) const {
-        const __amdgpu_buffer_rsrc_t r = mpc_rsrc(A.ws, A.ws_bytes);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), r, (int)voff, mpc_uni(soff), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, x), rs, (int)voff, mpc_uni(soff), 0);
         return x;
     }
     __device__ __forceinline__ double operator=(const FqWsRef& o) const { return (*this = (double)o); }
 };
-#define FQW(k_, row_) FqWsRef{A, ((uint32_t)(k_) * (uint32_t)FQ_ROWS * (uint32_t)A.Bp + (uint32_t)c.b) * 8u, (uint32_t)(row_) * (uint32_t)A.Bp * 8u}
+#define FQW(k_, row_) FqWsRef{c.rs, ((uint32_t)(k_) * (uint32_t)FQ_ROWS * (uint32_t)A.Bp + (uint32_t)c.b) * 8u, (uint32_t)(row_) * (uint32_t)A.Bp * 8u}
 #else
 #define FQW(k_, row_) A.ws[((size_t)(k_) * FQ_ROWS + (size_t)(row_)) * (size_t)A.Bp + (size_t)c.b]
 #endif
@@ -242,8 +246,15 @@ struct FqCtx {
     int it, status;
     double gscale, kkt;
     double rho[7], Phi[28], eps[5];      // what newton_prep hands to the stage's turn in the backward recursion
+    // what a turn of the recursions leaves for the later turns of the same stage -- the corrector's backward turn and both forward turns
+    // reuse the predictor's factorisation.  In the thread's registers: a turn is ONE stage's lanes working while everybody else waits
+    // at the barrier, so a workspace round trip inside it (~2 us to the L2 and back) was most of the turn, 40 times per iteration.
+    double hi[3], Puu[3], Kk[10], Pxu[10], pe[5], kf[2], dx0[5];
     double* loc;         // device: LDS rows [FL_ROWS][T]
     int t, T, IB;        // device: thread index, threads per workgroup, instances per workgroup
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs;           // buffer descriptor of the workspace
+#endif
 };
 struct FqRed { double a, b, c, d; };      // partial of one stage / combined value of one instance (meaning per phase)
 
@@ -311,7 +322,7 @@ MPC_HD void fq_build(const ForcesQpArgs& A, FqCtx& c, FqRed& part) {
         const bool on = fq_row_on(A, k, q);
         FQW(k, FQ_D + q) = on ? d : 0.0;
         FQW(k, FQ_S + q) = on ? fmax(d, 1.0) : 1.0;
-        FQW(k, FQ_LAM + q) = on ? 1.0 / fmax(d, 1.0) : 0.0;          // centred start: s * lam = 1 on every row
+        FQW(k, FQ_LAM + q) = on ? mpc_rcp(fmax(d, 1.0)) : 0.0;          // centred start: s * lam = 1 on every row
     }
     part.a = gs;
 }
@@ -404,7 +415,7 @@ MPC_HD void fq_newton_prep(const ForcesQpArgs& A, FqCtx& c, bool corr, double si
         const double rp = gw + s - d;
         double rc = s * lam;
         if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
-        const double D = lam / s, cf = lam + D * rp - rc / s;
+        const double is = mpc_rcp(s), D = lam * is, cf = lam + D * rp - rc * is;          // (s > 0: one reciprocal per row)
         c.rho[c0] += cf * v0;
         if (n == 3) { c.rho[c1] += cf * v1; c.rho[c2] += cf * v2; }
         if (!corr) {
@@ -417,7 +428,11 @@ MPC_HD void fq_newton_prep(const ForcesQpArgs& A, FqCtx& c, bool corr, double si
         }
     });
     FQ_UNROLL
-    for (int i = 0; i < 5; ++i) c.eps[i] = 0.0;
+    for (int i = 0; i < 5; ++i) {
+        c.eps[i] = 0.0;
+        // (stage 0: the start of the forward sweep, dx_0 = xinit - x_0 of the current iterate)
+        c.dx0[i] = (k == 0) ? -(w[2 + i] - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i])) : 0.0;
+    }
     if (k < N - 1)
         FQ_UNROLL
         for (int i = 0; i < 5; ++i) {
@@ -464,7 +479,7 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
                 FQ_UNROLL
                 for (int j = 0; j < 5; ++j) t += Pp[fq_sidx(i, j)] * eps[j];
                 Pe[i] = t;
-                FQW(k, FQ_PE + i) = t;
+                c.pe[i] = t;
             }
             // the u-rows of C' (P C), column by column: m = column j of P C (5 numbers live at a time, not the 5 x 7 product), then
             // rows 0, 1 of C' against it
@@ -492,7 +507,7 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
             for (int i = 0; i < 5; ++i) q5[i] = Pe[i] + pv[i];
         } else {
             FQ_UNROLL
-            for (int i = 0; i < 5; ++i) q5[i] = (double)FQW(k, FQ_PE + i) + pv[i];
+            for (int i = 0; i < 5; ++i) q5[i] = c.pe[i] + pv[i];
         }
         FQ_UNROLL
         for (int j = 0; j < 7; ++j) {
@@ -508,21 +523,22 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
         FQ_UNROLL
         for (int j = 0; j < 5; ++j) { Pxu[j] = Phi[2 + j]; Pxu[5 + j] = Phi[8 + j]; }
         const double det = Huu[0] * Huu[2] - Huu[1] * Huu[1];
-        hi[0] = Huu[2] / det; hi[1] = -Huu[1] / det; hi[2] = Huu[0] / det;
+        const double idet = 1.0 / det;
+        hi[0] = Huu[2] * idet; hi[1] = -Huu[1] * idet; hi[2] = Huu[0] * idet;
         FQ_UNROLL
         for (int j = 0; j < 5; ++j) {
             Kk[j] = -(hi[0] * Hux[j] + hi[1] * Hux[5 + j]);
             Kk[5 + j] = -(hi[1] * Hux[j] + hi[2] * Hux[5 + j]);
         }
         FQ_UNROLL
-        for (int i = 0; i < 3; ++i) { FQW(k, FQ_HUI + i) = hi[i]; FQW(k, FQ_PHU + i) = Puu[i]; }
+        for (int i = 0; i < 3; ++i) { c.hi[i] = hi[i]; c.Puu[i] = Puu[i]; }
         FQ_UNROLL
-        for (int i = 0; i < 10; ++i) { FQW(k, FQ_K + i) = Kk[i]; FQW(k, FQ_HXU + i) = Pxu[i]; }
+        for (int i = 0; i < 10; ++i) { c.Kk[i] = Kk[i]; c.Pxu[i] = Pxu[i]; }
     } else {
         FQ_UNROLL
-        for (int i = 0; i < 3; ++i) { hi[i] = FQW(k, FQ_HUI + i); Puu[i] = FQW(k, FQ_PHU + i); }
+        for (int i = 0; i < 3; ++i) { hi[i] = c.hi[i]; Puu[i] = c.Puu[i]; }
         FQ_UNROLL
-        for (int i = 0; i < 10; ++i) { Kk[i] = FQW(k, FQ_K + i); Pxu[i] = FQW(k, FQ_HXU + i); }
+        for (int i = 0; i < 10; ++i) { Kk[i] = c.Kk[i]; Pxu[i] = c.Pxu[i]; }
     }
     const double kf0 = -(hi[0] * hu[0] + hi[1] * hu[1]), kf1 = -(hi[1] * hu[0] + hi[2] * hu[1]);
     // Cost-to-go in the symmetric ("Joseph") form: with u = K x + kff and A_cl = A + B K,
@@ -582,9 +598,9 @@ MPC_HD void fq_newton_back(const ForcesQpArgs& A, FqCtx& c, bool corr) {
             }
         }
     }
-    // the step of u_k is finished in the forward sweep; keep kff (in the DW rows for now) and p_k
-    FQW(k, FQ_DW + 0) = kf0;
-    FQW(k, FQ_DW + 1) = kf1;
+    // the step of u_k is finished in the forward sweep; keep kff and p_k
+    c.kf[0] = kf0;
+    c.kf[1] = kf1;
     FQ_UNROLL
     for (int i = 0; i < 5; ++i) FQL(0, PV, i) = pn[i];
 }
@@ -596,13 +612,21 @@ MPC_HD void fq_newton_fwd(const ForcesQpArgs& A, FqCtx& c) {
     const int N = A.N, k = c.k;
     double dx[5];
     FQ_UNROLL
-    for (int i = 0; i < 5; ++i)
-        dx[i] = (k == 0) ? -((double)FQW(0, FQ_W + 2 + i) - ((double)A.xinit[(size_t)c.b * 5 + i] - (double)A.zbar[((size_t)c.b * N) * 7 + 2 + i]))
-                         : (double)FQL(0, DXIN, i);
-    double du[2] = {FQW(k, FQ_DW + 0), FQW(k, FQ_DW + 1)};
+    for (int i = 0; i < 5; ++i) dx[i] = (k == 0) ? c.dx0[i] : (double)FQL(0, DXIN, i);
+    double du[2] = {c.kf[0], c.kf[1]};
     FQ_UNROLL
-    for (int j = 0; j < 5; ++j) { du[0] += (double)FQW(k, FQ_K + j) * dx[j]; du[1] += (double)FQW(k, FQ_K + 5 + j) * dx[j]; }
+    for (int j = 0; j < 5; ++j) { du[0] += c.Kk[j] * dx[j]; du[1] += c.Kk[5 + j] * dx[j]; }
     const double dw[7] = {du[0], du[1], dx[0], dx[1], dx[2], dx[3], dx[4]};
+    if (k < N - 1) {
+        FQ_UNROLL
+        for (int i = 0; i < 5; ++i) {
+            // dx_{k+1} = C dw + eps,  eps = e_k - w_{k+1}[2:7] + C w_k  (newton_prep's: first, so that the next stage's turn can start)
+            double t = c.eps[i];
+            FQ_UNROLL
+            for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * dw[j];
+            FQL(1, DXIN, i) = t;
+        }
+    }
     FQ_UNROLL
     for (int i = 0; i < 7; ++i) FQW(k, FQ_DW + i) = dw[i];
     // new equality multipliers of block k: -(P_k dx_k + p_k)
@@ -612,16 +636,6 @@ MPC_HD void fq_newton_fwd(const ForcesQpArgs& A, FqCtx& c) {
         FQ_UNROLL
         for (int j = 0; j < 5; ++j) t += (double)FQL(0, P, fq_sidx(i, j)) * dx[j];
         FQW(k, FQ_DPI + i) = -t;
-    }
-    if (k < N - 1) {
-        FQ_UNROLL
-        for (int i = 0; i < 5; ++i) {
-            // dx_{k+1} = C dw + eps,  eps = e_k - w_{k+1}[2:7] + C w_k
-            double t = (double)FQW(k, FQ_E + i) - (double)FQW(k + 1, FQ_W + 2 + i);
-            FQ_UNROLL
-            for (int j = 0; j < 7; ++j) t += (double)FQL(0, C, i * 7 + j) * ((double)FQW(k, FQ_W + j) + dw[j]);
-            FQL(1, DXIN, i) = t;
-        }
     }
 }
 
@@ -640,7 +654,7 @@ MPC_HD void fq_newton_rows(const ForcesQpArgs& A, const FqCtx& c, bool corr, dou
         double rc = s * lam;
         if (corr) rc += (double)FQW(k, FQ_DS + q) * (double)FQW(k, FQ_DL + q) - sigma_mu;
         const double ds = -rp - gdw;
-        const double dl = -(rc + lam * ds) / s;
+        const double dl = -(rc + lam * ds) * mpc_rcp(s);
         FQW(k, FQ_DS + q) = ds;
         FQW(k, FQ_DL + q) = dl;
     });
@@ -656,8 +670,8 @@ MPC_HD void fq_steplen(const ForcesQpArgs& A, const FqCtx& c, double frac, FqRed
     for (int q = 0; q < FQ_MI; ++q) {
         if (!fq_row_on(A, k, q)) continue;
         const double s = FQW(k, FQ_S + q), lam = FQW(k, FQ_LAM + q), ds = FQW(k, FQ_DS + q), dl = FQW(k, FQ_DL + q);
-        if (ds < 0) a_p = fmin(a_p, -frac * s / ds);
-        if (dl < 0) a_d = fmin(a_d, -frac * lam / dl);
+        if (ds < 0) a_p = fmin(a_p, -frac * s * mpc_rcp(ds));          // (normal, non-zero denominators: estimate + two Newton steps)
+        if (dl < 0) a_d = fmin(a_d, -frac * lam * mpc_rcp(dl));
     }
     part.a = a_p;
     part.b = a_d;

@@ -1749,6 +1749,9 @@ __global__ void __launch_bounds__(256) k_forces_qp(const ForcesQpArgs A, const i
     c.it = 0; c.status = 0; c.kkt = INFINITY; c.gscale = 1.0;
     c.t = t; c.T = (int)blockDim.x; c.IB = IB;
     c.loc = fq_lds + 4 * blockDim.x;                       // behind the reduction scratch
+#if defined(__HIP_DEVICE_COMPILE__)
+    c.rs = mpc_rsrc(A.ws, A.ws_bytes);
+#endif
     FqRed part, tot;
     fq_build(A, c, part);
     tot = fq_block_reduce(part, FqRed{1.0, 0.0, 0.0, 0.0}, [](FqRed& a, const FqRed& p) { fq_max_combine(a, p); }, fq_lds, IB, N);
@@ -1771,14 +1774,18 @@ __global__ void __launch_bounds__(256) k_forces_qp(const ForcesQpArgs A, const i
                 sigma_mu = sg * sg * sg * mu;
             }
             fq_newton_prep(A, c, corr != 0, sigma_mu);
+            // (the turns hand P_k, p_k, dx_k on through LDS and read nothing but LDS and registers: their barriers order LDS traffic only --
+            //  __syncthreads would also wait for every global store of the turn to be acknowledged, forty times per iteration)
+            __syncthreads();
             for (int step = 0; step < N; ++step) {
                 if (c.k == N - 1 - step) fq_newton_back(A, c, corr != 0);
-                __syncthreads();
+                lds_barrier();
             }
             for (int step = 0; step < N; ++step) {
                 if (c.k == step) fq_newton_fwd(A, c);
-                __syncthreads();
+                lds_barrier();
             }
+            __syncthreads();                 // (the step rows the forward turns stored are read by the row phase below)
             fq_newton_rows(A, c, corr != 0, sigma_mu);
         }
         fq_steplen(A, c, 0.995, part);
