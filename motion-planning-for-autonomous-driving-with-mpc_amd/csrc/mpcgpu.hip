@@ -886,6 +886,55 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 // PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
 // of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
 // wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
+template <int NX> __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm);
+
+// restart of the instance of a one-instance workgroup of k_solve_wg at a level of its second chance: warm start -> tile-major Z, start-point
+// safeguard, start iterate (what k_start does for a block) -- see k_solve_wg<.., RESC>
+template <int NX>
+__device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0, double* lds,
+                                                     int (*or_slots)[8], uint32_t* live_out, const bool carry, const bool from_xs) {
+    using D = Dim<NX>;
+    const int t = threadIdx.x, N = P.N, bx = P.bx;
+    struct { int b, k; } c;
+    c.k = t / bx;
+    c.b = (int)b0 + (t & (bx - 1));
+    const bool valid = (c.k <= N) && (c.b < P.B);
+    if (valid) {
+        constexpr int NZ = D::NZ;
+        double v[MPC_EV(NZ)];
+        // (the scratch of the warm start: the tile-major rows of the cost-to-go, which this kernel does not use)
+        if (carry) {
+            ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
+            ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
+        }
+        if (from_xs) {
+            if (!carry) ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
+        } else {
+            const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
+            const double* xr = P.x0 + (size_t)c.b * nw;
+            v[0] = (c.k < N) ? MPC_GP(xr, 2 * c.k) : 0.0;
+            v[1] = (c.k < N) ? MPC_GP(xr, 2 * c.k + 1) : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v[2 + i] = MPC_GP(xr, 2 * N + NX * c.k + i);
+        }
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prestart_par_block<NX>(P, b0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots, false, live_out);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // RESC: the SECOND CHANCE of an instance that stalls (status 0 / -7: what rescue_dev does on the host, see there) starts inside the running
 // launch, in the wavefront that owns the instance -- one instance per workgroup (bx = 1), so the level's lower bound of the circle rows and
 // its tolerance are the workgroup's own copies of P.ol / P.tol.  An instance that stalls at iteration 4 ... 32 does not wait for the
@@ -896,7 +945,6 @@ struct WgRescue { double ol_raw, relax; int32_t on; };
 constexpr int RESC_LEVELS = 8;          // index q of IS_RLEV: 0 = the first attempt, 1-2 pass 1, 3-7 pass 2
 __device__ __forceinline__ double resc_fraction(int q) { return q == 2 || q == 7 ? 1.0 : q == 4 ? 0.4 : q == 5 ? 0.7 : q == 6 ? 0.9 : 0.0; }
 __device__ __forceinline__ bool resc_last(int q) { return q == 2 || q == 7; }
-template <int NX> __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm);
 
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
@@ -978,40 +1026,12 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                 P.ol = lo - resc.relax * fmax(1.0, fabs(lo));
                 P.tol = resc_last(q) ? tol0 : fmax(tol0, 1e-4);
             }
-            if (valid) {
-                constexpr int NZ = D::NZ;
-                double v[MPC_EV(NZ)];
-                // (the scratch of the warm start: the tile-major rows of the cost-to-go, which this kernel does not use)
-                if (carry) {
-                    ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
-                    ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
-                }
-                if (from_xs) {
-                    if (!carry) ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
-                } else {
-                    const size_t nw = (size_t)2 * N + (size_t)NX * (N + 1);
-                    const double* xr = P.x0 + (size_t)c.b * nw;
-                    v[0] = (c.k < N) ? MPC_GP(xr, 2 * c.k) : 0.0;
-                    v[1] = (c.k < N) ? MPC_GP(xr, 2 * c.k + 1) : 0.0;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) v[2 + i] = MPC_GP(xr, 2 * N + NX * c.k + i);
-                }
-                ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);
+            {
+                // (out of line, on a copy of the parameters: the start-point safeguard and the start iterate inlined here put the hot loop at 512
+                //  registers with scratch -- B = 256 lane following paid 1.7 % for a path it never takes)
+                const PRef Pc = P;
+                wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            prestart_par_block<NX>(P, b0, lds);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots, false, &sh_mask);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fresh = true;
             continue;
         }
