@@ -3,11 +3,12 @@
 consecutive first kernels of a solve (k_start<6>; k_ingest<6> on the unfused path) around a k_pipeline<6> + k_solve_wg<6> pair, with start
 offset, duration and the gap in front of it.
 usage: python tools/solve_timeline.py <kernel_trace.csv> [which solve, default: the 10th such]"""
+import re
 import csv, sys
 
 def short(k):
     k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
-    return k.replace("<6, false>", "<6>")          # (template arguments that do not matter here)
+    return re.sub(r"<(\d)(, \w+)+>", lambda m: "<" + m.group(1) + ">", k)          # (template arguments that do not matter here: kernel variant, second chance)
 
 rows = []
 with open(sys.argv[1]) as fh:

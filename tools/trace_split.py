@@ -8,6 +8,7 @@ headline configuration's iteration loop split by what they ran -- one kernel nam
                   on its own it solves a small batch alone (configuration 2, the sub-batches of a second chance); split by the
                   kernel that ran just before it
 usage: python tools/trace_split.py <kernel_trace.csv>"""
+import re
 import csv
 import sys
 from collections import defaultdict
@@ -15,7 +16,7 @@ from collections import defaultdict
 
 def short(k):
     k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
-    return k.replace("<6, false>", "<6>").replace("<5, false>", "<5>")       # (round 4: the loop kernels carry a second template argument, the `pair` variant)
+    return re.sub(r"<(\d)(, \w+)+>", lambda m: "<" + m.group(1) + ">", k)          # (template arguments that do not matter here: kernel variant, second chance)
 
 
 def main(path):
