@@ -148,7 +148,7 @@ MPC_HD uint32_t ws_index(const Params& P, const int32_t*, uint32_t row, uint32_t
 typedef unsigned int mpc_v2u __attribute__((ext_vector_type(2)));
 // buffer descriptor over a workspace; base pointer and scalar offsets pass through readfirstlane so that the compiler
 // can PROVE they are wave-uniform (otherwise each buffer op is wrapped in a waterfall loop)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t mpc_rsrc(const void* base, uint32_t bytes) {
+__host__ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mpc_rsrc(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)(uintptr_t)base;
     uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
@@ -163,7 +163,8 @@ __device__ __forceinline__ int mpc_uni(uint32_t v) { return __builtin_amdgcn_rea
 // s_mov + one s_and per site.)
 struct DevParams : Params {
     __amdgpu_buffer_rsrc_t rws, riws;
-    __device__ __forceinline__ explicit DevParams(const Params& q) : Params(q), rws(mpc_rsrc(q.WS, q.ws_bytes)), riws(mpc_rsrc(q.IWS, q.iws_bytes)) {}
+    // (host + device: host functions of a translation unit are type-checked in the device pass too, e.g. the host-side reference of tools/ubench)
+    __host__ __device__ __forceinline__ explicit DevParams(const Params& q) : Params(q), rws(mpc_rsrc(q.WS, q.ws_bytes)), riws(mpc_rsrc(q.IWS, q.iws_bytes)) {}
 };
 typedef DevParams PRef;
 struct WsRefD {          // element of the double workspace: converts to double (load) / assigns from double (store)

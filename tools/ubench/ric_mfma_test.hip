@@ -11,8 +11,9 @@
 using namespace mpc;
 
 template <int NX, int NI>
-__global__ void __launch_bounds__(64) k_test(const Params P, const double* recs /*[NI][N+1][Rec::SIZE]*/, const double* c0 /*[NI][NX]*/, const double* hux /*[NI][2]*/,
+__global__ void __launch_bounds__(64) k_test(const Params Pk, const double* recs /*[NI][N+1][Rec::SIZE]*/, const double* c0 /*[NI][NX]*/, const double* hux /*[NI][2]*/,
                                              const double* dlast, double* kout /*[NI][N][16]*/, unsigned long long* clk, int* okout, double* dout) {
+    const PRef P(Pk);
 #if defined(__HIP_DEVICE_COMPILE__)
     using RC = Rec<NX>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -107,7 +108,8 @@ static int run(int N, int NI, bool nonconvex) {
     (void)hipMemcpy(clk.data(), d_clk, clk.size() * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(okv.data(), d_ok, NI * 4, hipMemcpyDeviceToHost);
     (void)hipMemcpy(dout.data(), d_do, NI * 8, hipMemcpyDeviceToHost);
     // host reference
-    Params Ph{}; Ph.dt = dt; Ph.N = N;
+    Params Ph0{}; Ph0.dt = dt; Ph0.N = N;
+    const PRef Ph(Ph0);          // (what the phase functions take: on the device the parameters plus the buffer descriptors, on the host the parameters)
     double eP = 0, ep = 0, eK = 0, eD = 0; int bad = 0;
     auto wsat = [&](const double* base, int rows_ev, int k, int e, int b) { return base[((size_t)b * (N + 1) + k) * rows_ev + e]; };
     for (int b = 0; b < NI; ++b) {

@@ -18,8 +18,9 @@ __global__ void __launch_bounds__(64) k_scalar(double* out, int stages, unsigned
     constexpr int NX = 6;
     using D = Dim<NX>;
     const int lane = threadIdx.x;
-    Params P{};
-    P.dt = 0.1;
+    Params P0{};
+    P0.dt = 0.1;
+    const PRef P(P0);
     RicStage<NX> s;
     for (int i = 0; i < D::NS; ++i) s.H[i] = 0.0;
     for (int i = 0; i < NX; ++i) { s.H[D::sidx(i, i)] = 2.0 + 0.01 * lane + i; s.gx[i] = 0.1 * i; s.cn[i] = 1e-3 * (i + lane); }
