@@ -1,6 +1,6 @@
 """One timing sample of the headline solve with the library that is in place (A/B comparisons on one box: tools/ab_bench.sh copies
 variants of libmpcgpu.so over the built one and calls this in fresh processes, alternating).
-Usage (GPU box): python tools/ab_time.py [B] [family] [tag]"""
+Usage (GPU box): [MPC_AB_OPTS="option=value ..."] python tools/ab_time.py [B] [family] [tag]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -21,6 +21,9 @@ else:
 s = make_solver(cfg)
 if fam == "ca":
     set_cfg_bounds(s, cfg)
+for e in os.environ.get("MPC_AB_OPTS", "").split():          # option=value pairs, e.g. MPC_AB_OPTS="hybrid_live=40"
+    k_, v_ = e.split("=")
+    s.set_option(k_, v_)
 d = [torch.from_numpy(a).cuda() for a in (x0, p)]
 out = torch.empty_like(d[0]); st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty_like(st); kk = torch.empty(B, dtype=torch.float64, device="cuda")
 def step():
