@@ -36,6 +36,22 @@ def test_matches_oracle(fam):
     assert r.kkt.max() <= 1e-8
 
 
+@pytest.mark.parametrize("fam,B", [("zamlf_n30_nx6", 4096), ("usalf_n50_nx5", 2048), ("zamlf_n30_nx5", 2048), ("zamlf_n10_nx5", 4096)])
+def test_every_instance_of_a_full_batch_against_the_oracle(fam, B):
+    """BASELINE.json's metric configuration (N = 30, nx = 6, B = 4096) and the other lane-following families at full batch sizes: EVERY
+    instance against the C oracle -- same iteration count, |x - x_oracle| <= 1e-8, same status -- on the default path (variant 2 of the
+    kernels, hybrid solve, device math helpers); north_star asks for 1e-4 against IPOPT, the oracle restates IPOPT's algorithm"""
+    cfg, kw = FAMILIES[fam]
+    x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    r = s.solve(x0, p)
+    ro = OracleSolver(cfg).solve_batch(x0, p, nthreads=16)
+    assert np.all(r.status == 1) and np.all(ro["status"] == 1)
+    assert np.array_equal(r.iters, ro["iters"])
+    assert np.abs(r.x - ro["x"]).max() < TOL_ORACLE
+
+
 @pytest.mark.parametrize("fam", [f"{w}_n{n}_nx5" for w in ("zamlf", "usalf", "zamca", "first") for n in (10, 30, 50)] + ["zamlf_n30_nx6"])
 def test_matches_golden_optima(golden_dir, fam):
     """the grid of SURVEY.md section 8(c): optima from COLD starts of two scipy solvers (none seeded by the oracle or the kernels);
