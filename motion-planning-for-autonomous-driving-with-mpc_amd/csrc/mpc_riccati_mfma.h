@@ -173,6 +173,7 @@ __device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, int lane, doubl
 struct MfmaInst {
     uint32_t inst;             // instance (its cost-to-go and step go to the instance-major mailbox arrays MPK / MDZ of the workspace)
     double delta_last;
+    bool sym_hint;             // keep the cost-to-go symmetric whatever delta_last says (IS_ILL: a circle row with a large weight)
 };
 
 // x + (x with the two halves of every 16-lane row exchanged): the sum over the block index hi, left in both halves
@@ -220,7 +221,7 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
         delta[q] = 0.0;
         need[q] = true;
         ok[q] = false;
-        sym[q] = in[q].delta_last != 0.0;
+        sym[q] = in[q].delta_last != 0.0 || in[q].sym_hint;
         pkb[q] = mpc_uni(pk_arr + in[q].inst * (uint32_t)(N + 1) * PKS);
     }
     for (;;) {

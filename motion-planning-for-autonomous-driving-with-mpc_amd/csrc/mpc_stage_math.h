@@ -62,6 +62,11 @@ constexpr double ROLLOUT_FACTOR = 10.0;   // start-point safeguard, see prestart
 // Newton steps, which only reduce the dual infeasibility)
 constexpr double THETA_FLOOR = 1e-10;
 constexpr double EPS10 = 10.0 * 2.220446049250313e-16;
+// Circle rows that are active late in the iteration put weights z / s of 1e10 ... 1e13 into the condensed Hessian; the wave-per-instance
+// MFMA sweep reads its cost-to-go transposed where a product wants it so, and a matrix that is symmetric only up to 1e-16 x 1e12 then
+// costs the collision-avoidance family iterations (mean 25.6 against 24.5, and most of its instances that wander to the iteration limit:
+// profiles/r04_ca_lottery.txt).  Instances with such a row are symmetrised every stage, like the ones that ever needed an inertia correction.
+constexpr double ILL_WEIGHT = 1e4;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) const double* mpc_lds_cptr;
@@ -81,6 +86,7 @@ enum ScRow {
     SC_COUNT
 };
 enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW,
+             IS_ILL,                      // a circle row of the instance carries a large weight z / s (set by the stage phases of k_solve_wg, sticky): its MFMA sweeps keep the cost-to-go symmetric
              IS_RLEV, IS_ITACC,           // second chance inside k_solve_wg: level index (| 0x100: a level of this pass has converged), iterations of the attempts so far
              IS_COUNT };
 struct Params {
@@ -545,6 +551,7 @@ struct Ctx {
     bool fric_row;   // stage-0 friction row kept as a row (false: presolved into the bounds a0lb/a0ub of a_0)
     double a0lb, a0ub;
     bool conv;       // fixed-iteration (benchmark) mode: tolerance already reached, steps are accepted as they come
+    bool ill;        // a circle row of this stage has a weight z / s above ILL_WEIGHT at the new iterate (phase_ineq_assemble)
     mpc_lds_cptr bnd;                        // LDS copy of the bounds table [LB (N+1)*NZ | UB (N+1)*NZ] (device)
     int bnd_ub;
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
@@ -952,6 +959,7 @@ MPC_HD void phase_init_scalars(const PRef& P, Ctx<NX>& c, const Red0& red) {
         MPC_S(P.ISC, IS_HAVETH0) = 0;
         MPC_S(P.ISC, IS_CONV) = 0;
         MPC_S(P.ISC, IS_ITERS) = 0;
+        MPC_S(P.ISC, IS_ILL) = 0;
     }
 }
 
@@ -962,6 +970,7 @@ template <int NX>
 MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
     c.status = 0;
     c.active = false;
+    c.ill = false;
     if (!c.valid) return;
     // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
     const int32_t status = MPC_S(P.ISC, IS_STATUS), nfilt = MPC_S(P.ISC, IS_NFILT), iters = MPC_S(P.ISC, IS_ITERS);
@@ -1424,6 +1433,7 @@ MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp,
         double sg = 0.0, gbb = 0.0, rs = -nu;
         if (MPC_HAS_OL) side_kkt(s - P.ol, REUSE ? c.iglo[j] : mpc_rcp(s - P.ol), c.zlo[j], 1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
         if (MPC_HAS_OU) side_kkt(P.ou - s, REUSE ? c.iguo[j] : mpc_rcp(P.ou - s), c.zuo[j], -1.0, m, sg, gbb, rs, kp.cmin, kp.cmax, kp.sz, kp.gp);
+        if (m * sg > ILL_WEIGHT) c.ill = true;
         kp.dual = fmax(kp.dual, fabs(rs));
         const double res = dist - s;
         kp.theta += m * fabs(res);

@@ -169,6 +169,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     c.b = (int)b0 + (t & (bx - 1));
     c.valid = (c.k <= P.N) && (c.b < P.B);
     c.active = false;
+    c.ill = false;
     c.status = 0;
     c.iters = 0;
 #define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -243,6 +244,13 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     MPC_STAMP(7);
     Red3 r3;
     phase_eval_assemble<NX, !INIT, MB, VM>(P, c, r3);
+    if (MB && !INIT) {
+        // the instance's stage threads of this wavefront vote; the first of them leaves the (sticky) mark for the MFMA sweeps
+        const unsigned long long bal = __ballot((c.active && c.ill) ? 1 : 0);
+        // (lanes of this thread's instance column: every bx-th lane -- bx is a power of two)
+        const unsigned long long col = (bx >= 64 ? 1ull : ~0ull / ((1ull << bx) - 1ull)) << (t & (bx - 1));
+        if (bal != 0ull && c.active && (bal & col) != 0ull && ((t & 63) < bx)) MPC_S(P.ISC, IS_ILL) = 1;
+    }
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
@@ -1094,6 +1102,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                 const int bb = (int)b0 + g;
                 in.inst = (uint32_t)bb;
                 in.delta_last = MPC_UB(P.SC, (uint32_t)SC_DLAST, bb);
+                in.sym_hint = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, bb) != 0;
                 // x~_0 = (-c_0, 0.., 1) as B operand of the forward sweep (requested now, needed after the backward sweep)
                 x0 = 0.0;
                 if ((lane & 3) == 0) {

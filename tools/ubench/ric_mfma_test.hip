@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(64) k_test(const Params Pk, const double* recs
         const int b = inst * NI + q;
         in[q].inst = (uint32_t)b;
         in[q].delta_last = dlast[b];
+        in[q].sym_hint = false;
         rec[q] = (mpc_lds_ptr)(lp)lrec + q * (N + 1) * stride;
         x0[q] = 0.0;
         if ((lane & 3) == 0) x0[q] = (m.Rb < NX) ? -c0[b * NX + m.Rb] : (m.Rb == 7 ? 1.0 : 0.0);
