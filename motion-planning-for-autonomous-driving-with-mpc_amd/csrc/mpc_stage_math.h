@@ -83,11 +83,13 @@ enum ScRow {
     SC_C0,                       // 6 rows: c_0 = x_0 - r_0
     SC_ALPHA = SC_C0 + 6, SC_ADU, SC_PHI, SC_NTRIAL,
     SC_A0LB, SC_A0UB,            // per-instance bounds of a_0 (stage-0 friction row presolved into a bound)
+    SC_E0S,                      // second chance inside k_solve_wg: the KKT error the first attempt stopped at (given back with its row when every level fails)
     SC_COUNT
 };
 enum IsRow { IS_STATUS = 0, IS_ITERS, IS_NFILT, IS_HAVETH0, IS_CONV, IS_ROLL, IS_FROW,
              IS_ILL,                      // a circle row of the instance carries a large weight z / s (set by the stage phases of k_solve_wg, sticky): its MFMA sweeps keep the cost-to-go symmetric
-             IS_RLEV, IS_ITACC,           // second chance inside k_solve_wg: level index (| 0x100: a level of this pass has converged), iterations of the attempts so far
+             IS_RLEV, IS_ITACC,           // second chance inside k_solve_wg: level index (| 0x100: a level of this pass has converged; | 0x200: the first attempt stopped with
+                                          // status -7, else 0; bits 16-30: its iteration count), iterations of the attempts that count so far
              IS_COUNT };
 struct Params {
     int32_t B, Bp, N, nx, bx;    // instances, padded instances (multiple of 64), horizon, states, instances/block

@@ -269,6 +269,10 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
 #undef MPC_STAMP
 }
 
+#ifndef MPC_WITH_PAIR
+#define MPC_WITH_PAIR 0     // 1: also build variant 1 of k_pipeline / k_solve_wg (two threads per (instance, stage), option pair) -- measured 40-70 % slower
+#endif                      //    (profiles/r04_stage_split.txt); kept as source for the record, not part of the default library
+#if MPC_WITH_PAIR
 // ---------------------------------------------------------------------------------------------------------------
 // stage_pair: the same share of an iteration as stage_block<NX, false>, with TWO threads per (instance, stage) -- the model thread
 // (ROLE_A: threads [0, T) of the workgroup) and the barrier thread (ROLE_B: threads [T, 2 T)); T is a multiple of 64, so the role is
@@ -389,6 +393,9 @@ __device__ __forceinline__ void stage_pair(const PRef& P, const int n_mult, cons
     else stage_pair_role<NX, MB, ROLE_B>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
 }
 
+#else
+template <int NX> __host__ __device__ constexpr int pair_rows() { return 0; }
+#endif
 // VM: bound structure compiled into the phases (0xFF: looked up at run time; REF_VM: the reference's -- every path of a handle uses the
 // same instantiation of the phases, so that the pipeline, its fallback of one launch per kernel and the closed loop's replay give the same bits)
 template <int NX, bool INIT, int MAXT, uint32_t VM = 0xFFu>
@@ -681,7 +688,7 @@ struct PipeArgs {
 constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
 constexpr uint32_t PIPE_STATS = PIPE_ABORT + 2;         // [wait ticks riccati, wait ticks stage, busy ticks stage, items, workers stage, workers riccati]
-constexpr uint32_t PIPE_WG = PIPE_ABORT + 16;           // statistics of the k_solve_wg launch behind the pipeline (4 words): zeroed and copied back with the block
+constexpr uint32_t PIPE_WG = PIPE_ABORT + 16;           // statistics of the k_solve_wg launch behind the pipeline (5 words: rounds max, rounds, sweeps, instance-rounds, rescued): zeroed and copied back with the block
 constexpr uint32_t PIPE_HDR = PIPE_ABORT + 24;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
 constexpr uint32_t PIPE_EXIT = 0xFFFFFFFFu;
 constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-clock ticks = 50 ms
@@ -852,8 +859,11 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
+#if MPC_WITH_PAIR
         if (VAR == 1) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256, false, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        else
+#endif
+        stage_block<NX, false, 256, false, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
@@ -900,7 +910,7 @@ template <int NX> __device__ __forceinline__ void prestart_par_block(const PRef&
 // safeguard, start iterate (what k_start does for a block) -- see k_solve_wg<.., RESC>
 template <int NX>
 __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0, double* lds,
-                                                     int (*or_slots)[8], uint32_t* live_out, const bool carry, const bool from_xs) {
+                                                     int (*or_slots)[8], uint32_t* live_out, const bool carry, const bool from_xs, const bool keep_first, const bool first_tiled) {
     using D = Dim<NX>;
     const int t = threadIdx.x, N = P.N, bx = P.bx;
     struct { int b, k; } c;
@@ -910,6 +920,16 @@ __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_
     if (valid) {
         constexpr int NZ = D::NZ;
         double v[MPC_EV(NZ)];
+        static_assert(2 * MPC_EV(NZ) <= D::NPK, "two iterates fit the cost-to-go rows of a stage");
+        // (first level: the iterate the first attempt stopped at is kept -- behind the warm start in the same scratch rows --, with its KKT
+        //  error; should every level fail, the caller gets that row back, as from rescue_dev: wg_restore_first)
+        if (keep_first) {
+            // (an instance that came out of the pipeline stalled has never been taken over: its iterate is still tile-major)
+            if (first_tiled) ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);
+            else ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
+            ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, MPC_EV(NZ) + e)), v);
+            if (c.k == 0) MPC_S(P.SC, SC_E0S) = (double)MPC_S(P.SC, SC_E0);
+        }
         // (the scratch of the warm start: the tile-major rows of the cost-to-go, which this kernel does not use)
         if (carry) {
             ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
@@ -937,6 +957,33 @@ __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots, false, live_out);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// every level of the second chance has failed: the instance goes back to the caller as its FIRST attempt left it (row, status, iteration
+// count, KKT error) -- what rescue_dev does by writing back converged rows only
+template <int NX>
+__device__ __attribute__((noinline)) void wg_restore_first(const PRef& P, const uint32_t b0, const int st0, const int it0) {
+    using D = Dim<NX>;
+    constexpr int NZ = D::NZ;
+    const int t = threadIdx.x, bx = P.bx;
+    struct { int b, k; } c;
+    c.k = t / bx;
+    c.b = (int)b0 + (t & (bx - 1));
+    if (c.k <= P.N && c.b < P.B) {
+        double v[MPC_EV(NZ)];
+        ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, MPC_EV(NZ) + e)), v);
+        ws_store_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);          // (the hand-back at the end of the kernel copies these rows ...
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);             //  ... unless no level ever got a round: then these are what k_egest reads)
+        if (c.k == 0) {
+            MPC_S(P.SC, SC_E0) = (double)MPC_S(P.SC, SC_E0S);
+            MPC_S(P.ISC, IS_STATUS) = st0;
+            MPC_S(P.ISC, IS_ITERS) = it0;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1002,22 +1049,24 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                     const int st = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb), it = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb);
                     const int lev = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb);
                     const int q = lev & 0xFF;
-                    int has_xs = lev >> 8;
-                    const int acc = (q == 0 ? 0 : (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITACC, bb)) + it;
+                    int has_xs = (lev >> 8) & 1, first = lev & ~0x1FF;                  // (first: status and iteration count of the first attempt)
+                    int acc = (q == 0 ? 0 : (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITACC, bb)) + it;
                     if (q == 0) {
-                        if (st == 0 || st == -7) { next = 1; if (stats != nullptr) atomicAdd(stats + 4, 1u); }
+                        if (st == 0 || st == -7) { next = 1; first = (st == -7 ? 0x200 : 0) | (it << 16); if (stats != nullptr) atomicAdd(stats + 4, 1u); }
                     } else {
                         if (st == 1) { carry = 1; has_xs = 1; }
                         if (!resc_last(q)) next = q + 1;
-                        else if (st != 1 && q == 2) { next = 3; has_xs = 0; }          // pass 2 starts over from the caller's x0
+                        // pass 2 starts over from the caller's x0; the levels of a pass that ended open are not counted (rescue_dev: k_rescue_gather)
+                        else if (st != 1 && q == 2) { next = 3; has_xs = 0; acc = first >> 16; }
                     }
                     if (next >= 0) {
-                        MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb) = next | (has_xs << 8);
+                        MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb) = next | (has_xs << 8) | first;
                         MPC_UB(P.ISC, (uint32_t)IS_ITACC, bb) = acc;
+                        next |= has_xs << 8;
                     } else if (q != 0) {
-                        MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb) = acc;                   // (what the caller is told: all attempts together)
+                        if (st == 1) MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb) = acc;      // (what the caller is told: the first attempt and the levels of the pass that brought it in)
+                        else next = -2 - ((first >> 9) & 1) - 2 * (first >> 16);       // every level failed: -2 - (first status was -7) - 2 * (its iterations)
                     }
-                    next = next < 0 ? -1 : (next | (has_xs << 8));
                 }
                 sh_next[0] = next;
                 sh_next[1] = carry;
@@ -1025,6 +1074,11 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
             lds_barrier();
             const int nx_lev = sh_next[0], carry = sh_next[1];
             lds_barrier();
+            if (nx_lev <= -2) {
+                const int code = -2 - nx_lev;
+                const PRef Pc = P;
+                wg_restore_first<NX>(Pc, b0, (code & 1) ? -7 : 0, code >> 1);
+            }
             if (nx_lev < 0) break;
             const int q = nx_lev & 0xFF;
             const bool from_xs = (nx_lev >> 8) != 0;
@@ -1038,7 +1092,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                 // (out of line, on a copy of the parameters: the start-point safeguard and the start iterate inlined here put the hot loop at 512
                 //  registers with scratch -- B = 256 lane following paid 1.7 % for a path it never takes)
                 const PRef Pc = P;
-                wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs);
+                wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
             }
             fresh = true;
             continue;
@@ -1160,8 +1214,11 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
         WG_STAMP(14);
         // ---- the stage work of the round
         if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
+#if MPC_WITH_PAIR
         if (VAR == 1) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
-        else stage_block<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
+        else
+#endif
+        stage_block<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2083,7 +2140,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
-    else if (n == "pair") k.pair = value == nullptr ? 0 : (int)iv;
+    else if (n == "pair") { if (iv != 0 && value != nullptr && !MPC_WITH_PAIR) return MPC_ERR_INVALID; k.pair = value == nullptr ? 0 : (int)iv; }   // (variant 1 is only there in a -DMPC_WITH_PAIR=1 build)
     else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
     else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
     else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
@@ -2287,7 +2344,7 @@ int mpc_set_profiling(mpc_handle* h, int32_t enable) {
 int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
     if (!h || !name) return MPC_ERR_INVALID;
     const int rc = set_knob(h->knobs, name, value);
-    if (rc) h->err = std::string("unknown option: ") + name;
+    if (rc) h->err = std::string("unknown option (or a value this build does not support): ") + name;
     else apply_fric_literal(h->hp, h->knobs.friction_lb);
     return rc;
 }
@@ -2360,9 +2417,13 @@ static bool wants_mailbox(const mpc_handle* h) {
 static int ensure_ws(mpc_handle* h, size_t Bp) {
     const bool mb = wants_mailbox(h);
     if (Bp <= h->cap_Bp && (!mb || h->ws_mailbox)) return MPC_OK;
+    const size_t Bp_req = Bp;
     Bp = std::max(Bp, h->cap_Bp);                      // (grow only: also when all that changes is the mailbox section)
     free_ws(h);
-    const WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp, mb);
+    WsLayout w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp, mb);
+    // (a handle that grew close to the limit WITHOUT the mailbox section and now needs one: what was asked for fits -- max_rows_per_solve
+    //  has chunked the batch for the layout with the mailbox -- the old capacity with the section added may not)
+    if (w.total * sizeof(double) >= ((size_t)1 << 32) && Bp_req < Bp) { Bp = Bp_req; w = ws_layout(h->hp.desc.N, h->hp.desc.nx, Bp, mb); }
     if (w.total * sizeof(double) >= ((size_t)1 << 32)) {
         h->err = "batch too large: the workspace must stay below 4 GiB (32-bit buffer offsets); split the batch";
         return MPC_ERR_INVALID;
@@ -2473,8 +2534,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+#if MPC_WITH_PAIR
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+#endif
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -2595,7 +2658,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
     // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
-    auto wg_pair = [&](int bxw) { return kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
+    auto wg_pair = [&](int bxw) { return MPC_WITH_PAIR && kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
     auto wg_lds = [&](int bxw) {
         const int thr = ((S * bxw + 63) / 64) * 64;
         if (wg_pair(bxw))
@@ -2615,8 +2678,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const int thr = ((S * bxw + 63) / 64) * 64;
         WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
         const dim3 grid((B + bxw - 1) / bxw);
-        if (wg_pair(bxw)) hipLaunchKernelGGL((k_solve_wg<NX, true>), grid, dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
-        else if (wg_resc(bxw)) {
+#if MPC_WITH_PAIR
+        if (wg_pair(bxw)) { hipLaunchKernelGGL((k_solve_wg<NX, true>), grid, dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs); return; }
+#endif
+        if (wg_resc(bxw)) {
             rs.on = 1;
             h->resc_in_kernel = true;
             if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
@@ -2701,7 +2766,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
         // two threads per (instance, stage) in the stage workers (option pair): 512-thread workgroups
         const size_t lds_pair = ((size_t)(2 * nw) * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * threads) * sizeof(double);
-        const bool pipe_pair = kn.pair != 0 && pair_vm_ok && 2 * threads <= 512 && lds_pair <= lds_max;
+        const bool pipe_pair = MPC_WITH_PAIR && kn.pair != 0 && pair_vm_ok && 2 * threads <= 512 && lds_pair <= lds_max;
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
@@ -2740,8 +2805,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 P.DBG = d_pdbg;
             }
             prof.begin(3, stream);
+#if MPC_WITH_PAIR
             if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else
+#endif
+            if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
@@ -2772,6 +2840,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
             for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
+            if (h->resc_in_kernel) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
             if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
                 h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = (B + hyb_bx - 1) / hyb_bx;
                 h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
@@ -2780,6 +2849,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
                 // through an iteration, so start over with one launch per kernel -- and stay there for this handle
                 h->pipe_disabled = true;
+                h->resc_in_kernel = false;         // (the k_solve_wg behind the abandoned launch returned at once: no instance has had its second chance)
                 fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired); re-running with one launch per kernel\n");
                 return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
             }
