@@ -37,18 +37,7 @@
 
 namespace mpc {
 
-// LDS record of one (instance, stage), in doubles: the stage block as phase_finish stores it (BLK rows; the defect negated), three
-// constants for the "no entry" / identity / dt offsets, and the gain rows the backward sweep leaves for the forward sweep
-template <int NX>
-struct Rec {
-    using D = Dim<NX>;
-    static constexpr int A = D::B_A, RUU = D::B_RUU, GU = D::B_GU, NCN = D::B_CN, GX = D::B_GX, H = D::B_H;
-    static constexpr int ZERO = D::NBLK, ONE = ZERO + 1, DT = ZERO + 2;
-    static constexpr int K0 = (DT + 2) & ~1, K1 = K0 + 8;        // Kt rows: [K0 (NX) | 0.. | kff0], [K1 | .. | kff1]
-    static constexpr int HX = K1 + 8;                            // 2: Hux of stage 0 (zero in every other stage)
-    static constexpr int DUMMY = HX + 2;                         // target of the lanes that have no gain entry to write
-    static constexpr int SIZE = DUMMY + 2;
-};
+// (the LDS record of one (instance, stage) -- stage block, gains, cost-to-go, step -- is Rec<NX> of mpc_stage_math.h)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 
@@ -85,10 +74,10 @@ struct MfmaLane {
     int oB[2], oAA[2], oHC, oHA;        // backward: At as B operand of Y (per block column J) / as transposed A operand of T (per k-step), Ht, [Hux | gu]
     int oF1, oF2;                       // forward: A operand = rec[oF1] + fscale * rec[oF2]
     double fscale, dmask;               // dmask: 1 on the diagonal of the state block (delta_w goes there)
-    int pk_row;                         // row of the PK array this lane stores (P_k upper triangle, p_k), or -1
+    int pk_row;                         // entry of the cost-to-go this lane stores (P_k upper triangle, p_k: slot Rec::PK + pk_row of the stage's record), or -1
     int tr_addr;                        // byte address of the transposed lane (ds_bpermute), for the symmetrisation
     int k_off;                          // backward: where this lane writes its entry of Kt (or the dummy slot)
-    int dz_row;                         // forward: row of the DZ array this lane stores (du: 0, 1; dx: 2 + R), or -1
+    int dz_row;                         // forward: entry of the step this lane stores (du: 0, 1 -> Rec::DU; dx: 2 + R -> Rec::DX of the NEXT record), or -1
     bool dz_next;                       // ... of stage k + 1 (the dx lanes)
     int fix;                            // forward: 0 = keep the product, 1 = coordinate forced to 0 (spare row), 2 = forced to 1 (affine coordinate)
     int R, C, Rb;                       // natural row / column; row of x~ this lane carries as B operand of the forward sweep
@@ -171,7 +160,7 @@ __device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, int lane, doubl
 
 // What the sweeps need to know about the instance (wave-uniform)
 struct MfmaInst {
-    uint32_t inst;             // instance (its cost-to-go and step go to the instance-major mailbox arrays MPK / MDZ of the workspace)
+    uint32_t inst;             // instance
     double delta_last;
     bool sym_hint;             // keep the cost-to-go symmetric whatever delta_last says (IS_ILL: a circle row with a large weight)
 };
@@ -186,8 +175,10 @@ __device__ __forceinline__ double wv_sum_hi(double v) {
 // ---- backward sweeps of NI instances of one wavefront, interleaved (independent dependency chains in one instruction stream: the
 // wavefront issues in order, so a second instance fills the latencies of the first).  ok[q] = false: no admissible delta_w (status -7).
 // rec[q]: LDS records of instance q, stage k at rec[q] + k * Rec::SIZE; one more record in FRONT of every instance's records must be
-// readable (the operand prefetch of stage 0 reads "stage -1").  dump: 64 doubles of LDS the lanes without a gain entry may write.  Writes the Kt rows into the records and P_k / p_k into the PK rows of the workspace (lanes
-// without an entry write row 0 of the KK array, which this path does not use: no divergent store).
+// readable (the operand prefetch of stage 0 reads "stage -1").  dump: 64 doubles of LDS the lanes without an entry may write.  Writes
+// the Kt rows and the cost-to-go P_k / p_k into the records -- the cost-to-go over the Ruu / gu / gx / H entries of the stage, which the
+// sweep has in registers by then (Rec) -- nothing goes to memory.  rebuild(): called before a sweep is REPEATED with a larger delta_w;
+// must put the stage blocks back into the records of all NI instances.
 //
 // One stage, with M = M+ in natural layout (symmetric: as A operand its block (hi, lo) is read as M_{lo, hi}):
 //   column block J of Y = M+ At:  D = mfma(M, At_{hi, J}) gives M_{lo, hi} At_{hi, J} in block (hi, lo); the sum over hi (one DPP row
@@ -195,36 +186,34 @@ __device__ __forceinline__ double wv_sum_hi(double v) {
 //   B operands of T = At' Y + Ht: k-step K needs Y_{K, lo}: banks of S_0 / S_1 merged by one DPP each
 //   Gt rows come down from rows 2, 3 of the first of them (v_permlane32_swap) already replicated over hi, so Kt = -Lam^-1 Gt is the B
 //   operand of the rank-2 update as it stands and Gt' needs ONE bank move
-template <int NX, int NI>
+template <int NX, int NI, class Rebuild>
 __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
-                                              int lane, mpc_lds_ptr dump, double (&delta)[NI], bool (&ok)[NI], uint32_t& sweeps) {
+                                              int lane, mpc_lds_ptr dump, double (&delta)[NI], bool (&ok)[NI], uint32_t& sweeps, Rebuild&& rebuild) {
     using RC = Rec<NX>;
     using D = Dim<NX>;
     const int N = P.N;
     const double dt = P.dt, dt2 = dt * dt;
-    const __amdgpu_buffer_rsrc_t rsrc = P.rws;
-    constexpr uint32_t PKS = MPC_EV(D::NPK) * 8u;                         // bytes per stage of the mailbox PK rows
-    const uint32_t pk_arr = (uint32_t)(uintptr_t)P.MPK - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
-    const uint32_t pk_lane = m.pk_row >= 0 ? (uint32_t)m.pk_row * 8u + (uint32_t)N * PKS : 0u, pk_inc = m.pk_row >= 0 ? PKS : 0u;
     const int x = lane >> 4;
-    // where a lane writes its entry of Kt, as an offset from the records of the instance: the writers walk down the stages, the others
-    // stay on their own double of the dump area (a shared dummy address would serialise 48 lanes on one LDS bank)
-    const bool writer = m.k_off != RC::DUMMY;
-    const int w_inc = writer ? RC::SIZE : 0;
-    int w_first[NI];
+    // where a lane writes its entry of Kt / of the cost-to-go, as an offset from the records of the instance: the writers walk down the
+    // stages, the others stay on their own double of the dump area (a shared dummy address would serialise them on one LDS bank)
+    const bool writer = m.k_off != RC::DUMMY, pwriter = m.pk_row >= 0;
+    const int w_inc = writer ? RC::SIZE : 0, p_inc = pwriter ? RC::SIZE : 0;
+    int w_first[NI], p_first[NI];
 #pragma unroll
-    for (int q = 0; q < NI; ++q) w_first[q] = writer ? N * RC::SIZE + m.k_off : (int)(dump - rec[q]) + lane;
+    for (int q = 0; q < NI; ++q) {
+        w_first[q] = writer ? N * RC::SIZE + m.k_off : (int)(dump - rec[q]) + lane;
+        p_first[q] = pwriter ? N * RC::SIZE + RC::PK + m.pk_row : (int)(dump - rec[q]) + lane;
+    }
     bool need[NI], sym[NI];
-    int pkb[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         delta[q] = 0.0;
         need[q] = true;
         ok[q] = false;
         sym[q] = in[q].delta_last != 0.0 || in[q].sym_hint;
-        pkb[q] = mpc_uni(pk_arr + in[q].inst * (uint32_t)(N + 1) * PKS);
     }
-    for (;;) {
+    for (bool first = true;; first = false) {
+        if (!first) rebuild();
         ++sweeps;
         bool symm = false, symq[NI];
 #pragma unroll
@@ -232,19 +221,14 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
         double M[NI], b0[NI], b1[NI], aa0[NI], aa1[NI], hc[NI], ha[NI], ruu0[NI], ruu1[NI];
         mpc_lds_ptr pb0[NI], pb1[NI], paa0[NI], paa1[NI], phc[NI], pha[NI], pruu[NI];
         bool good[NI];
-        // (per-lane store offsets: the lanes with an entry walk down the stages of their instance's mailbox rows, the others stay on
-        //  row 0 of the KK array -- the scalar offset is the instance's, so theirs is taken relative to it)
-        uint32_t voff[NI];
-#pragma unroll
-        for (int q = 0; q < NI; ++q) voff[q] = m.pk_row >= 0 ? pk_lane : kk_arr - (uint32_t)pkb[q];
-        int wdec = 0;
+        int wdec = 0, pdec = 0;
         // terminal stage: M_N = Ht_N + delta_w I
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             mpc_lds_ptr r = rec[q] + N * RC::SIZE;
             M[q] = r[m.oHC] + delta[q] * m.dmask;
             good[q] = true;
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff[q], pkb[q], 0);
+            rec[q][p_first[q]] = M[q];                   // (over the terminal stage's own H / gx: every lane has read its entry)
             r = rec[q] + (N - 1) * RC::SIZE;
             b0[q] = r[m.oB[0]]; b1[q] = r[m.oB[1]]; aa0[q] = r[m.oAA[0]]; aa1[q] = r[m.oAA[1]]; hc[q] = r[m.oHC]; ha[q] = r[m.oHA];
             ruu0[q] = r[RC::RUU]; ruu1[q] = r[RC::RUU + 1];
@@ -263,9 +247,8 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
         auto stage = [&](auto sym_tag, auto off_tag) {
             constexpr bool SYM = decltype(sym_tag)::value;
             constexpr int OFF = decltype(off_tag)::value * RC::SIZE;          // the record to prefetch, from the operand addresses
-#pragma unroll
-            for (int q = 0; q < NI; ++q) voff[q] -= pk_inc;
             wdec += w_inc;
+            pdec += p_inc;
             double nb0[NI], nb1[NI], naa0[NI], naa1[NI], nhc[NI], nha[NI], nruu0[NI], nruu1[NI];
             double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], cl[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
             // The wavefront issues in order: the scalar chain Lam -> det -> 1 / det (ten dependent instructions) is cut into pieces that
@@ -329,7 +312,7 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
                 // (per instance, so that the result of an instance does not depend on which instance shares its wavefront)
                 if (SYM) { const double Ms = 0.5 * (M[q] + wv_bpermute(M[q], m.tr_addr)); M[q] = symq[q] ? Ms : M[q]; }
                 rec[q][w_first[q] - wdec] = Kt[q];                                              // gains for the forward sweep (lanes without an entry: the dump area)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, M[q]), rsrc, (int)voff[q], pkb[q], 0);   // cost-to-go for the stage threads
+                rec[q][p_first[q] - pdec] = M[q];                                               // cost-to-go for the stage threads, over this stage's consumed Ruu / gu / gx / H
                 b0[q] = nb0[q]; b1[q] = nb1[q]; aa0[q] = naa0[q]; aa1[q] = naa1[q]; hc[q] = nhc[q]; ha[q] = nha[q]; ruu0[q] = nruu0[q]; ruu1[q] = nruu1[q];
             }
 #undef MPC_FENCE
@@ -367,40 +350,33 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
     }
 }
 
-// ---- forward sweeps of NI instances: dz_k = (du_k, dx_k) into the DZ rows of the workspace ----------------------------------------------
+// ---- forward sweeps of NI instances: dz_k = (du_k, dx_k) into the records (Rec::DU / Rec::DX: over A[0..1] and -c of the stage, which the
+// sweep has consumed by the time it writes them) ------------------------------------------------------------------------------------------
 // One matrix instruction per stage: x~' = Acl' x~ with Acl' = At + Bt Kt in the state rows and the two rows of Kt in rows 6, 7 (the
 // affine coordinate is put back by hand), the k index spread over the hardware blocks (block (hi, lo) = Acl'_{lo, hi} x~_hi) and summed over
 // hi by a DPP row rotation.  x0[q]: B-operand register, lane (x, hi, *, 0) = x~_0[4 hi + x] (the affine coordinate 7 holds 1), zero for y != 0.
-// Lanes without an entry to store write row 0 of the unused KK array (no divergent store).
+// Lanes without an entry to store write the dump area.
 template <int NX, int NI>
-__device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI],
-                                             const double (&x0)[NI], const bool (&ok)[NI]) {
-    using D = Dim<NX>;
+__device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& m, const MfmaInst (&in)[NI], const mpc_lds_ptr (&rec)[NI], int lane,
+                                             mpc_lds_ptr dump, const double (&x0)[NI], const bool (&ok)[NI]) {
     using RC = Rec<NX>;
     const int N = P.N;
-    const __amdgpu_buffer_rsrc_t rsrc = P.rws;
-    constexpr uint32_t DZS = MPC_EV(D::NZ) * 8u;                           // bytes per stage of the mailbox DZ rows
     const bool st = m.dz_row >= 0;
-    const uint32_t dz_arr = (uint32_t)(uintptr_t)P.MDZ - (uint32_t)(uintptr_t)P.WS, kk_arr = (uint32_t)(uintptr_t)P.KK - (uint32_t)(uintptr_t)P.WS;
-    // per-lane running offset: storing lanes walk the DZ rows of their instance (the dx lanes one stage ahead), the others stay on the dump row
-    const uint32_t inc = st ? DZS : 0u;
+    // per-lane running offset from the records of the instance: du lanes write DU + row of record k, dx lanes DX + state of record k + 1
+    const int inc = st ? RC::SIZE : 0;
     const double fixval = (m.fix == 2) ? 1.0 : 0.0;
     const bool fix = m.fix != 0;
     double X[NI], f1[NI], f2[NI];
-    int base[NI];
-    uint32_t voff[NI];
+    int doff[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         X[q] = x0[q];
-        base[q] = mpc_uni(dz_arr + in[q].inst * (uint32_t)(N + 1) * DZS);
-        voff[q] = st ? (uint32_t)m.dz_row * 8u + (m.dz_next ? DZS : 0u) : kk_arr - (uint32_t)base[q];
-        // dx_0: the storing lanes (x, hi = 0, lo, 0) want row 4 lo + x, the operand layout carries row 4 hi + x: one bank move
-        if (ok[q]) {
-            const double xs = wv_dpp<DPP_SHR4, 0x2>(X[q], wv_dpp<DPP_SHL8, 0x1>(X[q], X[q]));      // bank (0, 1) <- bank (1, *)
-            if (m.dz_next) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, xs), rsrc, (int)(voff[q] - DZS), base[q], 0);
-        }
+        doff[q] = st ? (m.dz_next ? RC::SIZE + RC::DX + (m.dz_row - 2) : RC::DU + m.dz_row) : (int)(dump - rec[q]) + lane;
         mpc_lds_cptr r = rec[q];
-        f1[q] = r[m.oF1]; f2[q] = r[m.oF2];
+        f1[q] = r[m.oF1]; f2[q] = r[m.oF2];              // (before dx_0 goes over the -c entries of record 0)
+        // dx_0: the storing lanes (x, hi = 0, lo, 0) want row 4 lo + x, the operand layout carries row 4 hi + x: one bank move
+        const double xs = wv_dpp<DPP_SHR4, 0x2>(X[q], wv_dpp<DPP_SHL8, 0x1>(X[q], X[q]));      // bank (0, 1) <- bank (1, *)
+        if (ok[q] && m.dz_next) rec[q][doff[q] - RC::SIZE] = xs;
     }
     auto fstage = [&](int k) {
         double n1[NI], n2[NI], S[NI];
@@ -414,8 +390,9 @@ __device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& 
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             S[q] = wv_sum_hi(S[q]);                                              // lane (x, *, lo, 0) = x~'[4 lo + x]: dx_{k+1}, du_k in rows 6, 7
-            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, S[q]), rsrc, (int)voff[q], base[q], 0);
-            voff[q] += inc;
+            // (record k's operands were read a stage ago, record k + 1's at the top of this one: LDS operations of a wavefront keep their order)
+            if (ok[q]) rec[q][doff[q]] = S[q];
+            doff[q] += inc;
             S[q] = fix ? fixval : S[q];
             X[q] = wv_dpp<DPP_SHL4, 0x6>(S[q], S[q]);                            // block (hi, lo) <- x~_hi
             f1[q] = n1[q]; f2[q] = n2[q];
@@ -429,7 +406,7 @@ __device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& 
     if (st && !m.dz_next) {                                                  // du_N = 0
 #pragma unroll
         for (int q = 0; q < NI; ++q)
-            if (ok[q]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mpc_v2u, 0.0), rsrc, (int)voff[q], base[q], 0);
+            if (ok[q]) rec[q][doff[q]] = 0.0;
     }
 }
 

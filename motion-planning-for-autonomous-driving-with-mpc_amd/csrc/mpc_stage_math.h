@@ -518,6 +518,45 @@ MPC_HD double zreset(double z, double gap, double mu) {
     return fmin(fmax(z, lo), hi);
 }
 
+// LDS record of one (instance, stage) of the workgroup-resident path (k_solve_wg; sweeps in mpc_riccati_mfma.h), in doubles.  What lives
+// in it changes along a round -- nothing of it goes through memory:
+//   stage phases (phase_eval_finish / phase_finish)  ->  the condensed stage block: A, -c (NCN), and in the overlay area Ruu, gu, gx, H
+//   backward sweep of stage k                        ->  the gain rows K0 / K1 (for the forward sweep), and OVER the overlay area -- whose
+//                                                        entries the sweep has consumed one stage earlier -- the cost-to-go P_k, p_k
+//   forward sweep                                    ->  the step, over entries IT has consumed: du_k on A[0..1], dx_k on NCN
+//   stage phases (phase_preload)                     <-  step and cost-to-go
+// ZERO / ONE / DT: the "no entry" / identity / dt operands of the sweeps' per-lane offsets; HX: Hux of stage 0 (zero elsewhere).  A sweep
+// that has to be repeated (inertia correction) finds its Ruu / gu / gx / H overwritten: the records are rebuilt from the blocks' copy in
+// memory (MBLK, written by the same phases) first -- the rare path.
+template <int NX>
+struct Rec {
+    using D = Dim<NX>;
+    static constexpr int A = 0, NCN = 6, ZERO = 6 + (int)MPC_EV(NX), ONE = ZERO + 1, DT = ZERO + 2;
+    static constexpr int K0 = (DT + 2) & ~1, K1 = K0 + 8;        // Kt rows: [K0 (NX) | 0.. | kff0], [K1 | .. | kff1]
+    static constexpr int HX = K1 + 8;                            // 2
+    static constexpr int OV = HX + 2;                            // overlay area: stage-block part / cost-to-go
+    static constexpr int RUU = OV, GU = OV + 2, GX = OV + 4, H = GX + NX;
+    static constexpr int PK = OV;
+    static constexpr int DU = A, DX = NCN;                       // the step, once the forward sweep has passed
+    static constexpr int SIZE = OV + ((int)MPC_EV(4 + NX + D::NH) > (int)MPC_EV(D::NPK) ? (int)MPC_EV(4 + NX + D::NH) : (int)MPC_EV(D::NPK));
+    static constexpr int DUMMY = -1;                             // (marks lanes that have no gain entry to write)
+    static_assert(OV % 2 == 0 && K0 % 2 == 0 && NCN % 2 == 0 && SIZE % 2 == 0 && GX % 2 == 0, "pairs of a record are 16-byte aligned");
+    // slot of row i of the stage block as the phases store it (BLK rows: A | Ruu | gu | c | gx | H)
+    MPC_HD static constexpr int slot(int i) {
+        return i < D::B_RUU ? A + i : i < D::B_GU ? RUU + (i - D::B_RUU) : i < D::B_CN ? GU + (i - D::B_GU) : i < D::B_GX ? NCN + (i - D::B_CN)
+             : i < D::B_H ? GX + (i - D::B_GX) : H + (i - D::B_H);
+    }
+};
+
+template <int CNT> MPC_HD void rec_load(mpc_lds_cptr r, double* dst) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) dst[i] = r[i];
+}
+template <int CNT> MPC_HD void rec_store(mpc_lds_ptr r, const double* src) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) r[i] = src[i];
+}
+
 // per-thread context kept in registers across the phases of the stage kernel
 template <int NX>
 struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath
@@ -556,6 +595,7 @@ struct Ctx {
     bool ill;        // a circle row of this stage has a weight z / s above ILL_WEIGHT at the new iterate (phase_ineq_assemble)
     mpc_lds_cptr bnd;                        // LDS copy of the bounds table [LB (N+1)*NZ | UB (N+1)*NZ] (device)
     int bnd_ub;
+    mpc_lds_ptr rec;                         // k_solve_wg (the MB instantiations of the phases): the LDS record of this (instance, stage)
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
@@ -707,6 +747,49 @@ MPC_HD void load_obst(const PRef& P, Ctx<NX>& c) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.obst[i] = (!BATCH_WIDE && P.per_inst_obst) ? (double)MPC_S(P.OBST, i) : P.obst[i];
 }
+
+// what a stage thread of k_solve_wg keeps in registers from one round to the next (phase_preload<.., KEEP>): the iterate of its stage with
+// its multipliers, the reference and the state of the next stage -- nothing else of the context lives across the KKT solves
+template <int NX>
+struct CtxKeep {
+    static constexpr int NZ = NX + 2;
+    double z[NZ], zl[NZ], zu[NZ], lam[NX], rn[NX], xn[NX], r0[NX], so[3], nuo[3], zlo[3], zuo[3], obst[6];
+};
+template <int NX, uint32_t VM>
+MPC_HD void ctx_keep(const Ctx<NX>& c, CtxKeep<NX>& q, bool has_ou) {
+#pragma unroll
+    for (int i = 0; i < NX + 2; ++i) { q.z[i] = c.z[i]; if ((VM >> i) & 1u) { q.zl[i] = c.zl[i]; q.zu[i] = c.zu[i]; } }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { q.lam[i] = c.lam[i]; q.rn[i] = c.rn[i]; q.xn[i] = c.xn[i]; q.r0[i] = c.r0[i]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { q.so[j] = c.so[j]; q.nuo[j] = c.nuo[j]; q.zlo[j] = c.zlo[j]; if (has_ou) q.zuo[j] = c.zuo[j]; }
+    if (!(VM & 0x100u)) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q.obst[j] = c.obst[j];
+    }
+}
+// (a path that leaves the stage phases early has nothing to keep: saying so spares the registers of the old values through the phases)
+template <int NX>
+MPC_HD void ctx_forget(CtxKeep<NX>& q) {
+    double* v = reinterpret_cast<double*>(&q);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(CtxKeep<NX>) / sizeof(double)); ++i) v[i] = 0.0;
+}
+template <int NX, uint32_t VM>
+MPC_HD void ctx_restore(const PRef& P, Ctx<NX>& c, const CtxKeep<NX>& q, bool has_ou) {
+#pragma unroll
+    for (int i = 0; i < NX + 2; ++i) { c.z[i] = q.z[i]; c.zl[i] = ((VM >> i) & 1u) ? q.zl[i] : 0.0; c.zu[i] = ((VM >> i) & 1u) ? q.zu[i] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { c.lam[i] = q.lam[i]; c.rn[i] = q.rn[i]; c.xn[i] = q.xn[i]; c.r0[i] = q.r0[i]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { c.so[j] = q.so[j]; c.nuo[j] = q.nuo[j]; c.zlo[j] = q.zlo[j]; c.zuo[j] = has_ou ? q.zuo[j] : 0.0; }
+    if (VM & 0x100u) load_obst<NX, true>(P, c);
+    else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) c.obst[j] = q.obst[j];
+    }
+}
+
 
 // =========================================================================================================
 // Start-point safeguard (one instance per thread, before the init kernel).
@@ -1000,16 +1083,34 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
 // MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
+// KEEP (k_solve_wg, second and later rounds of a workgroup on its instances): the context still holds the iterate, its multipliers, the
+// reference of the next stage and x_{k+1} as the last round's update and neighbour exchange left them -- bit for bit what that round stored
+// and this one would load; only what the KKT solve produced in between (step, cost-to-go) and the stage-0 friction rows come from memory
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool KEEP = false>
 MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
+    if (KEEP) {
+        static_assert(!KEEP || (MB && ROLE == ROLE_ALL), "the kept context is the workgroup-resident path's");
+        rec_load<2>(c.rec + Rec<NX>::DU, c.dz);
+        rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2);
+        if (k < N) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn);
+        else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp.lam[i] = c.lam[i];
+        rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk);
+    } else {
     if (MPC_RB) load_obst<NX, (VM & 0x100u) != 0u>(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
-    if (MB) ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 0, e)), c.dz); else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
+    // (MB: step and cost-to-go come from the LDS record the sweeps of this workgroup left them in -- see Rec)
+    if (MB) { rec_load<2>(c.rec + Rec<NX>::DU, c.dz); rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2); }
+    else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         // multipliers of bounds that exist nowhere are never read (a_0 has per-instance bounds: stage 0 always loads its pair);
@@ -1030,7 +1131,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     if (MPC_RA && k < N) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
-        if (MB) ws_load_rows<NX>(MPC_ROWS(MPC_KM(P.MDZ, NZ, 1, 2 + e)), c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
+        if (MB) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
@@ -1039,7 +1140,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
         for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
-        if (MB) ws_load_rows<D::NPK>(MPC_ROWS(MPC_KM(P.MPK, D::NPK, 0, e)), tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
+        if (MB) rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
     }
     c.so[0] = c.so[1] = c.so[2] = 0.0;
     c.nuo[0] = c.nuo[1] = c.nuo[2] = 0.0;
@@ -1051,6 +1152,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         if (MPC_HAS_OL) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
         if (MPC_HAS_OU) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
     }
+    }   // !KEEP
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
     if (MPC_RA && k == 0) {                                // (fric_row is not known yet; the values are only used if it is set)
@@ -1469,6 +1571,7 @@ template <int NX>
 struct EvalTmp {
     double H[Dim<NX>::NS], rx[NX], ru[2], ruu[2], cn[NX], a[6];
     double theta, fc, prim, dual, cmin, cmax, smult, sz, gp;
+    double hx0, hx1;              // Hux of stage 0 (the kept friction row's; zero otherwise)
 };
 template <int NX, bool REUSE = false, int ROLE = ROLE_ALL, bool TG = false, uint32_t VM = 0xFFu>
 MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
@@ -1571,6 +1674,7 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
         }
     }
     // friction row (stage 0), unless presolved into the bounds of a_0
+    t.hx0 = t.hx1 = 0.0;
     if (k == 0 && c.fric_row) {
         double g[3], h[4];
         const double dfr = friction_eval(P, u[1], x[2], x[3], g, h, true);
@@ -1593,8 +1697,10 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
         H[D::sidx(2, 2)] += nu * h[1] + sg * g[1] * g[1];
         H[D::sidx(2, 3)] += nu * h[2] + sg * g[1] * g[2];
         H[D::sidx(3, 3)] += nu * h[3] + sg * g[2] * g[2];
-        MPC_S(P.SC, SC_HUX0) = sg * g[0] * g[1];
-        MPC_S(P.SC, SC_HUX1) = sg * g[0] * g[2];
+        t.hx0 = sg * g[0] * g[1];
+        t.hx1 = sg * g[0] * g[2];
+        MPC_S(P.SC, SC_HUX0) = t.hx0;
+        MPC_S(P.SC, SC_HUX1) = t.hx1;
         MPC_S(P.SC, SC_DFRIC) = dfr;
         MPC_S(P.SC, SC_GFR0) = g[0];
         MPC_S(P.SC, SC_GFR1) = g[1];
@@ -1659,9 +1765,19 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
                 if (D::hrow(i, j) >= 0) hh[D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0] = H[D::sidx(i, j)];
         }
         if (MB) {
+            // (the copy in memory is what a repeated sweep rebuilds the records from; the sweeps themselves read the record: the defect negated)
             ws_store_rows<8>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
             ws_store_rows<D::NH>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
+            using RC = Rec<NX>;
+            double ncn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ncn[i] = -cn[i];
+            rec_store<6>(c.rec + RC::A, head);
+            rec_store<2>(c.rec + RC::RUU, head + 6);
+            rec_store<NX>(c.rec + RC::NCN, ncn);
+            rec_store<D::NH>(c.rec + RC::H, hh);
+            if (k == 0) { c.rec[RC::HX] = t.hx0; c.rec[RC::HX + 1] = t.hx1; }
         } else {
             ws_store_rows<8>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_CN + e)), cn);
@@ -1731,8 +1847,11 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         for (int i = 0; i < NX; ++i) gx[i] = c.gxa[i] + mu * c.gxb[i];
         if (ROLE == ROLE_B) {
         } else if (MB) {
+            const double gu[2] = {c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]};
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), gx);
-            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
+            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), gu[0], gu[1]);
+            rec_store<NX>(c.rec + Rec<NX>::GX, gx);
+            rec_store<2>(c.rec + Rec<NX>::GU, gu);
         } else {
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_K(P.BLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);

@@ -154,16 +154,19 @@ constexpr uint32_t REF_VM = PAIR_VM | MPC_REF_FLAGS;
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
-template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu>
-__device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
-                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
-                                            uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
+// stage_block_ctx: the context is the caller's.  `keep` (k_solve_wg only, wave-uniform): it still holds the iterate of these instances from
+// the caller's last call -- see phase_preload<.., KEEP>
+template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu, bool KEEPS = false>
+__device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
+                                                const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp,
+                                                uint32_t* live_out, const bool bounds_in_lds, CtxKeep<NX>& kept, const bool keep,
+                                                const mpc_lds_ptr rec_base = nullptr) {
     int or_parity = 0;
+    Ctx<NX> c;
     // (the workgroup-resident kernel with the compiled-in bound structure fits the register file without the stash: -650 instructions,
     //  -490 of them scalar-register reloads, k_solve_wg 304 -> 295 us on the headline batch; neutral in the pipeline's stage workers)
-    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH && !(MB && VM != 0xFFu);
+    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH && !MB;
     const bool has_ou = (VM & VM_OSPEC) ? false : (P.has_ou != 0);     // (what the stash parks)
-    Ctx<NX> c;
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
     c.b = (int)b0 + (t & (bx - 1));
@@ -176,12 +179,15 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     MPC_STAMP(0);
     if (!INIT) {
         const unsigned long long m = tile_bits >> (b0 & 63u);
-        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
+        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) { if (KEEPS) ctx_forget(kept); return; }
     }
     // LDS: [reduction scratch | bounds table | exchange / stash rows | prefetch images]
-    double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
+    // (MB -- k_solve_wg, ONE wavefront per workgroup: no reduction scratch, no exchange rows; `lds` is the bounds table, rec_base the
+    //  records of the workgroup's instances)
+    double* lds_b = MB ? lds : lds + (blockDim.x >> 6) * 10 * bx;
     const int nb = (P.N + 1) * (NX + 2);
     double* lds_x = lds_b + 2 * nb;
+    if (MB) c.rec = rec_base + ((t & (bx - 1)) * (P.N + 1) + (c.k <= P.N ? c.k : 0)) * Rec<NX>::SIZE;
     // (a persistent stage worker of the pipeline copies the table -- the same for every item of the batch -- once: nothing else of
     //  its work items touches that part of the LDS)
     if (!bounds_in_lds)
@@ -197,7 +203,8 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        phase_preload<NX, MB, ROLE_ALL, VM>(P, c, tmp);              // every array load of the kernel is in flight before the first wait
+        if (KEEPS && keep) { ctx_restore<NX, VM>(P, c, kept, has_ou); phase_preload<NX, MB, ROLE_ALL, VM, KEEPS>(P, c, tmp); }
+        else phase_preload<NX, MB, ROLE_ALL, VM>(P, c, tmp);         // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         // (the bounds table is read from here on: a block that has just copied it passes a barrier -- behind its loads, which are in flight;
@@ -207,7 +214,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         // t / bx of column t % bx, a wavefront covers 64 / bx consecutive stages, and the last wavefront starts at a stage <= N), and all
         // stage threads of an instance hold the same flags (they come out of the block-wide reductions bit for bit) -- so the vote of one
         // wavefront is the vote of the block.  Three barriers + LDS round trips less per work item.
-        if (!__any(c.active ? 1 : 0)) return;
+        if (!__any(c.active ? 1 : 0)) { if (KEEPS) ctx_forget(kept); return; }
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
@@ -228,8 +235,16 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         phase_apply_update<NX, MB, ROLE_ALL, VM>(P, c);
         MPC_STAMP(6);
     }
-    // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
-    {
+    // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
+    if (MB) {
+        // (one wavefront: the neighbour is lane t + bx)
+        const int tn = t + bx;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xs = __shfl_down(c.z[2 + i], (unsigned)bx, 64), ls = __shfl_down(c.lam[i], (unsigned)bx, 64);
+            if (tn < (int)blockDim.x) { c.xn[i] = xs; c.lamn[i] = ls; }
+        }
+    } else {
         double* ex = lds_x;                                   // behind the reduction scratch and the bounds table
         const int T = blockDim.x;
 #pragma unroll
@@ -255,6 +270,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
     phase_finish<NX, MB>(P, c, r3, n_mult, n_z);
+    if (KEEPS) ctx_keep<NX, VM>(c, kept, has_ou);
     MPC_STAMP(10);
     // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
     // (k_solve_wg: the same ballot IS the activity mask of its next round -- bit l: instance b0 + l goes on; no status row is re-read)
@@ -267,6 +283,13 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         if (t == 0 && cnt) atomicAdd(P.run_counter, cnt);
     }
 #undef MPC_STAMP
+}
+template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu>
+__device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
+                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
+                                            uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
+    CtxKeep<NX> none;
+    stage_block_ctx<NX, INIT, MAXT, MB, VM, false>(P, n_mult, n_z, stash_rows, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, none, false);
 }
 
 #ifndef MPC_WITH_PAIR
@@ -1001,8 +1024,20 @@ constexpr int RESC_LEVELS = 8;          // index q of IS_RLEV: 0 = the first att
 __device__ __forceinline__ double resc_fraction(int q) { return q == 2 || q == 7 ? 1.0 : q == 4 ? 0.4 : q == 5 ? 0.7 : q == 6 ? 0.9 : 0.0; }
 __device__ __forceinline__ bool resc_last(int q) { return q == 2 || q == 7; }
 
+// LDS of k_solve_wg, in doubles: the pad record (also the dump area of the sweeps: one double per lane), the records, the bounds table
+template <int NX>
+struct WgLds {
+    static constexpr int PAD = Rec<NX>::SIZE > 64 ? Rec<NX>::SIZE : 64;
+    __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2); }
+};
+// (the stage threads of k_solve_wg keep their iterate in registers from round to round -- measured: the registers it takes through the
+//  sweeps cost more in scratch traffic than the loads it saves; kept as a switch)
+constexpr bool WG_KEEP = false;
+#ifndef MPC_DBG_REBUILD
+#define MPC_DBG_REBUILD 0
+#endif
 template <int NX, int VAR, bool RESC = false>
-__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
+__global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
                                                                    const WgRescue resc) {
     PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1016,17 +1051,23 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
     using D = Dim<NX>;
     using RC = Rec<NX>;
     const int bx = P.bx, t = threadIdx.x, N = P.N;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nw = (int)(blockDim.x >> 6);
+    const int lane = t;                          // ONE wavefront per workgroup (bx = 1 or 2 instances, (N + 1) * bx <= 64 stage threads)
     const uint32_t b0 = (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
     struct { int b, k; } c;                      // (the workspace accessors are written in terms of c.b / c.k)
     c.k = t / bx;
     c.b = (int)b0 + (t & (bx - 1));
-    const bool valid = (c.k <= N) && (c.b < P.B);         // (PAIR: false for the barrier threads, t / bx >= T / bx > N)
-    // LDS of the sweeps (aliases the stage phases' region): [dump area of the sweeps, 64 doubles per wavefront | one pad record | records]
-    const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * nw + RC::SIZE;
-    const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds + 64 * wave;
+    const bool valid = (c.k <= N) && (c.b < P.B);
+    // LDS: [one pad record -- what the sweeps' operand prefetch of "stage -1" reads and what their lanes without an entry write | records
+    //       of the workgroup's instances, Rec<NX> | bounds table of the stage phases]; nothing else: one wavefront needs no reduction
+    //       scratch and exchanges neighbour stages by lane shuffles
+    const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + WgLds<NX>::PAD;
+    const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds;
+    double* const lds_bnd = lds + WgLds<NX>::PAD + (size_t)RC::SIZE * ((N + 1) * bx);
+    bool bounds_ok = false;
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
+    CtxKeep<NX> ctx;                              // what the stage threads keep from round to round (phase_preload<.., KEEP>)
+    bool keep = false;
     if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
@@ -1095,6 +1136,8 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                 wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
             }
             fresh = true;
+            keep = false;
+            bounds_ok = false;                    // (the restart used the whole LDS)
             continue;
         }
         ++rounds;
@@ -1104,7 +1147,6 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
         //      pipeline / the start-iterate kernel left them) into the instance-major mailbox arrays the rounds below work on -- one
         //      wavefront reads all stages of its one or two instances, and only there are the pieces of a thread contiguous
         if (fresh && valid) {
-            constexpr bool MB = true;
             auto move = [&](auto cnt, auto from, auto to) {
                 constexpr int CNT = decltype(cnt)::value;
                 double v[MPC_EV(CNT)];
@@ -1121,25 +1163,34 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
             move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MZUO, 3, 0, e)));
             move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), MPC_ROWS(MPC_KM(P.MLAM, NX, 0, e)));
             move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.REF, NX, 0, e)), MPC_ROWS(MPC_KM(P.MREF, NX, 0, e)));
-            (void)MB;
         }
-        // ---- stage blocks -> LDS records, instance-major (every stage thread its own; defect negated, three constants, Hux of stage 0)
-        if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
-            double blk[MPC_EV(D::NBLK)];
-            // (the blocks this launch starts from were written tile-major by the start-iterate kernel or the pipeline; its own rounds
-            //  write the instance-major mailbox: 272 contiguous bytes per thread instead of 17 pieces in 17 lines)
-            if (fresh) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
-            else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), blk);
-            double hx0 = 0.0, hx1 = 0.0;
-            if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
-            const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
+        // ---- stage blocks -> LDS records (every stage thread its own; defect negated, three constants, Hux of stage 0).  Only when the
+        //      instances have just been taken over (the blocks were written tile-major by the start-iterate kernel or the pipeline) and
+        //      when a sweep has to be repeated (from the copy in the mailbox): the rounds' own blocks go from the stage phases straight
+        //      into the records.
+        const bool tiled = fresh;
+        auto build_records = [&]() {
+            if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
+                double blk[MPC_EV(D::NBLK)];
+                if (tiled) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
+                else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), blk);
+                double hx0 = 0.0, hx1 = 0.0;
+                if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
+                const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
 #pragma unroll
-            for (int i = 0; i < D::NBLK; ++i) r[i] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
-            r[RC::ZERO] = 0.0;
-            r[RC::ONE] = 1.0;
-            r[RC::DT] = P.dt;
-            r[RC::HX] = hx0;
-            r[RC::HX + 1] = hx1;
+                for (int i = 0; i < D::NBLK; ++i) r[RC::slot(i)] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
+                r[RC::ZERO] = 0.0;
+                r[RC::ONE] = 1.0;
+                r[RC::DT] = P.dt;
+                r[RC::HX] = hx0;
+                r[RC::HX + 1] = hx1;
+            }
+        };
+        if (fresh || MPC_DBG_REBUILD) build_records();
+        if (!bounds_ok) {
+            const int nb = (N + 1) * D::NZ;
+            for (int q = t; q < nb; q += 64) { lds_bnd[q] = MPC_GP(P.LB, q); lds_bnd[nb + q] = MPC_GP(P.UB, q); }
+            bounds_ok = true;
         }
         lds_barrier();
         fresh = false;
@@ -1150,7 +1201,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
         asm volatile("" : "+v"(lane_v));
         MfmaLane<NX> m;
         mfma_lane_setup<NX>(m, lane_v, P.dt);
-        // ---- KKT solves: wave w takes instances w and w + nw of the block (interleaved in one instruction stream), then w + 2 nw, ...
+        // ---- KKT solves of the live instances (two: interleaved in one instruction stream)
         {
             auto inst_of = [&](int g, MfmaInst& in, double& x0) {
                 const int bb = (int)b0 + g;
@@ -1174,51 +1225,46 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_solve_wg(const Params 
                     MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb) = -7;
                 }
             };
-            // the live instances of this wave, in pairs
-            uint32_t mine = 0u;
-            for (int g = wave; g < bx; g += nw) mine |= mask & (1u << g);
-            while (mine) {
-                const int g0 = __builtin_ctz(mine);
-                mine &= mine - 1u;
-                if (mine) {
-                    const int g1 = __builtin_ctz(mine);
-                    mine &= mine - 1u;
-                    MfmaInst in[2];
-                    double x0[2], delta[2];
-                    bool ok[2];
-                    inst_of(g0, in[0], x0[0]);
-                    inst_of(g1, in[1], x0[1]);
-                    const mpc_lds_ptr rec[2] = {recs + g0 * (N + 1) * RC::SIZE, recs + g1 * (N + 1) * RC::SIZE};
-                    mfma_backward<NX, 2>(P, m, in, rec, lane, dump, delta, ok, sweeps);
-                    mfma_forward<NX, 2>(P, m, in, rec, x0, ok);
-                    finish(g0, ok[0], delta[0]);
-                    finish(g1, ok[1], delta[1]);
-                } else {
-                    MfmaInst in[1];
-                    double x0[1], delta[1];
-                    bool ok[1];
-                    inst_of(g0, in[0], x0[0]);
-                    const mpc_lds_ptr rec[1] = {recs + g0 * (N + 1) * RC::SIZE};
-                    mfma_backward<NX, 1>(P, m, in, rec, lane, dump, delta, ok, sweeps);
-                    mfma_forward<NX, 1>(P, m, in, rec, x0, ok);
-                    finish(g0, ok[0], delta[0]);
-                }
+            // a sweep that is repeated with an inertia correction starts from the stage blocks again: its cost-to-go went over them
+            auto rebuild = [&]() { lds_barrier(); build_records(); lds_barrier(); };
+            uint32_t mine = mask;
+            const int g0 = __builtin_ctz(mine);
+            mine &= mine - 1u;
+            if (mine) {
+                const int g1 = __builtin_ctz(mine);
+                MfmaInst in[2];
+                double x0[2], delta[2];
+                bool ok[2];
+                inst_of(g0, in[0], x0[0]);
+                inst_of(g1, in[1], x0[1]);
+                const mpc_lds_ptr rec[2] = {recs + g0 * (N + 1) * RC::SIZE, recs + g1 * (N + 1) * RC::SIZE};
+                mfma_backward<NX, 2>(P, m, in, rec, lane, dump, delta, ok, sweeps, rebuild);
+                mfma_forward<NX, 2>(P, m, in, rec, lane, dump, x0, ok);
+                finish(g0, ok[0], delta[0]);
+                finish(g1, ok[1], delta[1]);
+            } else {
+                MfmaInst in[1];
+                double x0[1], delta[1];
+                bool ok[1];
+                inst_of(g0, in[0], x0[0]);
+                const mpc_lds_ptr rec[1] = {recs + g0 * (N + 1) * RC::SIZE};
+                mfma_backward<NX, 1>(P, m, in, rec, lane, dump, delta, ok, sweeps, rebuild);
+                mfma_forward<NX, 1>(P, m, in, rec, lane, dump, x0, ok);
+                finish(g0, ok[0], delta[0]);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // cost-to-go and step are in the L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the status of an instance the sweeps gave up on is out)
         lds_barrier();
-        // (producer and consumer of every row are wavefronts of THIS workgroup: one CU, one write-through vector L1 -- workgroup scope
+        // (producer and consumer of every row are lanes of THIS wavefront: one CU, one write-through vector L1 -- workgroup scope
         //  orders them without the cache invalidation an agent-scope acquire costs, which would send every load of the round to the HBM)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(14);
         // ---- the stage work of the round
         if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
-#if MPC_WITH_PAIR
-        if (VAR == 1) stage_pair<NX, true>(P, n_mult, n_z, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask, false, (int)(blockDim.x >> 1));
-        else
-#endif
-        stage_block<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds, or_slots, rounds == 3u, &sh_mask);
+        stage_block_ctx<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu, WG_KEEP>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds_bnd, or_slots, rounds == 3u,
+                                                                                 &sh_mask, true, ctx, keep, recs);
+        keep = WG_KEEP;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2497,6 +2543,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
     // workgroup-resident solve with whole 8-instance workgroups (k_solve_wg, option resident): the stage phases of the streaming paths +
     // the wave-per-instance MFMA Riccati, no pipeline at all (the hybrid solve uses the same kernel with one wavefront per workgroup)
+    // (option resident: k_solve_wg alone, whatever the batch size -- the stage phases of the streaming paths + the wave-per-instance MFMA Riccati)
     const bool use_wg = kn.resident != 0 && small_wg && h->ws_mailbox && !trace && !kn.stage_timing && kn.groups <= 0;
     Params P;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB, h->ws_mailbox);
@@ -2658,29 +2705,22 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
     // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
-    auto wg_pair = [&](int bxw) { return MPC_WITH_PAIR && kn.pair != 0 && pair_vm_ok && 2 * (((S * bxw + 63) / 64) * 64) <= 512; };
+    // LDS of a k_solve_wg workgroup (ONE wavefront, bxw = 1 or 2 instances): records + bounds table; a restart of the second chance runs the
+    // start-point safeguard and the start iterate in the same memory
     auto wg_lds = [&](int bxw) {
-        const int thr = ((S * bxw + 63) / 64) * 64;
-        if (wg_pair(bxw))
-            return std::max(((size_t)(2 * thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * thr) * sizeof(double),
-                            ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (2 * thr / 64) + Rec<NX>::SIZE) * sizeof(double));
-        // (RESC: the start-point safeguard of a restart -- bounds table, rollout / defect rows, scan increments, three words per column)
         const size_t pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bxw + (size_t)3 * bxw) * sizeof(double);
-        return std::max(std::max(((size_t)(thr / 64) * 10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)stash_rows * thr) * sizeof(double),
-                                 ((size_t)S * bxw * Rec<NX>::SIZE + (size_t)64 * (thr / 64) + Rec<NX>::SIZE) * sizeof(double)), bxw == 1 ? pre : (size_t)0);
+        const size_t init = ((size_t)10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)2 * NX * 64) * sizeof(double);
+        return std::max(WgLds<NX>::doubles(S, bxw) * sizeof(double), bxw == 1 ? std::max(pre, init) : (size_t)0);
     };
     // the second chance inside the launch (k_solve_wg<.., RESC>): one instance per workgroup, the conditions of rescue_dev
     const bool resc_cond = kn.rescue && kn.rescue_wg && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
-    auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1 && !wg_pair(bxw); };
+    auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1; };
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
         Params Pw = P;
         Pw.bx = bxw;
-        const int thr = ((S * bxw + 63) / 64) * 64;
+        const int thr = 64;                        // (S * bxw <= 64: checked where the path is chosen)
         WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
         const dim3 grid((B + bxw - 1) / bxw);
-#if MPC_WITH_PAIR
-        if (wg_pair(bxw)) { hipLaunchKernelGGL((k_solve_wg<NX, true>), grid, dim3(2 * thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs); return; }
-#endif
         if (wg_resc(bxw)) {
             rs.on = 1;
             h->resc_in_kernel = true;
@@ -2700,14 +2740,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
     if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
-    const size_t lds_wg = wg_lds(bx);
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
-    if ((use_wg && lds_wg <= lds_max && threads <= 256) || wg_only) {
+    if ((use_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4) || wg_only) {
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
         // (one fill: outside an asynchronous closed loop word 1, its sticky abort word, means nothing)
         if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 7 * sizeof(uint32_t), stream));
         else HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 5 * sizeof(uint32_t), stream));
-        const int nblk_dbg = wg_only ? (B + hyb_bx - 1) / hyb_bx : nblk;
+        const int nblk_dbg = (B + hyb_bx - 1) / hyb_bx;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
             HIP_TRY(h, hipMalloc(&t_rdbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg));
@@ -2715,7 +2754,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             P.DBG = t_rdbg.as<unsigned long long>();
         }
         prof.begin(5, stream);
-        launch_wg(wg_only ? hyb_bx : bx, nullptr, h->d_fail + 2);
+        launch_wg(hyb_bx, nullptr, h->d_fail + 2);
         prof.end(stream);
         prof.begin(2, stream);
         hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail, (uint32_t*)nullptr, 0u);

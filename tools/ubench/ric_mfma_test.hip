@@ -41,11 +41,29 @@ __global__ void __launch_bounds__(64) k_test(const Params Pk, const double* recs
     }
     uint32_t sweeps = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    mfma_backward<NX, NI>(P, m, in, rec, lane, (mpc_lds_ptr)(lp)lds, delta, ok, sweeps);
+    // (a sweep that is repeated with an inertia correction finds its stage blocks overwritten by the cost-to-go: put them back)
+    auto rebuild = [&]() {
+        __syncthreads();
+        for (int q = lane; q < NI * (N + 1) * stride; q += 64) lrec[q] = recs[(size_t)inst * NI * (N + 1) * stride + q];
+        __syncthreads();
+    };
+    mfma_backward<NX, NI>(P, m, in, rec, lane, (mpc_lds_ptr)(lp)lds, delta, ok, sweeps, rebuild);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    mfma_forward<NX, NI>(P, m, in, rec, x0, ok);
+    mfma_forward<NX, NI>(P, m, in, rec, lane, (mpc_lds_ptr)(lp)lds, x0, ok);
     const unsigned long long t2 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    // cost-to-go and step: out of the records (Rec::PK, Rec::DU / Rec::DX) into the rows the host compares
+    {
+        using D = Dim<NX>;
+        for (int q = 0; q < NI; ++q) {
+            const size_t b = (size_t)inst * NI + q;
+            for (int k = 0; k <= N; ++k) {
+                const double* r = lrec + (q * (N + 1) + k) * stride;
+                if (lane < D::NPK) P.MPK[(b * (N + 1) + k) * MPC_EV(D::NPK) + lane] = r[RC::PK + lane];
+                if (lane < D::NZ) P.MDZ[(b * (N + 1) + k) * MPC_EV(D::NZ) + lane] = lane < 2 ? r[RC::DU + lane] : r[RC::DX + lane - 2];
+            }
+        }
+    }
     for (int q = 0; q < NI; ++q)
         for (int k = 0; k < N; ++k)
             if (lane < 16) kout[((size_t)(inst * NI + q) * N + k) * 16 + lane] = lrec[(q * (N + 1) + k) * stride + RC::K0 + lane];
@@ -86,7 +104,7 @@ static int run(int N, int NI, bool nonconvex) {
             r[RC::HX] = k == 0 ? hux[b * 2] : 0.0; r[RC::HX + 1] = k == 0 ? hux[b * 2 + 1] : 0.0;
         }
     }
-    // workspace: mailbox PK rows then DZ rows ([instance][stage][row]), then a dump row
+    // workspace: PK rows then DZ rows ([instance][stage][row]) the kernel copies out of the records
     const size_t pk_el = (size_t)(N + 1) * MPC_EV(D::NPK) * NI, dz_el = (size_t)(N + 1) * MPC_EV(D::NZ) * NI;
     double* d_ws; (void)hipMalloc(&d_ws, (pk_el + dz_el + 128) * 8); (void)hipMemset(d_ws, 0, (pk_el + dz_el + 128) * 8);
     Params P{};
