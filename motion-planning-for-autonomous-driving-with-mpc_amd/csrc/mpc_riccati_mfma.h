@@ -82,9 +82,13 @@ struct MfmaLane {
     int fix;                            // forward: 0 = keep the product, 1 = coordinate forced to 0 (spare row), 2 = forced to 1 (affine coordinate)
     int R, C, Rb;                       // natural row / column; row of x~ this lane carries as B operand of the forward sweep
 };
+#endif   // __HIP_DEVICE_COMPILE__
 
+// The constants depend on the lane (and NX) alone: a table built by the compiler, four packed words per lane.  (They used to be worked out
+// by every wavefront in every round -- ~900 instructions of comparisons and exec-mask branches, 3 - 4 k ticks of a 59 k-tick round -- so as
+// not to hold twenty registers across the stage phases; the four words stay in registers and unpack in ~30 instructions.)
 template <int NX>
-__device__ __forceinline__ int rec_aoff(int r, int c) {
+MPC_HD constexpr int rec_aoff(int r, int c) {
     using RC = Rec<NX>;
     if (r < NX && c < NX) {
         if (r == c) return RC::ONE;
@@ -102,7 +106,7 @@ __device__ __forceinline__ int rec_aoff(int r, int c) {
     return RC::ZERO;
 }
 template <int NX>
-__device__ __forceinline__ int rec_hoff(int r, int c) {
+MPC_HD constexpr int rec_hoff(int r, int c) {
     using RC = Rec<NX>;
     if (r < NX && c < NX) {
         const int i = r < c ? r : c, j = r < c ? c : r;
@@ -114,48 +118,86 @@ __device__ __forceinline__ int rec_hoff(int r, int c) {
     if (r == 7 && c < NX) return RC::GX + c;
     return RC::ZERO;
 }
-
+struct MfmaWords { uint32_t w[4]; };
+// w0: oB0 | oB1 << 8 | oAA0 << 16 | oAA1 << 24      w1: oHC | oHA << 8 | oF1 << 16 | oF2 << 24
+// w2: (pk_row + 1) | (k_off + 1) << 6 | (dz_row + 1) << 13 | dz_next << 17 | fix << 18 | R << 20 | C << 23 | Rb << 26 | (fscale is dt) << 29 | dmask << 30
+// w3: tr_addr
 template <int NX>
-__device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, int lane, double dt) {
+MPC_HD constexpr MfmaWords mfma_lane_words(int lane) {
     using RC = Rec<NX>;
     using D = Dim<NX>;
+    static_assert(RC::SIZE < 256, "record offsets are packed into bytes");
     const int x = lane >> 4, hi = (lane >> 3) & 1, lo = (lane >> 2) & 1, y = lane & 3;
-    m.R = 4 * hi + x;
-    m.C = lane & 7;
-    m.Rb = 4 * hi + x;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        m.oB[q] = rec_aoff<NX>(4 * hi + x, 4 * q + y);        // block (hi, lo) of the B operand of column block q: At_{hi, q}
-        m.oAA[q] = rec_aoff<NX>(4 * q + x, 4 * hi + y);       // k-step q: (At')_{hi, q} read transposed
-    }
-    m.oHC = rec_hoff<NX>(m.R, m.C);
+    const int R = 4 * hi + x, C = lane & 7, Rb = 4 * hi + x;
+    const int oB0 = rec_aoff<NX>(4 * hi + x, y), oB1 = rec_aoff<NX>(4 * hi + x, 4 + y);        // block (hi, lo) of the B operand of column block q: At_{hi, q}
+    const int oAA0 = rec_aoff<NX>(x, 4 * hi + y), oAA1 = rec_aoff<NX>(4 + x, 4 * hi + y);      // k-step q: (At')_{hi, q} read transposed
+    const int oHC = rec_hoff<NX>(R, C);
     // rows x = 0, 1 of Gt live in both halves (hi) of the 16-lane rows: [Hux | gu] is added there
-    m.oHA = (x < 2 && m.C == 7) ? RC::GU + x : (x == 1 && m.C == 2) ? RC::HX : (x == 1 && m.C == 3) ? RC::HX + 1 : RC::ZERO;
-    m.dmask = (m.R == m.C && m.R < NX) ? 1.0 : 0.0;
-    m.pk_row = -1;
-    if (m.R < NX && m.C < NX && m.R <= m.C) m.pk_row = D::sidx(m.R, m.C);
-    if (m.R < NX && m.C == 7) m.pk_row = D::NS + m.R;
-    m.tr_addr = (16 * y + 8 * lo + 4 * hi + x) * 4;
-    m.k_off = (x < 2 && hi == 0) ? ((x == 0 ? RC::K0 : RC::K1) + m.C) : RC::DUMMY;
+    const int oHA = (x < 2 && C == 7) ? RC::GU + x : (x == 1 && C == 2) ? RC::HX : (x == 1 && C == 3) ? RC::HX + 1 : RC::ZERO;
+    const int dmask = (R == C && R < NX) ? 1 : 0;
+    int pk_row = -1;
+    if (R < NX && C < NX && R <= C) pk_row = D::sidx(R, C);
+    if (R < NX && C == 7) pk_row = D::NS + R;
+    const int tr_addr = (16 * y + 8 * lo + 4 * hi + x) * 4;
+    const int k_off = (x < 2 && hi == 0) ? ((x == 0 ? RC::K0 : RC::K1) + C) : RC::DUMMY;
     // forward sweep: hardware block (hi = K, lo = I) holds Acl'_{I K}, read transposed: A_blk[i = y][k = x] = Acl'[4 lo + y][4 hi + x]
+    int oF1 = RC::ZERO, oF2 = RC::ZERO, fdt = 0;
     {
         const int r = 4 * lo + y, c = 4 * hi + x;
-        if (r < NX) { m.oF1 = rec_aoff<NX>(r, c); m.oF2 = (r == 2) ? RC::K0 + c : (r == 3) ? RC::K1 + c : RC::ZERO; m.fscale = dt; }
-        else { m.oF1 = RC::ZERO; m.oF2 = (r == 6) ? RC::K0 + c : (r == 7) ? RC::K1 + c : RC::ZERO; m.fscale = 1.0; }
+        if (r < NX) { oF1 = rec_aoff<NX>(r, c); oF2 = (r == 2) ? RC::K0 + c : (r == 3) ? RC::K1 + c : RC::ZERO; fdt = 1; }
+        else { oF1 = RC::ZERO; oF2 = (r == 6) ? RC::K0 + c : (r == 7) ? RC::K1 + c : RC::ZERO; fdt = 0; }
     }
     // the product of the forward sweep, summed over hi: lane (x, *, lo, y = 0) carries row 4 lo + x: states, du_0 (row 6), du_1 (row 7)
+    int dz_row = -1, dz_next = 0, fix = 0;
     {
         const int r = 4 * lo + x;
-        m.dz_row = -1;
-        m.dz_next = false;
-        m.fix = 0;
         if (y == 0 && hi == 0) {
-            if (r < NX) { m.dz_row = 2 + r; m.dz_next = true; }
-            else if (r >= 6) m.dz_row = r - 6;
+            if (r < NX) { dz_row = 2 + r; dz_next = 1; }
+            else if (r >= 6) dz_row = r - 6;
         }
-        if (r == 7) m.fix = 2; else if (r >= NX) m.fix = 1;
-        if (y != 0) m.fix = 1;
+        if (r == 7) fix = 2; else if (r >= NX) fix = 1;
+        if (y != 0) fix = 1;
     }
+    MfmaWords o{};
+    o.w[0] = (uint32_t)oB0 | (uint32_t)oB1 << 8 | (uint32_t)oAA0 << 16 | (uint32_t)oAA1 << 24;
+    o.w[1] = (uint32_t)oHC | (uint32_t)oHA << 8 | (uint32_t)oF1 << 16 | (uint32_t)oF2 << 24;
+    o.w[2] = (uint32_t)(pk_row + 1) | (uint32_t)(k_off + 1) << 6 | (uint32_t)(dz_row + 1) << 13 | (uint32_t)dz_next << 17 | (uint32_t)fix << 18 | (uint32_t)R << 20 |
+             (uint32_t)C << 23 | (uint32_t)Rb << 26 | (uint32_t)fdt << 29 | (uint32_t)dmask << 30;
+    o.w[3] = (uint32_t)tr_addr;
+    return o;
+}
+template <int NX> struct MfmaTab { MfmaWords lane[64]; };
+template <int NX>
+MPC_HD constexpr MfmaTab<NX> mfma_make_tab() {
+    MfmaTab<NX> t{};
+    for (int l = 0; l < 64; ++l) t.lane[l] = mfma_lane_words<NX>(l);
+    return t;
+}
+#if defined(__HIPCC__)
+template <int NX> __device__ const MfmaTab<NX> g_mfma_tab = mfma_make_tab<NX>();
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// the four words of a lane (kept in registers by the caller from round to round)
+template <int NX>
+__device__ __forceinline__ MfmaWords mfma_lane_load(int lane) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&g_mfma_tab<NX>.lane[lane & 63]);
+    return MfmaWords{{v.x, v.y, v.z, v.w}};
+}
+template <int NX>
+__device__ __forceinline__ void mfma_lane_setup(MfmaLane<NX>& m, const MfmaWords& w, double dt) {
+    m.oB[0] = (int)(w.w[0] & 255u); m.oB[1] = (int)((w.w[0] >> 8) & 255u); m.oAA[0] = (int)((w.w[0] >> 16) & 255u); m.oAA[1] = (int)(w.w[0] >> 24);
+    m.oHC = (int)(w.w[1] & 255u); m.oHA = (int)((w.w[1] >> 8) & 255u); m.oF1 = (int)((w.w[1] >> 16) & 255u); m.oF2 = (int)(w.w[1] >> 24);
+    const uint32_t f = w.w[2];
+    m.pk_row = (int)(f & 63u) - 1;
+    m.k_off = (int)((f >> 6) & 127u) - 1;
+    m.dz_row = (int)((f >> 13) & 15u) - 1;
+    m.dz_next = ((f >> 17) & 1u) != 0u;
+    m.fix = (int)((f >> 18) & 3u);
+    m.R = (int)((f >> 20) & 7u); m.C = (int)((f >> 23) & 7u); m.Rb = (int)((f >> 26) & 7u);
+    m.fscale = ((f >> 29) & 1u) ? dt : 1.0;
+    m.dmask = ((f >> 30) & 1u) ? 1.0 : 0.0;
+    m.tr_addr = (int)w.w[3];
 }
 
 // What the sweeps need to know about the instance (wave-uniform)
@@ -378,30 +420,42 @@ __device__ __forceinline__ void mfma_forward(const PRef& P, const MfmaLane<NX>& 
         const double xs = wv_dpp<DPP_SHR4, 0x2>(X[q], wv_dpp<DPP_SHL8, 0x1>(X[q], X[q]));      // bank (0, 1) <- bank (1, *)
         if (ok[q] && m.dz_next) rec[q][doff[q] - RC::SIZE] = xs;
     }
-    auto fstage = [&](int k) {
+    // The result of a stage is stored one stage LATER, behind the operand reads of the stage after: the LDS returns in order, so a write
+    // between the product and the next reads would sit in front of them in the queue the chain waits on (177 -> 141 ticks per stage).
+    double Sprev[NI];
+    auto flush = [&]() {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            if (ok[q]) rec[q][doff[q]] = Sprev[q];
+            doff[q] += inc;
+        }
+    };
+    auto fstage = [&](int k, auto first_tag) {
         double n1[NI], n2[NI], S[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             mpc_lds_cptr rn = rec[q] + (k + 1) * RC::SIZE;                                  // (stage N: the terminal record, read and not used)
             n1[q] = rn[m.oF1]; n2[q] = rn[m.oF2];
         }
+        // (dx_k over record k's -c, du_{k-1} over record k - 1's A: both records' operands were read before -- LDS operations of a wavefront keep their order)
+        if (!decltype(first_tag)::value) flush();
 #pragma unroll
         for (int q = 0; q < NI; ++q) S[q] = wv_mfma(f1[q] + m.fscale * f2[q], X[q], 0.0);
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             S[q] = wv_sum_hi(S[q]);                                              // lane (x, *, lo, 0) = x~'[4 lo + x]: dx_{k+1}, du_k in rows 6, 7
-            // (record k's operands were read a stage ago, record k + 1's at the top of this one: LDS operations of a wavefront keep their order)
-            if (ok[q]) rec[q][doff[q]] = S[q];
-            doff[q] += inc;
+            Sprev[q] = S[q];
             S[q] = fix ? fixval : S[q];
             X[q] = wv_dpp<DPP_SHL4, 0x6>(S[q], S[q]);                            // block (hi, lo) <- x~_hi
             f1[q] = n1[q]; f2[q] = n2[q];
         }
     };
-    {
-        int k = 0;
-        for (; k + 1 < N; k += 2) { fstage(k); fstage(k + 1); }
-        if (k < N) fstage(k);
+    if (N >= 1) {
+        fstage(0, std::true_type{});
+        int k = 1;
+        for (; k + 1 < N; k += 2) { fstage(k, std::false_type{}); fstage(k + 1, std::false_type{}); }
+        if (k < N) fstage(k, std::false_type{});
+        flush();
     }
     if (st && !m.dz_next) {                                                  // du_N = 0
 #pragma unroll

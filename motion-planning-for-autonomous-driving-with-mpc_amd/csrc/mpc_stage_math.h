@@ -249,8 +249,18 @@ __device__ __forceinline__ WsRefI ws_ref3(const PRef& P, const int32_t* arr, uin
 //   MPC_KM(arr, R, dk, e) mailbox array (instance-major): row e of stage k + dk of thread c
 #define MPC_KM(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, ((uint32_t)(dk) * MPC_EV(R) + (uint32_t)(e)) * 8u, \
                                      (((uint32_t)c.b * (uint32_t)(P.N + 1) + (uint32_t)c.k) * MPC_EV(R)) * 8u}
+//   MPC_KI(arr, R, dk, e) mailbox array of the ITERATE (MZ ... MREF), stage-fastest inside the block of a workgroup's bx instances:
+//                         [workgroup][row pair][stage * bx + instance of the block][2] -- the same memory as the instance-major form (a
+//                         permutation inside the block), but the 16-byte pieces the stage threads of a wavefront touch with one instruction
+//                         are contiguous (8 cache lines per wave instruction instead of one per lane).  The layout belongs to the launch
+//                         (P.bx): k_solve_wg fills these arrays when it takes its instances over and reads them back when it leaves.
+#define MPC_KI(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, \
+                                     ((((uint32_t)(e) >> 1) * (uint32_t)(P.N + 1) + (uint32_t)(dk)) * (uint32_t)P.bx * 2u + ((uint32_t)(e) & 1u)) * 8u, \
+                                     (((uint32_t)c.b & ~((uint32_t)P.bx - 1u)) * (uint32_t)(P.N + 1) * MPC_EV(R) + ((uint32_t)c.k * (uint32_t)P.bx + ((uint32_t)c.b & ((uint32_t)P.bx - 1u))) * 2u) * 8u}
 #else
 typedef Params PRef;
+#define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)((uint32_t)c.b & ~((uint32_t)P.bx - 1u)) * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * P.bx * 2 + \
+                                     ((size_t)(c.k + (dk)) * P.bx + ((uint32_t)c.b & ((uint32_t)P.bx - 1u))) * 2 + ((uint32_t)(e) & 1u)])
 #define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
@@ -265,7 +275,7 @@ typedef Params PRef;
 #endif
 //   MPC_KX(ARR, R, dk, e) array ARR of the iterate: the instance-major mailbox copy MARR where the phase is instantiated with MB (the
 //                         workgroup-resident path), the tile-major array otherwise
-#define MPC_KX(arr_, R, dk, e) (MB ? MPC_KM(P.M##arr_, R, dk, e) : MPC_K(P.arr_, R, dk, e))
+#define MPC_KX(arr_, R, dk, e) (MB ? MPC_KI(P.M##arr_, R, dk, e) : MPC_K(P.arr_, R, dk, e))
 // CNT consecutive rows starting at an EVEN row: pairs with 16-byte accesses, an odd last row on its own.  `ref(e)` names
 // row e of the run (use MPC_ROWS around one of the accessors above, written in terms of `e`).
 #define MPC_ROWS(expr) [&](int e) -> decltype(auto) { return (expr); }
@@ -748,49 +758,6 @@ MPC_HD void load_obst(const PRef& P, Ctx<NX>& c) {
     for (int i = 0; i < 6; ++i) c.obst[i] = (!BATCH_WIDE && P.per_inst_obst) ? (double)MPC_S(P.OBST, i) : P.obst[i];
 }
 
-// what a stage thread of k_solve_wg keeps in registers from one round to the next (phase_preload<.., KEEP>): the iterate of its stage with
-// its multipliers, the reference and the state of the next stage -- nothing else of the context lives across the KKT solves
-template <int NX>
-struct CtxKeep {
-    static constexpr int NZ = NX + 2;
-    double z[NZ], zl[NZ], zu[NZ], lam[NX], rn[NX], xn[NX], r0[NX], so[3], nuo[3], zlo[3], zuo[3], obst[6];
-};
-template <int NX, uint32_t VM>
-MPC_HD void ctx_keep(const Ctx<NX>& c, CtxKeep<NX>& q, bool has_ou) {
-#pragma unroll
-    for (int i = 0; i < NX + 2; ++i) { q.z[i] = c.z[i]; if ((VM >> i) & 1u) { q.zl[i] = c.zl[i]; q.zu[i] = c.zu[i]; } }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { q.lam[i] = c.lam[i]; q.rn[i] = c.rn[i]; q.xn[i] = c.xn[i]; q.r0[i] = c.r0[i]; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { q.so[j] = c.so[j]; q.nuo[j] = c.nuo[j]; q.zlo[j] = c.zlo[j]; if (has_ou) q.zuo[j] = c.zuo[j]; }
-    if (!(VM & 0x100u)) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) q.obst[j] = c.obst[j];
-    }
-}
-// (a path that leaves the stage phases early has nothing to keep: saying so spares the registers of the old values through the phases)
-template <int NX>
-MPC_HD void ctx_forget(CtxKeep<NX>& q) {
-    double* v = reinterpret_cast<double*>(&q);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(CtxKeep<NX>) / sizeof(double)); ++i) v[i] = 0.0;
-}
-template <int NX, uint32_t VM>
-MPC_HD void ctx_restore(const PRef& P, Ctx<NX>& c, const CtxKeep<NX>& q, bool has_ou) {
-#pragma unroll
-    for (int i = 0; i < NX + 2; ++i) { c.z[i] = q.z[i]; c.zl[i] = ((VM >> i) & 1u) ? q.zl[i] : 0.0; c.zu[i] = ((VM >> i) & 1u) ? q.zu[i] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { c.lam[i] = q.lam[i]; c.rn[i] = q.rn[i]; c.xn[i] = q.xn[i]; c.r0[i] = q.r0[i]; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { c.so[j] = q.so[j]; c.nuo[j] = q.nuo[j]; c.zlo[j] = q.zlo[j]; c.zuo[j] = has_ou ? q.zuo[j] : 0.0; }
-    if (VM & 0x100u) load_obst<NX, true>(P, c);
-    else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) c.obst[j] = q.obst[j];
-    }
-}
-
-
 // =========================================================================================================
 // Start-point safeguard (one instance per thread, before the init kernel).
 // The caller's x0 is IPOPT's starting point in the reference (optimizer.py:602,607).  The reference's very first
@@ -1083,33 +1050,19 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
 // that needs nothing else: slack steps ds = J dx + (d - s) and multiplier steps dlam = -(P dx + p) - lam
 // MB (here, in phase_eval_assemble and phase_finish): the step, the cost-to-go and the stage blocks travel through the instance-major
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
-// KEEP (k_solve_wg, second and later rounds of a workgroup on its instances): the context still holds the iterate, its multipliers, the
-// reference of the next stage and x_{k+1} as the last round's update and neighbour exchange left them -- bit for bit what that round stored
-// and this one would load; only what the KKT solve produced in between (step, cost-to-go) and the stage-0 friction rows come from memory
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool KEEP = false>
+// REC (MB only): also read what the sweeps left in the LDS record (step, cost-to-go); false: memory only -- k_solve_wg issues these
+// loads between its two sweeps and reads the record once the forward sweep is through (phase_preload_rec)
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool REC = true>
 MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
-    if (KEEP) {
-        static_assert(!KEEP || (MB && ROLE == ROLE_ALL), "the kept context is the workgroup-resident path's");
-        rec_load<2>(c.rec + Rec<NX>::DU, c.dz);
-        rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2);
-        if (k < N) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn);
-        else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) tmp.lam[i] = c.lam[i];
-        rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk);
-    } else {
     if (MPC_RB) load_obst<NX, (VM & 0x100u) != 0u>(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
     // (MB: step and cost-to-go come from the LDS record the sweeps of this workgroup left them in -- see Rec)
-    if (MB) { rec_load<2>(c.rec + Rec<NX>::DU, c.dz); rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2); }
+    if (MB) { if (REC) { rec_load<2>(c.rec + Rec<NX>::DU, c.dz); rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2); } }
     else ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), c.dz);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
@@ -1131,7 +1084,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     if (MPC_RA && k < N) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
-        if (MB) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
+        if (MB) { if (REC) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); } else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
@@ -1140,7 +1093,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
 #pragma unroll
         for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
-        if (MB) rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk); else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
+        if (MB) { if (REC) rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk); } else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
     }
     c.so[0] = c.so[1] = c.so[2] = 0.0;
     c.nuo[0] = c.nuo[1] = c.nuo[2] = 0.0;
@@ -1152,7 +1105,6 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         if (MPC_HAS_OL) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
         if (MPC_HAS_OU) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
     }
-    }   // !KEEP
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
     if (MPC_RA && k == 0) {                                // (fric_row is not known yet; the values are only used if it is set)
@@ -1165,6 +1117,17 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         c.gfr0[1] = MPC_S(P.SC, SC_GFR1);
         c.gfr0[2] = MPC_S(P.SC, SC_GFR2);
     }
+}
+
+// the part of phase_preload<.., MB, .., REC = false> left out: step and cost-to-go from the LDS record
+template <int NX>
+MPC_HD void phase_preload_rec(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
+    using D = Dim<NX>;
+    if (!c.valid) return;
+    rec_load<2>(c.rec + Rec<NX>::DU, c.dz);
+    rec_load<NX>(c.rec + Rec<NX>::DX, c.dz + 2);
+    if (c.k < P.N) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn);
+    rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk);
 }
 
 // arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam

@@ -154,18 +154,13 @@ constexpr uint32_t REF_VM = PAIR_VM | MPC_REF_FLAGS;
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
-// stage_block_ctx: the context is the caller's.  `keep` (k_solve_wg only, wave-uniform): it still holds the iterate of these instances from
-// the caller's last call -- see phase_preload<.., KEEP>
-template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu, bool KEEPS = false>
-__device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
-                                                const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp,
-                                                uint32_t* live_out, const bool bounds_in_lds, CtxKeep<NX>& kept, const bool keep,
-                                                const mpc_lds_ptr rec_base = nullptr) {
+template <int NX, bool INIT, int MAXT, uint32_t VM = 0xFFu>
+__device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
+                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
+                                            uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
     int or_parity = 0;
     Ctx<NX> c;
-    // (the workgroup-resident kernel with the compiled-in bound structure fits the register file without the stash: -650 instructions,
-    //  -490 of them scalar-register reloads, k_solve_wg 304 -> 295 us on the headline batch; neutral in the pipeline's stage workers)
-    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH && !MB;
+    constexpr bool STASH = MAXT <= 256 && MPC_STAGE_STASH;
     const bool has_ou = (VM & VM_OSPEC) ? false : (P.has_ou != 0);     // (what the stash parks)
     const int bx = P.bx, t = threadIdx.x;
     c.k = t / bx;
@@ -179,15 +174,12 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
     MPC_STAMP(0);
     if (!INIT) {
         const unsigned long long m = tile_bits >> (b0 & 63u);
-        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) { if (KEEPS) ctx_forget(kept); return; }
+        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
     }
     // LDS: [reduction scratch | bounds table | exchange / stash rows | prefetch images]
-    // (MB -- k_solve_wg, ONE wavefront per workgroup: no reduction scratch, no exchange rows; `lds` is the bounds table, rec_base the
-    //  records of the workgroup's instances)
-    double* lds_b = MB ? lds : lds + (blockDim.x >> 6) * 10 * bx;
+    double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
     const int nb = (P.N + 1) * (NX + 2);
     double* lds_x = lds_b + 2 * nb;
-    if (MB) c.rec = rec_base + ((t & (bx - 1)) * (P.N + 1) + (c.k <= P.N ? c.k : 0)) * Rec<NX>::SIZE;
     // (a persistent stage worker of the pipeline copies the table -- the same for every item of the batch -- once: nothing else of
     //  its work items touches that part of the LDS)
     if (!bounds_in_lds)
@@ -203,8 +195,7 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        if (KEEPS && keep) { ctx_restore<NX, VM>(P, c, kept, has_ou); phase_preload<NX, MB, ROLE_ALL, VM, KEEPS>(P, c, tmp); }
-        else phase_preload<NX, MB, ROLE_ALL, VM>(P, c, tmp);         // every array load of the kernel is in flight before the first wait
+        phase_preload<NX, false, ROLE_ALL, VM>(P, c, tmp);           // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         // (the bounds table is read from here on: a block that has just copied it passes a barrier -- behind its loads, which are in flight;
@@ -214,7 +205,7 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
         // t / bx of column t % bx, a wavefront covers 64 / bx consecutive stages, and the last wavefront starts at a stage <= N), and all
         // stage threads of an instance hold the same flags (they come out of the block-wide reductions bit for bit) -- so the vote of one
         // wavefront is the vote of the block.  Three barriers + LDS round trips less per work item.
-        if (!__any(c.active ? 1 : 0)) { if (KEEPS) ctx_forget(kept); return; }
+        if (!__any(c.active ? 1 : 0)) return;
         MPC_STAMP(2);
         Red1 r1;
         phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
@@ -232,19 +223,11 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
         }
         if (STASH) stash_xfer<NX, false, VM>(c, stash, blockDim.x, t, has_ou);
         MPC_STAMP(5);
-        phase_apply_update<NX, MB, ROLE_ALL, VM>(P, c);
+        phase_apply_update<NX, false, ROLE_ALL, VM>(P, c);
         MPC_STAMP(6);
     }
-    // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
-    if (MB) {
-        // (one wavefront: the neighbour is lane t + bx)
-        const int tn = t + bx;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const double xs = __shfl_down(c.z[2 + i], (unsigned)bx, 64), ls = __shfl_down(c.lam[i], (unsigned)bx, 64);
-            if (tn < (int)blockDim.x) { c.xn[i] = xs; c.lamn[i] = ls; }
-        }
-    } else {
+    // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
+    {
         double* ex = lds_x;                                   // behind the reduction scratch and the bounds table
         const int T = blockDim.x;
 #pragma unroll
@@ -258,22 +241,13 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
     }
     MPC_STAMP(7);
     Red3 r3;
-    phase_eval_assemble<NX, !INIT, MB, VM>(P, c, r3);
-    if (MB && !INIT) {
-        // the instance's stage threads of this wavefront vote; the first of them leaves the (sticky) mark for the MFMA sweeps
-        const unsigned long long bal = __ballot((c.active && c.ill) ? 1 : 0);
-        // (lanes of this thread's instance column: every bx-th lane -- bx is a power of two)
-        const unsigned long long col = (bx >= 64 ? 1ull : ~0ull / ((1ull << bx) - 1ull)) << (t & (bx - 1));
-        if (bal != 0ull && c.active && (bal & col) != 0ull && ((t & 63) < bx)) MPC_S(P.ISC, IS_ILL) = 1;
-    }
+    phase_eval_assemble<NX, !INIT, false, VM>(P, c, r3);
     MPC_STAMP(8);
     block_reduce(r3, bx, lds);
     MPC_STAMP(9);
-    phase_finish<NX, MB>(P, c, r3, n_mult, n_z);
-    if (KEEPS) ctx_keep<NX, VM>(c, kept, has_ou);
+    phase_finish<NX, false>(P, c, r3, n_mult, n_z);
     MPC_STAMP(10);
     // convergence poll without an extra kernel: the stage-0 threads (all in wave 0) count the instances still iterating
-    // (k_solve_wg: the same ballot IS the activity mask of its next round -- bit l: instance b0 + l goes on; no status row is re-read)
     if (live_out != nullptr && t < 64) {
         const unsigned long long m = __ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0);
         if (t == 0) *live_out = (uint32_t)m;
@@ -284,12 +258,100 @@ __device__ __forceinline__ void stage_block_ctx(const PRef& P, const int n_mult,
     }
 #undef MPC_STAMP
 }
-template <int NX, bool INIT, int MAXT, bool MB = false, uint32_t VM = 0xFFu>
-__device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0,
-                                            const unsigned long long tile_bits, double* lds, int (*or_slots)[8], const bool stamp = true,
-                                            uint32_t* live_out = nullptr, const bool bounds_in_lds = false) {
-    CtxKeep<NX> none;
-    stage_block_ctx<NX, INIT, MAXT, MB, VM, false>(P, n_mult, n_z, stash_rows, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, none, false);
+
+// ---------------------------------------------------------------------------------------------------------------
+// The stage work of a round of k_solve_wg (ONE wavefront per workgroup: bx = 1 or 2 instances, their stage threads the lanes) -- the same
+// phases, bit for bit, as stage_block:
+//   mid()          the forward sweep of the KKT solve (called from here so that the stage context is this function's own: declared in the
+//                  kernel's scope it cost 270 spilled registers);
+//   then           everything the phases read from MEMORY (per-instance scalars, the iterate with its multipliers, the references) is
+//                  requested; step and cost-to-go come from the LDS records the sweeps left them in (Rec), then the phases; the new stage blocks go
+//                  straight into the records (and to the mailbox copy a repeated sweep rebuilds them from); neighbour stages are
+//                  exchanged by lane shuffles; no reduction touches the LDS.
+// What the kernel and the phases hand each other besides the records:
+//   fail  in : bit g: the sweeps of this round gave instance g up (no admissible inertia correction): its threads see status -7
+//   ill   out: bit g: a circle row of instance g carries a large weight (the sticky IS_ILL mark, also written to the workspace)
+//   c0    out: LDS, 8 doubles per instance: c_0 = x_0 - r_0 at the new iterate, the start of the next forward sweep
+// ---------------------------------------------------------------------------------------------------------------
+struct WgIo { uint32_t fail; uint32_t ill; double* c0; };
+template <int NX, uint32_t VM, class Mid>
+__device__ __forceinline__ void wg_stage(const PRef& P, const uint32_t b0, double* lds_bnd, const mpc_lds_ptr rec_base, const int n_mult, const int n_z, const bool stamp,
+                                         uint32_t* live_out, WgIo& io, Mid&& mid) {
+    const int bx = P.bx, t = threadIdx.x;
+    Ctx<NX> c;
+    PreTmp<NX> tmp;
+    c.k = t / bx;
+    c.b = (int)b0 + (t & (bx - 1));
+    c.valid = (c.k <= P.N) && (c.b < P.B);
+    c.active = false;
+    c.ill = false;
+    c.status = 0;
+    c.iters = 0;
+    c.rec = rec_base + ((t & (bx - 1)) * (P.N + 1) + (c.k <= P.N ? c.k : 0)) * Rec<NX>::SIZE;
+    c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_bnd;
+    c.bnd_ub = (P.N + 1) * (NX + 2);
+    // (Measured: with mid() BEHIND the two calls below -- the loads requested under the forward sweep -- the sweep takes 2.9 k ticks longer and
+    //  the phases start 2.5 k earlier: what the ~50 loads cost is their ISSUE, ~55 ticks each, wherever it happens, not their latency.)
+    mid();
+    phase_load_scalars<NX>(P, c);
+    phase_preload<NX, true, ROLE_ALL, VM, false>(P, c, tmp);
+#define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    MPC_STAMP(0);
+    if (((io.fail >> (t & (bx - 1))) & 1u) && c.valid) { c.status = -7; c.active = false; }      // (what the sweep has written to the status row)
+    phase_preload_rec<NX>(P, c, tmp);
+    phase_premath<NX>(P, c, tmp);
+    MPC_STAMP(1);
+    if (!__any(c.active ? 1 : 0)) return;
+    MPC_STAMP(2);
+    Red1 r1;
+    phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
+    MPC_STAMP(3);
+    block_reduce(r1, bx, nullptr);
+    phase_linesearch_begin<NX>(P, c, r1);
+    MPC_STAMP(4);
+    while (__any((c.active && c.searching) ? 1 : 0)) {
+        Red2 r2;
+        phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
+        block_reduce(r2, bx, nullptr);
+        phase_linesearch_decide<NX>(P, c, r2);
+    }
+    MPC_STAMP(5);
+    phase_apply_update<NX, true, ROLE_ALL, VM>(P, c);
+    MPC_STAMP(6);
+    {
+        // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate -- lane t + bx of this wavefront
+        const int tn = t + bx;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xs = __shfl_down(c.z[2 + i], (unsigned)bx, 64), ls = __shfl_down(c.lam[i], (unsigned)bx, 64);
+            if (tn < 64) { c.xn[i] = xs; c.lamn[i] = ls; }
+        }
+    }
+    MPC_STAMP(7);
+    Red3 r3;
+    phase_eval_assemble<NX, true, true, VM>(P, c, r3);
+    {
+        // the instance's stage threads vote; the first of them leaves the (sticky) mark for the MFMA sweeps
+        const unsigned long long bal = __ballot((c.active && c.ill) ? 1 : 0);
+        const unsigned long long col0 = ~0ull / ((1ull << bx) - 1ull);            // (lanes of instance 0 of the block: every bx-th lane -- bx is a power of two < 64)
+        if (c.active && (bal & (col0 << (t & (bx - 1)))) != 0ull && t < bx) MPC_S(P.ISC, IS_ILL) = 1;
+        io.ill |= ((bal & col0) != 0ull ? 1u : 0u) | ((bx > 1 && (bal & (col0 << 1)) != 0ull) ? 2u : 0u);
+        if (c.k == 0 && c.active) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) io.c0[(t & (bx - 1)) * 8 + i] = c.z[2 + i] - c.r0[i];
+        }
+    }
+    MPC_STAMP(8);
+    block_reduce(r3, bx, nullptr);
+    MPC_STAMP(9);
+    phase_finish<NX, true>(P, c, r3, n_mult, n_z);
+    MPC_STAMP(10);
+    // (the ballot IS the activity mask of the next round -- bit l: instance b0 + l goes on; no status row is re-read)
+    {
+        const unsigned long long m = __ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0);
+        if (t == 0) *live_out = (uint32_t)m;
+    }
+#undef MPC_STAMP
 }
 
 #ifndef MPC_WITH_PAIR
@@ -433,7 +495,7 @@ __global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(c
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
     // scalar load, uniform branch: finished workgroups leave without any vector memory traffic
     const unsigned long long bits = (!INIT && P.tile_mask != nullptr) ? P.tile_mask[b0 >> 6] : ~0ull;
-    stage_block<NX, INIT, MAXT, false, VM>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
+    stage_block<NX, INIT, MAXT, VM>(P, n_mult, n_z, stash_rows, b0, bits, lds, or_slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -886,7 +948,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         if (VAR == 1) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
         else
 #endif
-        stage_block<NX, false, 256, false, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
+        stage_block<NX, false, 256, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's rows are in the L2
@@ -949,13 +1011,13 @@ __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_
         if (keep_first) {
             // (an instance that came out of the pipeline stalled has never been taken over: its iterate is still tile-major)
             if (first_tiled) ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);
-            else ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
+            else ws_load_rows<NZ>(MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)), v);
             ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, MPC_EV(NZ) + e)), v);
             if (c.k == 0) MPC_S(P.SC, SC_E0S) = (double)MPC_S(P.SC, SC_E0);
         }
         // (the scratch of the warm start: the tile-major rows of the cost-to-go, which this kernel does not use)
         if (carry) {
-            ws_load_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);
+            ws_load_rows<NZ>(MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)), v);
             ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), v);
         }
         if (from_xs) {
@@ -999,7 +1061,7 @@ __device__ __attribute__((noinline)) void wg_restore_first(const PRef& P, const 
     if (c.k <= P.N && c.b < P.B) {
         double v[MPC_EV(NZ)];
         ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, MPC_EV(NZ) + e)), v);
-        ws_store_rows<NZ>(MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)), v);          // (the hand-back at the end of the kernel copies these rows ...
+        ws_store_rows<NZ>(MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)), v);          // (the hand-back at the end of the kernel copies these rows ...
         ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), v);             //  ... unless no level ever got a round: then these are what k_egest reads)
         if (c.k == 0) {
             MPC_S(P.SC, SC_E0) = (double)MPC_S(P.SC, SC_E0S);
@@ -1028,14 +1090,8 @@ __device__ __forceinline__ bool resc_last(int q) { return q == 2 || q == 7; }
 template <int NX>
 struct WgLds {
     static constexpr int PAD = Rec<NX>::SIZE > 64 ? Rec<NX>::SIZE : 64;
-    __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2); }
+    __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2) + (size_t)8 * bxw; }
 };
-// (the stage threads of k_solve_wg keep their iterate in registers from round to round -- measured: the registers it takes through the
-//  sweeps cost more in scratch traffic than the loads it saves; kept as a switch)
-constexpr bool WG_KEEP = false;
-#ifndef MPC_DBG_REBUILD
-#define MPC_DBG_REBUILD 0
-#endif
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
                                                                    const WgRescue resc) {
@@ -1063,11 +1119,15 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     const mpc_lds_ptr recs = (mpc_lds_ptr)(lds_ptr_t)lds + WgLds<NX>::PAD;
     const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds;
     double* const lds_bnd = lds + WgLds<NX>::PAD + (size_t)RC::SIZE * ((N + 1) * bx);
+    double* const lds_c0 = lds_bnd + 2 * (N + 1) * D::NZ;       // 8 doubles per instance: c_0 of the last stage phases
     bool bounds_ok = false;
+    // per instance (slot g of the workgroup), wave-uniform and in registers from round to round: the last inertia correction, the mark of
+    // heavily weighted circle rows -- read from the workspace when the instances are taken over
+    double dl0 = 0.0, dl1 = 0.0;
+    WgIo io{0u, 0u, lds_c0};
+    const MfmaWords lane_words = mfma_lane_load<NX>(lane);
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
-    CtxKeep<NX> ctx;                              // what the stage threads keep from round to round (phase_preload<.., KEEP>)
-    bool keep = false;
     if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
@@ -1136,7 +1196,6 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
             }
             fresh = true;
-            keep = false;
             bounds_ok = false;                    // (the restart used the whole LDS)
             continue;
         }
@@ -1154,15 +1213,21 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 ws_store_rows<CNT>(to, v);
             };
             constexpr int NZ = D::NZ;
-            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZ, NZ, 0, e)));
-            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZL, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZL, NZ, 0, e)));
-            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZU, NZ, 0, e)), MPC_ROWS(MPC_KM(P.MZU, NZ, 0, e)));
-            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.SO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MSO, 3, 0, e)));
-            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MNUO, 3, 0, e)));
-            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MZLO, 3, 0, e)));
-            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), MPC_ROWS(MPC_KM(P.MZUO, 3, 0, e)));
-            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), MPC_ROWS(MPC_KM(P.MLAM, NX, 0, e)));
-            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.REF, NX, 0, e)), MPC_ROWS(MPC_KM(P.MREF, NX, 0, e)));
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)));
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZL, NZ, 0, e)), MPC_ROWS(MPC_KI(P.MZL, NZ, 0, e)));
+            move(std::integral_constant<int, NZ>{}, MPC_ROWS(MPC_K(P.ZU, NZ, 0, e)), MPC_ROWS(MPC_KI(P.MZU, NZ, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.SO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MSO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MNUO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MZLO, 3, 0, e)));
+            move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MZUO, 3, 0, e)));
+            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), MPC_ROWS(MPC_KI(P.MLAM, NX, 0, e)));
+            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.REF, NX, 0, e)), MPC_ROWS(MPC_KI(P.MREF, NX, 0, e)));
+        }
+        if (fresh) {
+            // (the rows just moved are read by OTHER lanes too -- the neighbour stage's --: they are in the L2 before anything loads them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // ---- stage blocks -> LDS records (every stage thread its own; defect negated, three constants, Hux of stage 0).  Only when the
         //      instances have just been taken over (the blocks were written tile-major by the start-iterate kernel or the pipeline) and
@@ -1186,7 +1251,18 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 r[RC::HX + 1] = hx1;
             }
         };
-        if (fresh || MPC_DBG_REBUILD) build_records();
+        if (fresh) {
+            build_records();
+            const int b1 = (int)b0 + (bx > 1 ? 1 : 0);
+            dl0 = MPC_UB(P.SC, (uint32_t)SC_DLAST, (int)b0 < P.B ? (int)b0 : 0);
+            dl1 = MPC_UB(P.SC, (uint32_t)SC_DLAST, b1 < P.B ? b1 : 0);
+            io.ill = ((int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, (int)b0 < P.B ? (int)b0 : 0) != 0 ? 1u : 0u) |
+                     ((bx > 1 && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, b1 < P.B ? b1 : 0) != 0) ? 2u : 0u);
+            if (valid && c.k == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lds_c0[(t & (bx - 1)) * 8 + i] = MPC_S(P.SC, SC_C0 + i);
+            }
+        }
         if (!bounds_ok) {
             const int nb = (N + 1) * D::NZ;
             for (int q = t; q < nb; q += 64) { lds_bnd[q] = MPC_GP(P.LB, q); lds_bnd[nb + q] = MPC_GP(P.UB, q); }
@@ -1195,29 +1271,33 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         lds_barrier();
         fresh = false;
         WG_STAMP(13);
-        // (per-lane operand offsets of the sweeps: rebuilt every round from a lane id the compiler cannot see through, so that they are
-        //  not hoisted out of the loop and kept in registers across stage_block)
-        int lane_v = lane;
-        asm volatile("" : "+v"(lane_v));
+        // (per-lane operand offsets of the sweeps: unpacked every round from the lane's four table words -- opaque to the compiler here, so
+        //  that the twenty unpacked values are not hoisted out of the loop and kept in registers across stage_block)
+        MfmaWords lw = lane_words;
+        asm volatile("" : "+v"(lw.w[0]), "+v"(lw.w[1]), "+v"(lw.w[2]), "+v"(lw.w[3]));
         MfmaLane<NX> m;
-        mfma_lane_setup<NX>(m, lane_v, P.dt);
-        // ---- KKT solves of the live instances (two: interleaved in one instruction stream)
+        mfma_lane_setup<NX>(m, lw, P.dt);
+        // ---- KKT solves of the live instances (two: interleaved in one instruction stream), then the stage phases (wg_stage)
+        constexpr uint32_t SVM = VAR == 2 ? REF_VM : 0xFFu;
         {
             auto inst_of = [&](int g, MfmaInst& in, double& x0) {
-                const int bb = (int)b0 + g;
-                in.inst = (uint32_t)bb;
-                in.delta_last = MPC_UB(P.SC, (uint32_t)SC_DLAST, bb);
-                in.sym_hint = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, bb) != 0;
+                in.inst = b0 + (uint32_t)g;
+                in.delta_last = g ? dl1 : dl0;
+                in.sym_hint = ((io.ill >> g) & 1u) != 0u;
                 // x~_0 = (-c_0, 0.., 1) as B operand of the forward sweep (requested now, needed after the backward sweep)
                 x0 = 0.0;
                 if ((lane & 3) == 0) {
-                    if (m.Rb < NX) x0 = -(double)ws_ref3(P, P.SC, 0u, (uint32_t)bb, mpc_prow((uint32_t)(SC_C0 + m.Rb)));
+                    if (m.Rb < NX) x0 = -lds_c0[g * 8 + m.Rb];
                     else if (m.Rb == 7) x0 = 1.0;
                 }
             };
+            io.fail = 0u;
             auto finish = [&](int g, bool ok, double delta) {
                 const int bb = (int)b0 + g;
+                if (ok) { if (delta > 0.0) { if (g) dl1 = delta; else dl0 = delta; } }
+                else io.fail |= 1u << g;
                 if (lane != 0) return;
+                // (the workspace rows follow for whoever looks at the instance after this launch; nothing of this round reads them)
                 if (ok) {
                     if (delta > 0.0) MPC_UB(P.SC, (uint32_t)SC_DLAST, bb) = delta;
                     MPC_UB(P.SC, (uint32_t)SC_DELTA, bb) = delta;
@@ -1227,44 +1307,34 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             };
             // a sweep that is repeated with an inertia correction starts from the stage blocks again: its cost-to-go went over them
             auto rebuild = [&]() { lds_barrier(); build_records(); lds_barrier(); };
-            uint32_t mine = mask;
-            const int g0 = __builtin_ctz(mine);
-            mine &= mine - 1u;
-            if (mine) {
-                const int g1 = __builtin_ctz(mine);
-                MfmaInst in[2];
-                double x0[2], delta[2];
-                bool ok[2];
-                inst_of(g0, in[0], x0[0]);
-                inst_of(g1, in[1], x0[1]);
-                const mpc_lds_ptr rec[2] = {recs + g0 * (N + 1) * RC::SIZE, recs + g1 * (N + 1) * RC::SIZE};
-                mfma_backward<NX, 2>(P, m, in, rec, lane, dump, delta, ok, sweeps, rebuild);
-                mfma_forward<NX, 2>(P, m, in, rec, lane, dump, x0, ok);
+            const int g0 = __builtin_ctz(mask);
+            const bool two = (mask & (mask - 1u)) != 0u;
+            const int g1 = two ? 1 : g0;
+            MfmaInst in[2];
+            double x0[2], delta[2];
+            bool ok[2];
+            inst_of(g0, in[0], x0[0]);
+            inst_of(g1, in[1], x0[1]);
+            const mpc_lds_ptr rec[2] = {recs + g0 * (N + 1) * RC::SIZE, recs + g1 * (N + 1) * RC::SIZE};
+            typedef const MfmaInst (&In1)[1];
+            typedef const mpc_lds_ptr (&Rec1)[1];
+            typedef double (&D1)[1];
+            typedef const double (&CD1)[1];
+            typedef bool (&B1)[1];
+            typedef const bool (&CB1)[1];
+            if (two) mfma_backward<NX, 2>(P, m, in, rec, lane, dump, delta, ok, sweeps, rebuild);
+            else mfma_backward<NX, 1>(P, m, reinterpret_cast<In1>(in), reinterpret_cast<Rec1>(rec), lane, dump, reinterpret_cast<D1>(delta), reinterpret_cast<B1>(ok), sweeps, rebuild);
+            if (t == 0) sh_mask = 0u;                                 // (the stage phases leave early, before their ballot, when nothing is active)
+            // ---- the stage work of the round, with the forward sweep laid between its loads from memory and its reads of the records
+            wg_stage<NX, SVM>(P, b0, lds_bnd, recs, n_mult, n_z, rounds == 3u, &sh_mask, io, [&]() {
+                if (two) mfma_forward<NX, 2>(P, m, in, rec, lane, dump, x0, ok);
+                else mfma_forward<NX, 1>(P, m, reinterpret_cast<In1>(in), reinterpret_cast<Rec1>(rec), lane, dump, reinterpret_cast<CD1>(x0), reinterpret_cast<CB1>(ok));
                 finish(g0, ok[0], delta[0]);
-                finish(g1, ok[1], delta[1]);
-            } else {
-                MfmaInst in[1];
-                double x0[1], delta[1];
-                bool ok[1];
-                inst_of(g0, in[0], x0[0]);
-                const mpc_lds_ptr rec[1] = {recs + g0 * (N + 1) * RC::SIZE};
-                mfma_backward<NX, 1>(P, m, in, rec, lane, dump, delta, ok, sweeps, rebuild);
-                mfma_forward<NX, 1>(P, m, in, rec, lane, dump, x0, ok);
-                finish(g0, ok[0], delta[0]);
-            }
+                if (two) finish(g1, ok[1], delta[1]);
+                lds_barrier();                                       // (step and cost-to-go are in the records; nothing of the sweeps' went to memory that this round reads)
+                WG_STAMP(14);
+            });
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the status of an instance the sweeps gave up on is out)
-        lds_barrier();
-        // (producer and consumer of every row are lanes of THIS wavefront: one CU, one write-through vector L1 -- workgroup scope
-        //  orders them without the cache invalidation an agent-scope acquire costs, which would send every load of the round to the HBM)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WG_STAMP(14);
-        // ---- the stage work of the round
-        if (t == 0) sh_mask = 0u;                                     // (stage_block leaves early, before its ballot, when nothing is active)
-        stage_block_ctx<NX, false, 256, true, VAR == 2 ? REF_VM : 0xFFu, WG_KEEP>(P, n_mult, n_z, stash_rows, b0, (unsigned long long)mask << (b0 & 63u), lds_bnd, or_slots, rounds == 3u,
-                                                                                 &sh_mask, true, ctx, keep, recs);
-        keep = WG_KEEP;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1275,7 +1345,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     // the iterate goes back to the tile-major rows k_egest reads (a workgroup that found nothing to do never moved it)
     if (rounds > 0u && valid) {
         double v[D::NZ];
-        ws_load_rows<D::NZ>(MPC_ROWS(MPC_KM(P.MZ, D::NZ, 0, e)), v);
+        ws_load_rows<D::NZ>(MPC_ROWS(MPC_KI(P.MZ, D::NZ, 0, e)), v);
         ws_store_rows<D::NZ>(MPC_ROWS(MPC_K(P.Z, D::NZ, 0, e)), v);
     }
     if (stats != nullptr && t == 0) {

@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64) k_test(const Params Pk, const double* recs
     for (int q = lane; q < NI * (N + 1) * stride; q += 64) lrec[q] = recs[(size_t)inst * NI * (N + 1) * stride + q];
     __syncthreads();
     MfmaLane<NX> m;
-    mfma_lane_setup<NX>(m, lane, P.dt);
+    mfma_lane_setup<NX>(m, mfma_lane_load<NX>(lane), P.dt);
     typedef __attribute__((address_space(3))) void* lp;
     double x0[NI], delta[NI];
     bool ok[NI];
