@@ -461,7 +461,10 @@ def main():
         traffic, traffic_src = measure_traffic([tags[k] for k in loop])
     elif rank == 0:
         traffic, traffic_src = committed_traffic("+".join(loop)), "committed profiles/pmc_traffic.json"
-    roofline = dict(bound="hbm", kernel="+".join(loop), achieved=loop_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+    # bound: the roof the fraction is taken against (algorithmic bytes against the HBM peak).  limiter: what the counters say holds
+    # the kernels back -- neither roof: one wavefront per SIMD, ~half of its cycles waiting on its own dependent instruction stream
+    # (profiles/*_pmc_summary.txt: SQ_WAIT_ANY / SQ_WAVE_CYCLES ~ 0.5, VALU busy ~ 0.23, HBM traffic = 1.02 x the algorithmic bytes)
+    roofline = dict(bound="hbm", limiter="issue/latency", kernel="+".join(loop), achieved=loop_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=loop_gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     measured_copy_bw_gbs=copy_gbs, frac_vs_measured_copy_bw=(loop_gbs / copy_gbs) if copy_gbs else None,
                     copy_bw_note="the library's own 16-byte streaming copy (mpc_measure_copy_bandwidth), read + write bytes; the guide's float4 copy: 6290 GB/s",
@@ -496,39 +499,53 @@ def main():
         osol = OracleSolver(NLPConfig(N=fam.N, nx=fam.nx, Q=fam.Q, R=fam.R))
         avail = HOST_CPUS
         xs, ps = x0[:4096], p[:4096]
-        sweep = {}
-        for rnd in range(2):                                              # two passes over the thread counts: the first also places the threads
-            for cores in sorted({min(avail, c) for c in (16, 32, 64, 128, avail)}):   # OpenMP over instances, threads bound to cores
-                osol.solve_batch(xs, ps, nthreads=cores)                  # (a team of a new size is created and placed here)
+        # SUSTAINED throughput per thread count: a warm batch (the team is created and placed, the output arrays are touched), then back-to-back
+        # batches into the same arrays for ~0.8 s of wall clock (at least 5).  Why not the best single batch: the box's container runs under a
+        # CPU-time quota (cgroup cpu.max, reported below) -- a team of 128 threads finishes one batch in 6.5 ms and is then throttled for the rest
+        # of the 100 ms accounting period, every other batch takes 94 ms (tools/cpu_baseline_probe.py); round 4 took the minimum of two single
+        # batches for the sweep and got 9 x the rate the same team sustained.
+        def sustained(cores, seconds, min_batches=5):
+            out = osol.solve_batch(xs, ps, nthreads=cores)
+            ts = []
+            t_start = time.perf_counter()
+            while len(ts) < min_batches or time.perf_counter() - t_start < seconds:
                 t0 = time.perf_counter()
-                ro = osol.solve_batch(xs, ps, nthreads=cores)
-                t = time.perf_counter() - t0
-                sweep[cores] = min(sweep.get(cores, 1e30), t)
-        cores = min(sweep, key=sweep.get)
-        osol.solve_batch(xs, ps, nthreads=cores)                            # (back to the chosen team)
-        reps = max(1, int(round(3.0 / sweep[cores])))                       # ~3 s wall on the chosen thread count
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            ro = osol.solve_batch(xs, ps, nthreads=cores)
-        t_all = time.perf_counter() - t0
+                osol.solve_batch(xs, ps, nthreads=cores, out=out)
+                ts.append(time.perf_counter() - t0)
+            return len(ts) * len(xs) / (time.perf_counter() - t_start), float(np.median(ts)), len(ts), out
+        sweep, sweep_median = {}, {}
+        for cores in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):   # (SMT siblings -- all of `avail` -- only add contention: 20 k steps/s at 256 threads)
+            rate, med_t, _, _ = sustained(cores, 0.8)
+            sweep[cores], sweep_median[cores] = rate, med_t
+        cores = max(sweep, key=sweep.get)
+        value_cpu, med_t, reps, ro = sustained(cores, 3.0)                  # ~3 s on the chosen thread count: the reported value
+        agree = max(value_cpu, sweep[cores]) / max(1e-9, min(value_cpu, sweep[cores]))
         t0 = time.perf_counter()
         osol.solve_batch(xs[:1024], ps[:1024], nthreads=1)
         t_one = time.perf_counter() - t0
         n32 = min(32, avail)
-        t_32 = sweep.get(n32, 1e30)
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as fh:
+                q = fh.read().split()
+                quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+        except Exception:
+            pass
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as fh:
                 model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
         except Exception:
             pass
-        cpu_baseline = dict(value=reps * len(xs) / t_all, unit="MPC steps/s", cores=cores, kind="port",
-                            sample=f"{reps} x {len(xs)} instances of the same workload (N=30, nx=6), oracle/mpc_oracle.c, "
+        cpu_baseline = dict(value=value_cpu, unit="MPC steps/s", cores=cores, kind="port",
+                            sample=f"{reps} x {len(xs)} instances of the same workload (N=30, nx=6) back to back, oracle/mpc_oracle.c, "
                                    f"OpenMP over instances, all converged={bool((ro['status'] == 1).all())}",
-                            sample_short=f"{reps}x{len(xs)} instances, oracle C port, OpenMP bound to cores",
-                            single_thread_value=1024 / t_one, bound_32_threads_value=len(xs) / t_32, bound_threads=n32,
-                            omp_proc_bind=os.environ.get("OMP_PROC_BIND"), cpu_model=model, host_cpus=avail,
-                            sweep_steps_per_s={str(c): len(xs) / t for c, t in sorted(sweep.items())},
+                            sample_short=f"{reps}x{len(xs)} instances back to back (sustained), oracle C port, OpenMP bound to cores",
+                            single_thread_value=1024 / t_one, bound_32_threads_value=sweep.get(n32), bound_threads=n32,
+                            omp_proc_bind=os.environ.get("OMP_PROC_BIND"), cpu_model=model, host_cpus=avail, cgroup_cpu_quota=quota,
+                            median_batch_ms=med_t * 1e3, agrees_with_sweep_within=agree, stable=bool(agree <= 1.3),
+                            sweep_steps_per_s={str(c): r for c, r in sorted(sweep.items())},
+                            sweep_median_batch_ms={str(c): t * 1e3 for c, t in sorted(sweep_median.items())},
                             casadi_ipopt=casadi_probe(fam, x0, p, wl), published_casadi_ipopt=PUBLISHED_CASADI)
 
     # ---- BASELINE.json configurations 2 - 5 under the same clock (single-GPU run only; a few batches each, ~1 s in total)
@@ -578,11 +595,12 @@ def compact_line(out):
                 converged_frac=_g(out["converged_frac"]), mean_iters=_g(out["mean_iters"]), max_iters=out["max_iters"],
                 roofline=dict(bound=r["bound"], kernel=r["kernel"], achieved=_g(r["achieved"]), peak=r["peak"], unit=r["unit"], frac=_g(r["frac"], 4),
                               traffic=_g(r["traffic"]), avg_launch_us=_g(r["avg_launch_us"]), bytes_per_launch=_g(r["algorithmic_bytes_per_launch"]),
-                              copy_bw=_g(r.get("measured_copy_bw_gbs"), 4),
+                              copy_bw=_g(r.get("measured_copy_bw_gbs"), 4), whole_step=_g(r["whole_step"]["frac"], 4), limiter=r["limiter"],
                               kernels={k: [_g(v["avg_us"], 4), _g(v["gbs"], 4), _g(v["frac"], 3)] for k, v in r["kernels"].items()}))
     if cb:
         line["cpu_baseline"] = dict(value=_g(cb["value"]), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=cb["sample_short"],
-                                    one_thread=_g(cb["single_thread_value"], 4), bound32=_g(cb.get("bound_32_threads_value"), 4))
+                                    one_thread=_g(cb["single_thread_value"], 4), sweep={k: _g(v, 3) for k, v in cb["sweep_steps_per_s"].items()},
+                                    stable=cb["stable"], cpu_quota=_g(cb.get("cgroup_cpu_quota"), 3))
     else:
         line["cpu_baseline"] = None
     if out.get("configs"):
