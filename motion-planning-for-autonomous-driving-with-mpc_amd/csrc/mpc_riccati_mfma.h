@@ -292,7 +292,7 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
             wdec += w_inc;
             pdec += p_inc;
             double nb0[NI], nb1[NI], naa0[NI], naa1[NI], nhc[NI], nha[NI], nruu0[NI], nruu1[NI];
-            double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], cl[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI];
+            double L00[NI], L01[NI], L11[NI], det[NI], rc[NI], er[NI], cl[NI], S0[NI], S1[NI], B0[NI], B1[NI], T[NI], G[NI], Gs[NI], Kt[NI], Ke[NI];
             // The wavefront issues in order: the scalar chain Lam -> det -> 1 / det (ten dependent instructions) is cut into pieces that
             // are laid between the steps of the matrix chain, and the scheduling fences keep the compiler from clumping them again.
 #define MPC_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -312,7 +312,13 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
             }
             MPC_FENCE();
 #pragma unroll
-            for (int q = 0; q < NI; ++q) det[q] = fma(L00[q], L11[q], -(L01[q] * L01[q]));
+            for (int q = 0; q < NI; ++q) {
+                // (SYM -- instances with heavily weighted circle rows: Lam = Ruu + w g g' is dominated by a rank-one term, L00 L11 and L01^2 agree
+                //  to the first ten digits; Kahan's difference of products keeps the rounding error of L01^2, which is as large as det itself)
+                const double pp = L01[q] * L01[q];
+                det[q] = fma(L00[q], L11[q], -pp);
+                if (SYM) det[q] -= symq[q] ? fma(L01[q], L01[q], -pp) : 0.0;            // (per instance: an instance's bits do not depend on its wavefront mate)
+            }
             MPC_FENCE();
 #pragma unroll
             for (int q = 0; q < NI; ++q) { rc[q] = __builtin_amdgcn_rcp(det[q]); S0[q] = wv_sum_hi(S0[q]); }       // S0: lane (x, *, lo, y) = Y[4 lo + x][y]
@@ -343,12 +349,15 @@ __device__ __forceinline__ void mfma_backward(const PRef& P, const MfmaLane<NX>&
                 Gs[q] = wv_swap16(G[q]);
                 good[q] = good[q] && (L00[q] > 0.0) && (det[q] > 0.0);
                 Kt[q] = -cl[q] * G[q];                                              // -adj(Lam) Gt = L01 Gs - cl G, without waiting for 1 / det
+                if (SYM) Ke[q] = symq[q] ? fma(-cl[q], G[q], -Kt[q]) : 0.0;                         // (the rounding error of that product: the two terms cancel like those of det)
             }
             MPC_FENCE();
 #pragma unroll
             for (int q = 0; q < NI; ++q) {
                 const double GA = wv_dpp<DPP_SHL4, 0x6>(G[q], G[q]);               // block (hi, lo) = column block hi of Gt (read transposed)
-                Kt[q] = fma(L01[q], Gs[q], Kt[q]) * rc[q];                         // Kt = -Lam^-1 Gt  (rc = 1 / det: v_rcp_f64 + two Newton steps)
+                Kt[q] = fma(L01[q], Gs[q], Kt[q]);
+                if (SYM) Kt[q] += Ke[q];
+                Kt[q] *= rc[q];                                                     // Kt = -Lam^-1 Gt  (rc = 1 / det: v_rcp_f64 + two Newton steps)
                 M[q] = wv_mfma(GA, Kt[q], T[q]);                                   // M = T + Gt' Kt + delta_w I
                 if (SYM) M[q] += delta[q] * m.dmask;
                 // (per instance, so that the result of an instance does not depend on which instance shares its wavefront)

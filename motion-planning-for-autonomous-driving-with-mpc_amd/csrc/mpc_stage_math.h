@@ -1883,9 +1883,20 @@ MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>
 // Neither half stores anything: the gains and the cost-to-go stay in registers (RicGain, Ps, pv) and ric_store_stage
 // writes them as 16-byte row pairs once both halves are done -- a global store holds the issuing wave for ~25-30 cycles
 // whatever its width (tools/ubench/store_cost.hip), so 21 wide stores cost half of 41 narrow ones.
+// a b + c d with the fused operation spelled out (which of the two products the compiler fuses is otherwise its choice, per instantiation)
+#ifndef MPC_FMA2_ORDER
+#define MPC_FMA2_ORDER 0
+#endif
+#if MPC_FMA2_ORDER == 0
+#define MPC_FMA2(a, b, c, d) fma((a), (b), (c) * (d))
+#else
+#define MPC_FMA2(a, b, c, d) fma((c), (d), (a) * (b))
+#endif
 template <int NX>
 struct RicGain {
     double G0[NX], G1[NX], i00, i01, i11;       // G = B'(P+ A) (+ Hux at stage 0), Lam^-1
+    double L00, L01, L11, idet;                 // (SYM: Lam itself, for the compensated products of marked instances)
+    bool comp;
     double K0[NX], K1[NX], kf0, kf1;            // feedback gains K = -Lam^-1 G and feed-forward kff (rows of KK)
 };
 
@@ -1895,6 +1906,12 @@ struct RicGain {
 template <int NX, int NE = NX, bool SYM = true>
 MPC_HD bool ric_matrix_step(const PRef& P, int k, const RicStage<NX>& s, double delta, double hux0, double hux1, double* Ps, RicGain<NX>& g,
                             bool sym_gk = false) {
+    // Which product of a sum a b + c d is fused into the addition is, by default, the optimiser's choice -- made per INSTANTIATION, from what
+    // surrounds the expression.  A lane's bits must not depend on whether its wavefront runs the SYM instantiation (some mate carries an
+    // inertia correction) or the plain one: here the front end fuses, expression by expression as written, the same way everywhere.
+#if defined(__clang__)
+#pragma clang fp contract(on)
+#endif
     using D = Dim<NX>;
     const double dt = P.dt;
     const double a03 = s.a[0], a04 = s.a[1], a13 = s.a[2], a14 = s.a[3], a42 = s.a[4], a43 = s.a[5];
@@ -1921,18 +1938,39 @@ MPC_HD bool ric_matrix_step(const PRef& P, int k, const RicStage<NX>& s, double 
     const double L00 = s.ruu[0] + dt * dt * sym<NX>(Ps, 2, 2) + delta;
     const double L01 = dt * dt * sym<NX>(Ps, 2, 3);
     const double L11 = s.ruu[1] + dt * dt * sym<NX>(Ps, 3, 3) + delta;
-    const double det = L00 * L11 - L01 * L01;
+    // (sym_gk -- instances with heavily weighted circle rows or an inertia correction behind them: Lam = Ruu + w g g' is dominated by a rank-one
+    //  term, L00 L11 and L01^2 agree to the first ten digits and the rounding error of L01^2 is as large as det itself -- Kahan's difference of
+    //  products; likewise adj(Lam) G below.  This cancellation, not the asymmetry, was what made the collision-avoidance family a lottery of
+    //  instances wandering at a KKT error of 1e-8 ... 1e-4 (profiles/r05_ca_lottery.txt).)
+    double det = fma(-L01, L01, L00 * L11);             // (spelled out: the same bits in every instantiation)
+    if (SYM) {
+        const double l01sq = L01 * L01;
+        const double detc = fma(L00, L11, -l01sq) - fma(L01, L01, -l01sq);
+        det = sym_gk ? detc : det;
+    }
     // (no early exit when Lam is not positive definite: the lane just carries garbage to the end of the sweep, which is
     //  repeated with a larger delta_w anyway -- a divergent exit here costs every lane ~70 select instructions per stage)
     const bool pd = (L00 > 0.0) && (det > 0.0);
     const double idet = 1.0 / det;
     g.i00 = L11 * idet; g.i01 = -L01 * idet; g.i11 = L00 * idet;
+    if (SYM) { g.L00 = L00; g.L01 = L01; g.L11 = L11; g.idet = idet; g.comp = sym_gk; }
     double* K0 = g.K0;
     double* K1 = g.K1;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-        K0[j] = -(g.i00 * g.G0[j] + g.i01 * g.G1[j]);
-        K1[j] = -(g.i01 * g.G0[j] + g.i11 * g.G1[j]);
+        if (SYM) {
+            // -adj(Lam) G / det with the rounding errors of the leading products carried along (same bits as below for the instances without the mark)
+            const double a0 = L11 * g.G0[j], b0 = L00 * g.G1[j];
+            const double e0 = sym_gk ? fma(L11, g.G0[j], -a0) : 0.0, e1 = sym_gk ? fma(L00, g.G1[j], -b0) : 0.0;
+            // (the unmarked form with its fused operation spelled out: the same bits in both instantiations, whatever surrounds it)
+            const double k0 = sym_gk ? -((fma(-L01, g.G1[j], a0) + e0) * idet) : -MPC_FMA2(g.i00, g.G0[j], g.i01, g.G1[j]);
+            const double k1 = sym_gk ? -((fma(-L01, g.G0[j], b0) + e1) * idet) : -MPC_FMA2(g.i01, g.G0[j], g.i11, g.G1[j]);
+            K0[j] = k0;
+            K1[j] = k1;
+        } else {
+            K0[j] = -MPC_FMA2(g.i00, g.G0[j], g.i01, g.G1[j]);
+            K1[j] = -MPC_FMA2(g.i01, g.G0[j], g.i11, g.G1[j]);
+        }
     }
 #pragma unroll
     for (int j = NE; j < NX; ++j) { K0[j] = 0.0; K1[j] = 0.0; g.G0[j] = 0.0; g.G1[j] = 0.0; }
@@ -1974,8 +2012,11 @@ MPC_HD bool ric_matrix_step(const PRef& P, int k, const RicStage<NX>& s, double 
 }
 
 // Pn = P_{k+1} (the cost-to-go the matrix half STARTED from), g = what the matrix half of stage k left; pv: p+ -> p_k
-template <int NX, int NE = NX>
+template <int NX, int NE = NX, bool SYM = false>
 MPC_HD void ric_vector_step(const PRef& P, const RicStage<NX>& s, const double* Pn, RicGain<NX>& g, double* pv) {
+#if defined(__clang__)
+#pragma clang fp contract(on)          // (see ric_matrix_step)
+#endif
     using D = Dim<NX>;
     constexpr int NS = D::NS;
     const double dt = P.dt;
@@ -1991,7 +2032,13 @@ MPC_HD void ric_vector_step(const PRef& P, const RicStage<NX>& s, const double* 
     }
     // l = gu + B'h,  kff = -Lam^-1 l
     const double l0 = s.gu[0] + dt * h[2], l1 = s.gu[1] + dt * h[3];
-    const double kf0 = -(g.i00 * l0 + g.i01 * l1), kf1 = -(g.i01 * l0 + g.i11 * l1);
+    double kf0 = -MPC_FMA2(g.i00, l0, g.i01, l1), kf1 = -MPC_FMA2(g.i01, l0, g.i11, l1);
+    if (SYM) {           // (as for the gain rows in ric_matrix_step)
+        const double a0 = g.L11 * l0, b0 = g.L00 * l1;
+        const double c0 = -((fma(-g.L01, l1, a0) + fma(g.L11, l0, -a0)) * g.idet), c1 = -((fma(-g.L01, l0, b0) + fma(g.L00, l1, -b0)) * g.idet);
+        kf0 = g.comp ? c0 : kf0;
+        kf1 = g.comp ? c1 : kf1;
+    }
     g.kf0 = kf0;
     g.kf1 = kf1;
     // p_k = gx + A'h + G'kff
@@ -2040,7 +2087,7 @@ MPC_HD bool riccati_backward_step(const PRef& P, uint32_t bb, int k, const RicSt
     for (int i = 0; i < NS; ++i) Pn[i] = Ps[i];
     RicGain<NX> g;
     if (!ric_matrix_step<NX, NE, SYM>(P, k, s, delta, hux0, hux1, Ps, g, sym_gk)) return false;
-    ric_vector_step<NX, NE>(P, s, Pn, g, pv);
+    ric_vector_step<NX, NE, SYM>(P, s, Pn, g, pv);
     ric_store_stage<NX>(P, bb, k, Ps, pv, g);
     return true;
 }

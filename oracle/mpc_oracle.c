@@ -644,15 +644,21 @@ static int solve_impl(const mpco_desc* d, const double* lbx_in, const double* ub
                     L[a][a] += delta;
                     l[a] = W->gu[k][a] + d->dt * h[2 + a];
                 }
-                const double det = L[0][0] * L[1][1] - L[0][1] * L[1][0];
+                /* Lam = Ruu + B'P+B is dominated by a rank-one term w g g' once a circle row is active (w = z / s up to 1e13): L00 L11 and L01^2
+                 * agree to ten digits, and so do the two products of every entry of adj(Lam) G.  Differences of products with the rounding
+                 * error of the subtracted product carried along (Kahan); without it the collision-avoidance family has instances that wander
+                 * at a KKT error of 1e-8 ... 1e-4 for dozens of iterations (profiles/r05_ca_lottery.txt). */
+                const double l01sq = L[0][1] * L[1][0];
+                const double det = fma(L[0][0], L[1][1], -l01sq) - fma(L[0][1], L[1][0], -l01sq);
                 if (!(L[0][0] > 0.0) || !(det > 0.0)) { ok = 0; break; }
-                const double i00 = L[1][1] / det, i01 = -L[0][1] / det, i11 = L[0][0] / det;
+#define DOP(a, b, c, d) (fma((a), (b), -((c) * (d))) - fma((c), (d), -((c) * (d))))      /* a b - c d */
                 for (int j = 0; j < nx; ++j) {
-                    W->K[k][0][j] = -(i00 * G[0][j] + i01 * G[1][j]);
-                    W->K[k][1][j] = -(i01 * G[0][j] + i11 * G[1][j]);
+                    W->K[k][0][j] = -DOP(L[1][1], G[0][j], L[0][1], G[1][j]) / det;
+                    W->K[k][1][j] = -DOP(L[0][0], G[1][j], L[0][1], G[0][j]) / det;
                 }
-                W->kff[k][0] = -(i00 * l[0] + i01 * l[1]);
-                W->kff[k][1] = -(i01 * l[0] + i11 * l[1]);
+                W->kff[k][0] = -DOP(L[1][1], l[0], L[0][1], l[1]) / det;
+                W->kff[k][1] = -DOP(L[0][0], l[1], L[0][1], l[0]) / det;
+#undef DOP
                 for (int i = 0; i < nx; ++i) {
                     for (int j = 0; j < nx; ++j) {
                         double s = W->Hxx[k][i][j] + (i == j ? delta : 0.0);
