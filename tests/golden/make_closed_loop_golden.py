@@ -36,7 +36,8 @@ N = 30
 class DenseBackend:
     """answers sol(...) with the literal dense IPM; records every call"""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, literal=False):
+        self.literal = literal                     # the stage-0 friction row as IPOPT sees it: lbg[0] = 0 WITH its barrier (optimizer.py:378, 424-425)
         self.cfg, self.nlp = cfg, BicycleNLP(cfg)
         self.n_w, self.n_g, self.N = cfg.n_w, cfg.n_g, cfg.N
         self.calls = []
@@ -48,7 +49,8 @@ class DenseBackend:
         x0, p = np.asarray(x0, float).ravel(), np.asarray(p, float).ravel()
         lbx, ubx, lbg, ubg = self.b
         lbg = lbg.copy()
-        lbg[0] = -np.inf                           # |y| >= 0 is implied by the absolute value (no barrier on it)
+        if not self.literal:
+            lbg[0] = -np.inf                       # |y| >= 0 is implied by the absolute value (no barrier on it)
         ipm = DenseIPM(self.nlp)
         tried = []
         r = ipm.solve(x0, p, lbg=lbg, ubg=ubg, lbx=lbx, ubx=ubx)
@@ -71,30 +73,44 @@ class DenseBackend:
         return pkg.SolveResult(r["x"][None], np.array([1], np.int32), np.array([r["iters"]], np.int32), np.array([r["kkt"]]))
 
 
-def main():
+def main(friction=False):
+    """friction: the second fixture, closed_loop_n30_friction.npz -- the same loop from a start with a NEGATIVE steering angle and a lateral
+    offset to the left, with the literal friction row: then c = -v_0^2 tan(delta_0) / 2.578 > 0 and the row sqrt((a_0^2 - c)^2) in [0, a_max]
+    vanishes at a_0 = +-sqrt(c), walls the row's slack does not cross"""
     from test_scenario import SETTINGS_LF
     settings = {k: (dict(v) if isinstance(v, dict) else v) for k, v in SETTINGS_LF.items()}
     settings["general_planning_settings"] = dict(settings["general_planning_settings"], predict_horizon=N, noised=False)
     sc = scn.read_scenario(XML)
     conf = scn.Configuration(settings, sc, 1).configuration
     assert conf.iter_length == N                    # L = N: the window is frozen from the first step
+    if friction:
+        # the variant: the (straight) reference path runs 14 points further, so that 14 steps of ordinary lane following -- small accelerations,
+        # the optimum BETWEEN the walls -- come before the window's tail freezes (optimizer.py:670-683)
+        rp, orn = np.asarray(conf.reference_path), np.asarray(conf.orientation)
+        ext = rp[-1] + (rp[-1] - rp[-2]) * np.arange(1, 15)[:, None]
+        conf.reference_path = np.vstack([rp, ext])
+        conf.orientation = np.concatenate([orn, np.full(14, orn[-1])])
+        conf.iter_length = N + 14
     pp = sc.planning_problems[1]
     init_values = (np.array(pp.initial_position), pp.initial_velocity, 0.0, pp.initial_orientation)
+    if friction:
+        th = pp.initial_orientation
+        init_values = (np.array(pp.initial_position) + 0.6 * np.array([-np.sin(th), np.cos(th)]), pp.initial_velocity, -0.03, th)
     o = opt.CasadiOptimizer(configuration=conf, init_values=init_values, predict_horizon=N)
     o.use_device_loop = False
-    be = DenseBackend(NLPConfig(N=N, nx=5, **WEIGHTS_ZAM_LF))
+    be = DenseBackend(NLPConfig(N=N, nx=5, **WEIGHTS_ZAM_LF), literal=friction)
     o._sol = opt.NlpSolverHandle(be)
     o._sol.rescue = False
     states, controls, _ = o.optimize()
     c = be.calls
-    np.savez_compressed(os.path.join(OUT, "closed_loop_n30.npz"),
+    np.savez_compressed(os.path.join(OUT, "closed_loop_n30_friction.npz" if friction else "closed_loop_n30.npz"),
                         x0=np.array([q["x0"] for q in c]), p=np.array([q["p"] for q in c]), w=np.array([q["w"] for q in c]),
                         f=np.array([q["f"] for q in c]), iters=np.array([q["iters"] for q in c]), kkt=np.array([q["kkt"] for q in c]),
                         start=np.array([q["start"] for q in c]), states=states, controls=controls,
                         path=np.asarray(conf.reference_path), orientation=np.asarray(conf.orientation), v_des=float(conf.desired_velocity),
-                        init_state=np.array([init_values[0][0], init_values[0][1], 0.0, init_values[1], init_values[3]]))
-    print("wrote closed_loop_n30.npz:", len(c), "steps; a0 of step 0 =", controls[0, 1])
+                        init_state=np.array([init_values[0][0], init_values[0][1], init_values[2], init_values[1], init_values[3]]))
+    print("wrote", "closed_loop_n30_friction.npz:" if friction else "closed_loop_n30.npz:", len(c), "steps; a0 of step 0 =", controls[0, 1])
 
 
 if __name__ == "__main__":
-    main()
+    main(friction="--friction" in sys.argv)

@@ -679,6 +679,22 @@ def test_gpu_replays_the_dense_ipm_closed_loop_triplets(golden_dir):
     assert np.abs(s2 - g["states"]).max() < TOL_TRAJ and np.abs(c2 - g["controls"]).max() < TOL_TRAJ
 
 
+@pytest.mark.parametrize("friction_lb", ["ipopt", "nlp"])
+def test_gpu_replays_the_friction_row_fixture(golden_dir, friction_lb):
+    """the loop that visits the kink of the reference's stage-0 friction row (tests/test_parity_pins.py, closed_loop_n30_friction.npz: N = 30, no
+    noise, answers of the dense IPM with the LITERAL row): the kernels with the row as IPOPT sees it (`friction_lb = ipopt`) and with the
+    default reading reproduce every triplet to north_star's 1e-4 (1e-5 in fact)"""
+    g = np.load(os.path.join(golden_dir, "closed_loop_n30_friction.npz"))
+    cfg = NLPConfig(N=30, nx=5)
+    s = make_solver(cfg)
+    set_cfg_bounds(s, cfg)
+    s.set_option("friction_lb", friction_lb)
+    r = s.solve(g["x0"], g["p"])
+    assert np.all(r.status == 1)
+    err = np.abs(r.x - g["w"]).max(axis=1)
+    assert err.max() < 1e-5 and np.mean(err < 1e-6) >= 0.9, err
+
+
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "usalf_n50_nx5", "zamca_n30_nx5"])
 def test_kkt_certificate_of_gpu_solutions(fam):
     """acceptance that does not rest on the sibling interior-point implementations: stationarity / feasibility of the KERNELS'

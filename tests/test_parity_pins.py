@@ -93,3 +93,30 @@ def test_goldens_and_oracle_answers_pass_the_kkt_certificate(loop, golden_dir):
     w = r["x"][0].copy()
     w[3] += 1e-2
     assert kkt_certificate(n, w, p[0])["stationarity"] > 1e-5
+
+
+# ---- the friction row at N = 30 without noise (round 5): a loop that visits the kink of optimizer.py:378 -------------------------------------------
+
+def test_friction_fixture_visits_the_kink_and_both_readings_of_the_row_agree(golden_dir):
+    """closed_loop_n30_friction.npz (make_closed_loop_golden.py --friction): ZAM_Over-1_1 lane following, N = 30, no noise, started 0.6 m to the
+    left of the path, 14 path points appended so that ordinary lane following precedes the frozen tail -- every sol(...) answered by the
+    dense IPM with the reference's friction row LITERAL (lbg[0] = 0 with its barrier, optimizer.py:378, 424-425).  The loop visits states
+    with delta_0 < 0, i.e. c = -v_0^2 tan(delta_0) / 2.578 > 0, where the row vanishes at a_0 = +-sqrt(c), and its answers there lie BETWEEN
+    those walls.  Both readings of the row -- `friction_lb = ipopt` (literal) and the default `nlp` (lower bound implied, presolved into a bound
+    on a_0) -- reproduce every triplet: without noise the warm start of a step is the shifted last plan, which lies on the optimum's side of
+    the walls; the two differ only for noised warm starts (tests/test_recorded_residuals.py).  That is why `nlp` stays the default."""
+    g = np.load(os.path.join(golden_dir, "closed_loop_n30_friction.npz"))
+    st, ct = g["states"], g["controls"]
+    c = -st[:, 3] ** 2 * np.tan(st[:, 2]) / 2.578
+    kink = np.flatnonzero((c > 0.1) & (np.abs(ct[:, 1]) < np.sqrt(np.maximum(c, 0.0)) - 0.05))
+    assert len(kink) >= 3 and np.all(st[kink, 2] < 0), kink                 # (steps 2, 3, 4: walls at 1.68 / 1.40 / 0.80, a_0 = 0.77 / 0.63 / 0.51)
+    cfg = NLPConfig(N=30, nx=5, **WEIGHTS_ZAM_LF)
+    for mode in ("ipopt", False):
+        r = OracleSolver(cfg, literal_friction_row=mode).solve_batch(g["x0"], g["p"], nthreads=4)
+        assert np.all(r["status"] == 1), mode
+        err = np.abs(r["x"] - g["w"]).max(axis=1)
+        assert err.max() < 1e-5 and np.mean(err < 1e-6) >= 0.9, (mode, err)
+    nlp = BicycleNLP(cfg)
+    for i in kink[:3]:
+        cert = kkt_certificate(nlp, g["w"][i], g["p"][i])
+        assert cert["stationarity"] < 1e-7 and cert["feasibility"] < 1e-6, (i, cert)
