@@ -679,6 +679,67 @@ def test_gpu_replays_the_dense_ipm_closed_loop_triplets(golden_dir):
     assert np.abs(s2 - g["states"]).max() < TOL_TRAJ and np.abs(c2 - g["controls"]).max() < TOL_TRAJ
 
 
+def test_pipeline_survives_copy_kernels_of_another_stream():
+    """multi-GPU readiness on a one-GPU box: with `--gather overlap` RCCL's copy kernels of the 8.1 MB packed block run
+    on a stream of their own WHILE the next solve's persistent k_pipeline owns every CU.  Here a second stream is kept busy with copy kernels
+    of that size for the whole duration of the solves: the pipeline's workgroups then arrive late / share their CUs, the roles are dealt by
+    arrival order and the waits are bounded -- the launch must neither be abandoned nor restarted, and the rows must be the bits of the solve
+    without company.  Prints the slowdown (not asserted: it is the price of the overlap, measured)."""
+    import time
+    import torch
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    B = 4096
+    x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg)
+    d = [torch.from_numpy(a).cuda() for a in (x0, p)]
+    out = torch.empty_like(d[0]); st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty_like(st)
+
+    def step():
+        s.solve_device(B, d[0].data_ptr(), d[1].data_ptr(), out.data_ptr(), st.data_ptr(), it.data_ptr())
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    t_solo = (time.perf_counter() - t0) / 10
+    assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+    ref, ref_it = out.cpu().numpy().copy(), it.cpu().numpy().copy()
+    n_el = (B * (x0.shape[1] + 2))                                       # the packed block of sharding.pack_rows: rows + status + iterations
+    src = torch.randn(n_el, dtype=torch.float64, device="cuda"); dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    import threading
+    t_busy, bad, done = [], [], threading.Event()
+
+    def solves():                                                        # (ctypes releases the GIL inside the call: the copies below are issued meanwhile)
+        try:
+            for rep in range(24):
+                t0 = time.perf_counter()
+                step()
+                t_busy.append(time.perf_counter() - t0)
+                if not (s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]):
+                    bad.append(("fallback", rep))                       # abandoned launch / one launch per kernel
+                if not (np.array_equal(out.cpu().numpy(), ref) and np.array_equal(it.cpu().numpy(), ref_it)):
+                    bad.append(("bits", rep))
+        finally:
+            done.set()
+    th = threading.Thread(target=solves)
+    n_copies = 0
+    with torch.cuda.stream(side):
+        th.start()
+        while not done.is_set():                                           # an 8.1 MB copy kernel every few tens of microseconds for as long as the solves run
+            dst.copy_(src, non_blocking=True)
+            n_copies += 1
+            if n_copies % 64 == 0:
+                side.synchronize()                                          # (bounds the queue: the copies stay BESIDE the solves, not ahead of them)
+    th.join()
+    torch.cuda.synchronize()
+    assert not bad, bad
+    assert torch.equal(dst, src) and n_copies >= 100
+    print(f"\n[copy kernels beside the pipeline] solve alone {t_solo * 1e3:.3f} ms, with {n_copies} 8.1 MB copy kernels of another stream beside {len(t_busy)} solves "
+          f"{np.median(t_busy) * 1e3:.3f} ms (x{np.median(t_busy) / t_solo:.2f}, slowest {max(t_busy) * 1e3:.3f} ms); pipeline ran every time, rows bit-identical")
+
+
 @pytest.mark.parametrize("friction_lb", ["ipopt", "nlp"])
 def test_gpu_replays_the_friction_row_fixture(golden_dir, friction_lb):
     """the loop that visits the kink of the reference's stage-0 friction row (tests/test_parity_pins.py, closed_loop_n30_friction.npz: N = 30, no
