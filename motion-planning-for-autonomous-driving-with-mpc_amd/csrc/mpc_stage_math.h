@@ -254,13 +254,15 @@ __device__ __forceinline__ WsRefI ws_ref3(const PRef& P, const int32_t* arr, uin
 //                         permutation inside the block), but the 16-byte pieces the stage threads of a wavefront touch with one instruction
 //                         are contiguous (8 cache lines per wave instruction instead of one per lane).  The layout belongs to the launch
 //                         (P.bx): k_solve_wg fills these arrays when it takes its instances over and reads them back when it leaves.
+//                         (c.mb: the block's first instance SLOT = workgroup index x bx, c.bl: this thread's slot in the block -- the
+//                         instances a workgroup works on need not be neighbours: k_solve_wg behind the pipeline takes them from a list)
 #define MPC_KI(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, \
                                      ((((uint32_t)(e) >> 1) * (uint32_t)(P.N + 1) + (uint32_t)(dk)) * (uint32_t)P.bx * 2u + ((uint32_t)(e) & 1u)) * 8u, \
-                                     (((uint32_t)c.b & ~((uint32_t)P.bx - 1u)) * (uint32_t)(P.N + 1) * MPC_EV(R) + ((uint32_t)c.k * (uint32_t)P.bx + ((uint32_t)c.b & ((uint32_t)P.bx - 1u))) * 2u) * 8u}
+                                     ((uint32_t)c.mb * (uint32_t)(P.N + 1) * MPC_EV(R) + ((uint32_t)c.k * (uint32_t)P.bx + (uint32_t)c.bl) * 2u) * 8u}
 #else
 typedef Params PRef;
-#define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)((uint32_t)c.b & ~((uint32_t)P.bx - 1u)) * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * P.bx * 2 + \
-                                     ((size_t)(c.k + (dk)) * P.bx + ((uint32_t)c.b & ((uint32_t)P.bx - 1u))) * 2 + ((uint32_t)(e) & 1u)])
+#define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)c.mb * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * P.bx * 2 + \
+                                     ((size_t)(c.k + (dk)) * P.bx + (size_t)c.bl) * 2 + ((uint32_t)(e) & 1u)])
 #define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
@@ -575,6 +577,7 @@ template <int NX>
 struct Ctx {
     static constexpr int NZ = NX + 2;
     int b, k;
+    int mb, bl;      // (k_solve_wg: first instance slot of the workgroup's block, this thread's slot in it -- MPC_KI)
     bool valid;      // b < B and k <= N
     bool active;     // valid and instance still iterating
     // --- iterate pieces live across the line search

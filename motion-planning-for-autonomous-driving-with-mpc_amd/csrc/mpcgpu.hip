@@ -275,14 +275,16 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
 // ---------------------------------------------------------------------------------------------------------------
 struct WgIo { uint32_t fail; uint32_t ill; double* c0; };
 template <int NX, uint32_t VM, class Mid>
-__device__ __forceinline__ void wg_stage(const PRef& P, const uint32_t b0, double* lds_bnd, const mpc_lds_ptr rec_base, const int n_mult, const int n_z, const bool stamp,
+__device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int ib1, double* lds_bnd, const mpc_lds_ptr rec_base, const int n_mult, const int n_z, const bool stamp,
                                          uint32_t* live_out, WgIo& io, Mid&& mid) {
     const int bx = P.bx, t = threadIdx.x;
     Ctx<NX> c;
     PreTmp<NX> tmp;
     c.k = t / bx;
-    c.b = (int)b0 + (t & (bx - 1));
-    c.valid = (c.k <= P.N) && (c.b < P.B);
+    c.bl = t & (bx - 1);
+    c.mb = (int)blockIdx.x * bx;
+    c.b = c.bl ? ib1 : ib0;
+    c.valid = (c.k <= P.N) && (c.b >= 0) && (c.b < P.B);
     c.active = false;
     c.ill = false;
     c.status = 0;
@@ -511,6 +513,7 @@ __global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(c
 // mpc_stage_math.h (shared with the CPU emulation harness).  Inertia correction: if some lane finds an indefinite
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t HO_BUCKETS = 4;  // hand-over lists of the hybrid solve, by KKT error: >= 1e-3 | >= 1e-4 | >= 1e-5 | below (rank correlation with the iterations left: 0.9)
 constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 17 KiB each at nx = 6)
 constexpr int RIC_DEPTH_F = 10;     // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead --
                                     // fed by TWO loader waves (even / odd stages), each limited to 4 stages in flight by the 6-bit vmcnt
@@ -523,6 +526,32 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
     else if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
     else if (stages_behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The tiles of the hybrid solve leave the pipeline with a few instances still iterating: they go onto the lists k_solve_wg deals its
+// workgroups from -- one list per bucket of the KKT error the instance stands at, a predictor of the iterations it still needs (one
+// agent-scope ticket per tile and bucket, a slot per live lane).  A launch of its own between the two: one wavefront per tile.  (Appended
+// by the retiring Riccati worker inside k_pipeline -- no launch, no gap -- the few instructions cost its sweeps 13 us per solve.)
+__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count) {
+    const PRef P(Pk);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (skip_if != nullptr && *skip_if != 0u) return;
+    const int lane = threadIdx.x;
+    const int b = (int)blockIdx.x * 64 + lane;
+    const uint32_t bb = (uint32_t)b;
+    const bool active = b < P.B && (int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING;
+    if (__ballot(active ? 1 : 0) == 0ull) return;
+    const double e0 = active ? (double)MPC_U(P.SC, (uint32_t)SC_E0) : 0.0;
+    const int bucket = e0 >= 1e-3 ? 0 : e0 >= 1e-4 ? 1 : e0 >= 1e-5 ? 2 : 3;
+    for (int q = 0; q < (int)HO_BUCKETS; ++q) {
+        const unsigned long long mq = __ballot((active && bucket == q) ? 1 : 0);
+        if (mq == 0ull) continue;
+        uint32_t base = 0u;
+        if (lane == 0) base = __hip_atomic_fetch_add(ho_count + q, (uint32_t)__popcll(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (active && bucket == q) ho_list[(uint32_t)q * (uint32_t)P.Bp + base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = b;
+    }
+#endif
 }
 
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
@@ -774,9 +803,13 @@ constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: 
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
 constexpr uint32_t PIPE_STATS = PIPE_ABORT + 2;         // [wait ticks riccati, wait ticks stage, busy ticks stage, items, workers stage, workers riccati]
 constexpr uint32_t PIPE_WG = PIPE_ABORT + 16;           // statistics of the k_solve_wg launch behind the pipeline (5 words: rounds max, rounds, sweeps, instance-rounds, rescued): zeroed and copied back with the block
-constexpr uint32_t PIPE_HDR = PIPE_ABORT + 24;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
+constexpr uint32_t PIPE_HO = PIPE_ABORT + 24;           // hand-over list: instances left by retiring tiles, per bucket of their KKT error (HO_BUCKETS words)
+constexpr uint32_t PIPE_HDR = PIPE_ABORT + 32;          // then: stage_done[ntiles] | pad to 2 words | slots[8][cap] (uint64)
 constexpr uint32_t PIPE_EXIT = 0xFFFFFFFFu;
 constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-clock ticks = 50 ms
+#ifndef MPC_PIPE_SLEEP
+#define MPC_PIPE_SLEEP 8                                        // s_sleep argument between two polls of a hand-off flag (x 64 clocks)
+#endif
 __host__ __device__ inline uint32_t pipe_slots_off(uint32_t ntiles) { return (PIPE_HDR + ntiles + 1u) & ~1u; }
 __host__ __device__ inline size_t pipe_ctl_words(uint32_t ntiles, uint32_t cap) { return (size_t)pipe_slots_off(ntiles) + (size_t)16 * cap; }
 
@@ -868,7 +901,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                     while (pipe_ld(stage_done + tile) < need) {
                         if (pipe_ld(abort_w)) { ok = 0u; break; }
                         if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); ok = 0u; break; }
-                        __builtin_amdgcn_s_sleep(8);
+                        __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
                     }
                     waited += wall_clock64() - t0;
                     pipe_acquire((A.flags & 9u) == 0u);
@@ -922,7 +955,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 if ((uint32_t)(v >> 32) == tk + 1u) { item = (uint32_t)v; break; }
                 if (pipe_ld(X + 48) >= n_tiles_x || pipe_ld(abort_w)) break;             // every tile of this XCD is finished: nothing can arrive
                 if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
             }
             const unsigned long long t1 = wall_clock64();
             PIPE_STAMP(12);
@@ -998,9 +1031,11 @@ __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_
                                                      int (*or_slots)[8], uint32_t* live_out, const bool carry, const bool from_xs, const bool keep_first, const bool first_tiled) {
     using D = Dim<NX>;
     const int t = threadIdx.x, N = P.N, bx = P.bx;
-    struct { int b, k; } c;
+    struct { int b, k, mb, bl; } c;
     c.k = t / bx;
-    c.b = (int)b0 + (t & (bx - 1));
+    c.bl = t & (bx - 1);
+    c.mb = (int)blockIdx.x * bx;
+    c.b = (int)b0 + c.bl;
     const bool valid = (c.k <= N) && (c.b < P.B);
     if (valid) {
         constexpr int NZ = D::NZ;
@@ -1055,9 +1090,11 @@ __device__ __attribute__((noinline)) void wg_restore_first(const PRef& P, const 
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     const int t = threadIdx.x, bx = P.bx;
-    struct { int b, k; } c;
+    struct { int b, k, mb, bl; } c;
     c.k = t / bx;
-    c.b = (int)b0 + (t & (bx - 1));
+    c.bl = t & (bx - 1);
+    c.mb = (int)blockIdx.x * bx;
+    c.b = (int)b0 + c.bl;
     if (c.k <= P.N && c.b < P.B) {
         double v[MPC_EV(NZ)];
         ws_load_rows<NZ>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, MPC_EV(NZ) + e)), v);
@@ -1094,7 +1131,7 @@ struct WgLds {
 };
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
-                                                                   const WgRescue resc) {
+                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
     PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1109,10 +1146,35 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     const int bx = P.bx, t = threadIdx.x, N = P.N;
     const int lane = t;                          // ONE wavefront per workgroup (bx = 1 or 2 instances, (N + 1) * bx <= 64 stage threads)
     const uint32_t b0 = (blockIdx.x + (uint32_t)P.tile0 * (64u / (uint32_t)bx)) * (uint32_t)bx;
-    struct { int b, k; } c;                      // (the workspace accessors are written in terms of c.b / c.k)
+    // The instances of this workgroup (slots 0 and 1 of its block; -1: none).  Without a list: b0 and its neighbour.  Behind the pipeline: from the
+    // list of instances its retiring tiles have left -- workgroup i takes entries i and i + gridDim.x, so that the launch needs no more
+    // workgroups than the machine holds at once and every one of them starts at once (with two instances per workgroup by position, 1 163 of the
+    // 2 048 workgroups of the headline batch had work, 139 more than there are slots: the last of them started 90 us into a 250 us launch).
+    // The lists are one per bucket of the KKT error at the hand-over, largest first: V = their concatenation, longest-running instances first.
+    // Workgroup i takes V[i]; the n - G entries beyond the G workgroups go, shortest last, to the workgroups from G - 1 downwards -- the
+    // instances with the most iterations in front of them have a wavefront to themselves (a round with one live instance takes 25 us, with two 34).
+    int ib0 = (int)b0 < P.B ? (int)b0 : -1, ib1 = (bx > 1 && (int)b0 + 1 < P.B) ? (int)b0 + 1 : -1;
+    if (list != nullptr) {
+        uint32_t cnt[HO_BUCKETS], n = 0u;
+#pragma unroll
+        for (int q = 0; q < (int)HO_BUCKETS; ++q) { cnt[q] = list_n[q]; n += cnt[q]; }
+        auto entry = [&](uint32_t v) -> int {
+            if (v >= n) return -1;
+#pragma unroll
+            for (int q = 0; q < (int)HO_BUCKETS; ++q) { if (v < cnt[q]) return list[(uint32_t)q * (uint32_t)P.Bp + v]; v -= cnt[q]; }
+            return -1;
+        };
+        const uint32_t G = gridDim.x;
+        ib0 = entry(blockIdx.x);
+        ib1 = bx > 1 ? entry(2u * G - 1u - blockIdx.x) : -1;            // (V[G + m] belongs to workgroup G - 1 - m)
+        if (ib0 < 0) return;
+    }
+    struct { int b, k, mb, bl; } c;              // (the workspace accessors are written in terms of c.b / c.k; MPC_KI: c.mb / c.bl)
     c.k = t / bx;
-    c.b = (int)b0 + (t & (bx - 1));
-    const bool valid = (c.k <= N) && (c.b < P.B);
+    c.bl = t & (bx - 1);
+    c.mb = (int)blockIdx.x * bx;
+    c.b = c.bl ? ib1 : ib0;
+    const bool valid = (c.k <= N) && (c.b >= 0) && (c.b < P.B);
     // LDS: [one pad record -- what the sweeps' operand prefetch of "stage -1" reads and what their lanes without an entry write | records
     //       of the workgroup's instances, Rec<NX> | bounds table of the stage phases]; nothing else: one wavefront needs no reduction
     //       scratch and exchanges neighbour stages by lane shuffles
@@ -1128,13 +1190,14 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     const MfmaWords lane_words = mfma_lane_load<NX>(lane);
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
+    const unsigned long long t_begin = wtrace ? wall_clock64() : 0ull;        // (option wg_trace: when did this workgroup start, how long did it run, how many rounds)
     if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
         //      left the mask in sh_mask (an instance the sweeps gave up on is inactive there: phase_load_scalars reads its status)
         if (rounds == 0u && t < 64) {
-            const int bb = (int)b0 + t;
-            const bool run = t < bx && bb < P.B && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb) == ST_RUNNING;
+            const int bb = t ? ib1 : ib0;
+            const bool run = t < bx && bb >= 0 && bb < P.B && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb >= 0 ? bb : 0) == ST_RUNNING;
             const unsigned long long mk = __ballot(run ? 1 : 0);
             if (t == 0) sh_mask = (uint32_t)mk;
         }
@@ -1253,11 +1316,10 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         };
         if (fresh) {
             build_records();
-            const int b1 = (int)b0 + (bx > 1 ? 1 : 0);
-            dl0 = MPC_UB(P.SC, (uint32_t)SC_DLAST, (int)b0 < P.B ? (int)b0 : 0);
-            dl1 = MPC_UB(P.SC, (uint32_t)SC_DLAST, b1 < P.B ? b1 : 0);
-            io.ill = ((int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, (int)b0 < P.B ? (int)b0 : 0) != 0 ? 1u : 0u) |
-                     ((bx > 1 && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, b1 < P.B ? b1 : 0) != 0) ? 2u : 0u);
+            const int a0 = ib0 >= 0 ? ib0 : 0, a1 = ib1 >= 0 ? ib1 : a0;
+            dl0 = MPC_UB(P.SC, (uint32_t)SC_DLAST, a0);
+            dl1 = MPC_UB(P.SC, (uint32_t)SC_DLAST, a1);
+            io.ill = ((int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, a0) != 0 ? 1u : 0u) | ((bx > 1 && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, a1) != 0) ? 2u : 0u);
             if (valid && c.k == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) lds_c0[(t & (bx - 1)) * 8 + i] = MPC_S(P.SC, SC_C0 + i);
@@ -1281,7 +1343,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         constexpr uint32_t SVM = VAR == 2 ? REF_VM : 0xFFu;
         {
             auto inst_of = [&](int g, MfmaInst& in, double& x0) {
-                in.inst = b0 + (uint32_t)g;
+                in.inst = (uint32_t)(g ? ib1 : ib0);
                 in.delta_last = g ? dl1 : dl0;
                 in.sym_hint = ((io.ill >> g) & 1u) != 0u;
                 // x~_0 = (-c_0, 0.., 1) as B operand of the forward sweep (requested now, needed after the backward sweep)
@@ -1293,7 +1355,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             };
             io.fail = 0u;
             auto finish = [&](int g, bool ok, double delta) {
-                const int bb = (int)b0 + g;
+                const int bb = g ? ib1 : ib0;
                 if (ok) { if (delta > 0.0) { if (g) dl1 = delta; else dl0 = delta; } }
                 else io.fail |= 1u << g;
                 if (lane != 0) return;
@@ -1326,7 +1388,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             else mfma_backward<NX, 1>(P, m, reinterpret_cast<In1>(in), reinterpret_cast<Rec1>(rec), lane, dump, reinterpret_cast<D1>(delta), reinterpret_cast<B1>(ok), sweeps, rebuild);
             if (t == 0) sh_mask = 0u;                                 // (the stage phases leave early, before their ballot, when nothing is active)
             // ---- the stage work of the round, with the forward sweep laid between its loads from memory and its reads of the records
-            wg_stage<NX, SVM>(P, b0, lds_bnd, recs, n_mult, n_z, rounds == 3u, &sh_mask, io, [&]() {
+            wg_stage<NX, SVM>(P, ib0, ib1, lds_bnd, recs, n_mult, n_z, rounds == 3u, &sh_mask, io, [&]() {
                 if (two) mfma_forward<NX, 2>(P, m, in, rec, lane, dump, x0, ok);
                 else mfma_forward<NX, 1>(P, m, reinterpret_cast<In1>(in), reinterpret_cast<Rec1>(rec), lane, dump, reinterpret_cast<CD1>(x0), reinterpret_cast<CB1>(ok));
                 finish(g0, ok[0], delta[0]);
@@ -1347,6 +1409,12 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         double v[D::NZ];
         ws_load_rows<D::NZ>(MPC_ROWS(MPC_KI(P.MZ, D::NZ, 0, e)), v);
         ws_store_rows<D::NZ>(MPC_ROWS(MPC_K(P.Z, D::NZ, 0, e)), v);
+    }
+    if (wtrace != nullptr && t == 0) {
+        wtrace[blockIdx.x * 4 + 0] = t_begin;
+        wtrace[blockIdx.x * 4 + 1] = wall_clock64();
+        wtrace[blockIdx.x * 4 + 2] = rounds;
+        wtrace[blockIdx.x * 4 + 3] = inst_rounds;
     }
     if (stats != nullptr && t == 0) {
         atomicMax(stats + 0, rounds);
@@ -2220,7 +2288,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2253,6 +2321,8 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "prestart_chains") k.prestart_chains = on != 0;
     else if (n == "resident") k.resident = value == nullptr ? 0 : (int)iv;
     else if (n == "res_timing") k.res_timing = on != 0;
+    else if (n == "wg_trace") k.wg_trace = on != 0;
+    else if (n == "wg_list") k.wg_list = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2283,6 +2353,8 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "prestart_chains") *out = k.prestart_chains;
     else if (n == "resident") *out = k.resident;
     else if (n == "res_timing") *out = k.res_timing;
+    else if (n == "wg_trace") *out = k.wg_trace;
+    else if (n == "wg_list") *out = k.wg_list;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2296,7 +2368,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2785,20 +2857,55 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // the second chance inside the launch (k_solve_wg<.., RESC>): one instance per workgroup, the conditions of rescue_dev
     const bool resc_cond = kn.rescue && kn.rescue_wg && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
     auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1; };
+    DevTmp t_wtrace;
+    unsigned long long* d_wtrace = nullptr;
+    int n_wtrace = 0;
+    const int32_t* wg_list = nullptr;                   // (behind the pipeline: the instances its retiring tiles left, see k_solve_wg)
+    const uint32_t* wg_list_n = nullptr;
+    int wg_grid = 0;
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
+        if (kn.wg_trace && !h->async_loop && !h->in_rescue) {
+            n_wtrace = (B + bxw - 1) / bxw;
+            if (hipMalloc(&t_wtrace.p, sizeof(unsigned long long) * 4 * (size_t)n_wtrace) == hipSuccess) {
+                d_wtrace = t_wtrace.as<unsigned long long>();
+                (void)hipMemsetAsync(d_wtrace, 0, sizeof(unsigned long long) * 4 * (size_t)n_wtrace, stream);
+            }
+        }
         Params Pw = P;
         Pw.bx = bxw;
         const int thr = 64;                        // (S * bxw <= 64: checked where the path is chosen)
         WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
-        const dim3 grid((B + bxw - 1) / bxw);
+        const dim3 grid(wg_grid > 0 ? wg_grid : (B + bxw - 1) / bxw);
         if (wg_resc(bxw)) {
             rs.on = 1;
             h->resc_in_kernel = true;
-            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
-            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
         }
-        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
-        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs);
+        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+    };
+    // option wg_trace: every workgroup of k_solve_wg leaves its start, its end (100 MHz wall clock) and its rounds: when did the long ones start?
+    auto report_wtrace = [&]() {
+        if (!d_wtrace) return;
+        std::vector<unsigned long long> hw((size_t)4 * n_wtrace);
+        if (hipMemcpy(hw.data(), d_wtrace, hw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        std::vector<int> live;
+        for (int w = 0; w < n_wtrace; ++w) if (hw[4 * w + 2]) { t0 = std::min(t0, hw[4 * w]); t1 = std::max(t1, hw[4 * w + 1]); live.push_back(w); }
+        if (live.empty()) return;
+        std::sort(live.begin(), live.end(), [&](int a, int b) { return hw[4 * a + 1] > hw[4 * b + 1]; });
+        int late = 0;
+        double start_max = 0;
+        for (int w : live) { const double st = (double)(hw[4 * w] - t0) * 1e-2; if (st > 5.0) ++late; start_max = std::max(start_max, st); }
+        fprintf(stderr, "[mpcgpu wg_trace] %d workgroups with work of %d; span %.1f us; %d of them start more than 5 us after the first (latest start %.1f us); the last to finish:\n",
+                (int)live.size(), n_wtrace, (double)(t1 - t0) * 1e-2, late, start_max);
+        for (size_t i = 0; i < live.size() && i < 12; ++i) {
+            const int w = live[i];
+            const double st = (double)(hw[4 * w] - t0) * 1e-2, en = (double)(hw[4 * w + 1] - t0) * 1e-2;
+            fprintf(stderr, "    workgroup %5d: start %6.1f us  end %6.1f us  rounds %2d  instance-rounds %2d  -> %.1f us per round\n", w, st, en, (int)hw[4 * w + 2], (int)hw[4 * w + 3],
+                    (en - st) / (double)hw[4 * w + 2]);
+        }
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
     // stragglers one wavefront per (hybrid_bx) instance -- `hand` = live instances per tile at which a tile changes over
@@ -2838,6 +2945,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, wait_stream(h, stream));
         if (h->resc_in_kernel) h->rescued_last = (int)h->h_fail[6];
+        report_wtrace();
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
             std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
             HIP_TRY(h, hipMemcpy(hd.data(), P.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2892,6 +3000,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
             A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
             A.handover = (uint32_t)hand;
+            int32_t* ho_list = nullptr;
+            if (hand > 0 && kn.wg_list) {
+                ho_list = static_cast<int32_t*>(scratch_get(h, 36, (size_t)HO_BUCKETS * Bp * sizeof(int32_t)));
+                if (!ho_list) { h->err = "out of device memory"; return MPC_ERR_HIP; }
+            }
             const size_t words = pipe_ctl_words(A.ntiles, A.cap);
             if (h->pipe_words < words) {
                 if (h->d_pipe) (void)hipFree(h->d_pipe);
@@ -2923,6 +3036,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
                 prof.begin(5, stream);
+                if (ho_list) {
+                    // (the counters: words of the control block, zero at the start of every solve)
+                    hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO);
+                    wg_list = ho_list; wg_list_n = ctl + PIPE_HO;
+                    // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
+                    wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
+                }
                 launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
                 prof.end(stream);
             }
@@ -2948,6 +3068,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipMemcpyAsync(h->h_pipe, ctl + PIPE_ABORT, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
+            report_wtrace();
             for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
             if (h->resc_in_kernel) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
             if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
