@@ -2916,7 +2916,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
     const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
-    if (hyb_ok) hand = kn.hybrid_live >= 0 ? std::min(64, kn.hybrid_live) : std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
+    if (hyb_ok) {
+        // what the straggler launch holds at once, per tile (4 wavefront slots per CU x hyb_bx instances) ...
+        const int base = std::min(64, 4 * h->n_cu * hyb_bx / std::max(1, (int)(Bp / 64)));
+        // ... and half as much again when k_solve_wg deals its workgroups from the hand-over lists: the instances beyond the machine's slots are
+        // the ones closest to convergence and start when the first wavefronts free up, while the tiles leave the pipeline a round earlier --
+        // its rounds cost an instance 67 us, a straggler round 25 us (tools/hand_sweep.py: 3 - 5 % per batch on four instance sets at B = 4096,
+        // B = 3000 / 8192 and N = 50 likewise; above ~50 of 64 the pipeline no longer carries the bulk)
+        hand = (base >= 64 || !kn.wg_list) ? base : std::max(base, std::min(50, 3 * base / 2));
+        if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
+    }
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
     if ((use_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4) || wg_only) {
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
