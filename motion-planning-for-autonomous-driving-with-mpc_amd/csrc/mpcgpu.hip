@@ -530,16 +530,14 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 
 // The tiles of the hybrid solve leave the pipeline with a few instances still iterating: they go onto the lists k_solve_wg deals its
 // workgroups from -- one list per bucket of the KKT error the instance stands at, a predictor of the iterations it still needs (one
-// agent-scope ticket per tile and bucket, a slot per live lane).  A launch of its own between the two: one wavefront per tile.  (Appended
-// by the retiring Riccati worker inside k_pipeline -- no launch, no gap -- the few instructions cost its sweeps 13 us per solve.)
-__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count) {
-    const PRef P(Pk);
+// agent-scope ticket per tile and bucket, a slot per live lane).  Done by the pipeline's stage workers on their way out (option ho_inline,
+// the default) or by a launch of its own between the two kernels (5.5 us).  (Appended by the retiring Riccati worker inside riccati_tile
+// the few instructions cost its sweeps 13 us per solve; as an out-of-line call they put the whole kernel on scratch.)
+// (one wavefront, lane = instance b of a tile)
+__device__ __forceinline__ void ho_lists(const PRef& P, const uint32_t bb, int32_t* ho_list, uint32_t* ho_count) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (skip_if != nullptr && *skip_if != 0u) return;
-    const int lane = threadIdx.x;
-    const int b = (int)blockIdx.x * 64 + lane;
-    const uint32_t bb = (uint32_t)b;
-    const bool active = b < P.B && (int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING;
+    const int lane = threadIdx.x & 63;
+    const bool active = (int)bb < P.B && (int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING;
     if (__ballot(active ? 1 : 0) == 0ull) return;
     const double e0 = active ? (double)MPC_U(P.SC, (uint32_t)SC_E0) : 0.0;
     const int bucket = e0 >= 1e-3 ? 0 : e0 >= 1e-4 ? 1 : e0 >= 1e-5 ? 2 : 3;
@@ -549,9 +547,14 @@ __global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t
         uint32_t base = 0u;
         if (lane == 0) base = __hip_atomic_fetch_add(ho_count + q, (uint32_t)__popcll(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (active && bucket == q) ho_list[(uint32_t)q * (uint32_t)P.Bp + base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = b;
+        if (active && bucket == q) ho_list[(uint32_t)q * (uint32_t)P.Bp + base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = (int32_t)bb;
     }
 #endif
+}
+__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count) {
+    const PRef P(Pk);
+    if (skip_if != nullptr && *skip_if != 0u) return;
+    ho_lists(P, blockIdx.x * 64u + threadIdx.x, ho_list, ho_count);
 }
 
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
@@ -794,12 +797,13 @@ struct PipeArgs {
     uint32_t cap;           // ready-queue slots per XCD, a power of two >= 2 * items of one XCD
     uint32_t items;         // stage work items per tile = 64 / bx
     uint32_t handover;      // a tile with at most this many instances still iterating leaves the pipeline (0: tiles run to the end)
+    int32_t* ho_list;       // ... and the stage workers put them onto the hand-over lists on their way out (nullptr: k_ho_lists does, or nobody)
     uint32_t flags;         // bit 0: producers also issue an agent-scope release (MPCGPU_PIPE_RELEASE: the protocol that does not
                             // rely on a tile staying inside one L2; same results, 10-17 % slower); bit 1: raise the abort word at
                             // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path); bit 3: consumers acquire at agent scope
                             // (MPCGPU_PIPE_L2INV) instead of dropping their own L1 only -- implied by bit 0
 };
-constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48
+constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48, hand-over ticket @56
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
 constexpr uint32_t PIPE_STATS = PIPE_ABORT + 2;         // [wait ticks riccati, wait ticks stage, busy ticks stage, items, workers stage, workers riccati]
 constexpr uint32_t PIPE_WG = PIPE_ABORT + 16;           // statistics of the k_solve_wg launch behind the pipeline (5 words: rounds max, rounds, sweeps, instance-rounds, rescued): zeroed and copied back with the block
@@ -997,6 +1001,19 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         ++n_pass;
     }
 #undef PIPE_STAMP
+    // ---- hybrid solve: the stage workers of an XCD leave when every tile of the XCD has stopped -- on their way out they put the instances the
+    //      tiles left onto the hand-over lists (ho_lists; tiles dealt by ticket).  A launch of its own for this costs 5.5 us between the two kernels.
+    if (A.ho_list != nullptr && t < 64 && pipe_ld(abort_w) == 0u) {
+        pipe_acquire((A.flags & 9u) == 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (;;) {
+            uint32_t j = 0u;
+            if (t == 0) j = pipe_add(X + 56, 1u);
+            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            if (j >= n_tiles_x) break;
+            ho_lists(P, (j * n_xcd + xcd) * 64u + (uint32_t)t, A.ho_list, A.ctl + PIPE_HO);
+        }
+    }
     if (t == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS);
         atomicAdd(st + 1, waited);
@@ -2288,7 +2305,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2323,6 +2340,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "res_timing") k.res_timing = on != 0;
     else if (n == "wg_trace") k.wg_trace = on != 0;
     else if (n == "wg_list") k.wg_list = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "ho_inline") k.ho_inline = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2355,6 +2373,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "res_timing") *out = k.res_timing;
     else if (n == "wg_trace") *out = k.wg_trace;
     else if (n == "wg_list") *out = k.wg_list;
+    else if (n == "ho_inline") *out = k.ho_inline;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2368,7 +2387,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -3010,9 +3029,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
             A.handover = (uint32_t)hand;
             int32_t* ho_list = nullptr;
+            A.ho_list = nullptr;
             if (hand > 0 && kn.wg_list) {
                 ho_list = static_cast<int32_t*>(scratch_get(h, 36, (size_t)HO_BUCKETS * Bp * sizeof(int32_t)));
                 if (!ho_list) { h->err = "out of device memory"; return MPC_ERR_HIP; }
+                if (kn.ho_inline) A.ho_list = ho_list;
             }
             const size_t words = pipe_ctl_words(A.ntiles, A.cap);
             if (h->pipe_words < words) {
@@ -3047,7 +3068,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 prof.begin(5, stream);
                 if (ho_list) {
                     // (the counters: words of the control block, zero at the start of every solve)
-                    hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO);
+                    if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO);
                     wg_list = ho_list; wg_list_n = ctl + PIPE_HO;
                     // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));

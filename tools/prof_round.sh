@@ -1,10 +1,10 @@
 set -u
-O=gpurun_out/r4h; mkdir -p $O
+O=${1:-gpurun_out/r5prof}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O/bench.err; echo bench rc=$?
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/head -o head --output-format csv -- python bench.py --headline-only --no-cpu-baseline --no-traffic > $O/head.log 2>&1; echo head rc=$?
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r4h --output-format csv -- python bench.py --no-cpu-baseline --no-traffic > $O/prof.log 2>&1; echo prof rc=$?
-python tools/trace_split.py $O/prof/r4h_kernel_trace.csv > $O/kernel_trace_split.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o full --output-format csv -- python bench.py --no-cpu-baseline --no-traffic > $O/prof.log 2>&1; echo prof rc=$?
+python tools/trace_split.py $O/prof/full_kernel_trace.csv > $O/kernel_trace_split.txt 2>&1
 python tools/solve_timeline.py $O/head/head_kernel_trace.csv > $O/solve_timeline.txt 2>&1
 timeout 1500 bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1; echo pmc rc=$?
 python tools/pmc_summary.py $O/pmc --json $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1
