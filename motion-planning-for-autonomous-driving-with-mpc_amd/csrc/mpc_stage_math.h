@@ -796,13 +796,11 @@ MPC_HD void ingest_instance(const PRef& P, int b) {
 // lower branch of the absolute value cannot bind, -fu - c <= 0).  The row has zero gradient at the usual warm
 // start a_0 = 0; the bound form is exact, has the same KKT points and needs no slack.
 template <int NX>
-MPC_HD int prestart_a0(const PRef& P, int b, double& a0lb, double& a0ub) {
-    const uint32_t bb = (uint32_t)b;
+MPC_HD int prestart_a0_of(const PRef& P, const double dl0, const double v0, double& a0lb, double& a0ub) {
     a0lb = MPC_GP(P.LB, 1);
     a0ub = MPC_GP(P.UB, 1);
     int frow = 1;
     if (!P.has_fl && P.has_fu) {
-        const double dl0 = PRX(0, 2), v0 = PRX(0, 3);
         const double cf = v0 * (tan(dl0) * v0 / P.friction_div);
         const double Rhi = P.fu - cf, Rlo = -P.fu - cf;
         if (Rhi > 0.0 && Rlo <= 0.0) {
@@ -813,6 +811,12 @@ MPC_HD int prestart_a0(const PRef& P, int b, double& a0lb, double& a0ub) {
         }
     }
     return frow;
+}
+template <int NX>
+MPC_HD int prestart_a0(const PRef& P, int b, double& a0lb, double& a0ub) {
+    const uint32_t bb = (uint32_t)b;
+    const double dl0 = PRX(0, 2), v0 = PRX(0, 3);
+    return prestart_a0_of<NX>(P, dl0, v0, a0lb, a0ub);
 }
 // The two chains of the start-point safeguard are independent of each other (the GPU runs them in two wavefronts):
 //   ROLLOUT = true : forward rollout of the caller's control guess from r_0, stored in ROLL; returns its clipping defect
@@ -935,16 +939,22 @@ MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
         }
         const double v = push_in(raw, lb, ub);
         c.z[i] = v;
-        MPC_K(P.Z, NZ, 0, i) = v;
         c.zl[i] = has_lo(lb) ? 1.0 : 0.0;
         c.zu[i] = has_hi(ub) ? 1.0 : 0.0;
-        MPC_K(P.ZL, NZ, 0, i) = c.zl[i];
-        MPC_K(P.ZU, NZ, 0, i) = c.zu[i];
-        MPC_K(P.DZ, NZ, 0, i) = 0.0;
+    }
+    // (stores by row pair -- half the store instructions of the start iterate)
+    {
+        double zero[MPC_EV(NZ)];
+#pragma unroll
+        for (int i = 0; i < (int)MPC_EV(NZ); ++i) zero[i] = 0.0;
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.ZL, NZ, 0, e)), c.zl);
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.ZU, NZ, 0, e)), c.zu);
+        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), zero);
+        ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), zero);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        MPC_K(P.LAM, NX, 0, i) = 0.0;
         c.lam[i] = 0.0;
         c.rn[i] = (k < N) ? (double)MPC_K(P.REF, NX, 1, i) : 0.0;
         c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
@@ -958,14 +968,14 @@ MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         c.so[j] = push_in(dist[j], ol, ou);
-        MPC_K(P.SO, 3, 0, j) = c.so[j];
         c.nuo[j] = 0.0;
         c.zlo[j] = P.has_ol ? 1.0 : 0.0;
         c.zuo[j] = P.has_ou ? 1.0 : 0.0;
-        MPC_K(P.NUO, 3, 0, j) = 0.0;
-        MPC_K(P.ZLO, 3, 0, j) = c.zlo[j];
-        MPC_K(P.ZUO, 3, 0, j) = c.zuo[j];
     }
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.SO, 3, 0, e)), c.so);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.NUO, 3, 0, e)), c.nuo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), c.zlo);
+    ws_store_rows<3>(MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), c.zuo);
     if (k == 0) {
         const double fl = P.has_fl ? P.fl : -INFINITY, fu = P.has_fu ? P.fu : INFINITY;
         const double dfr = c.fric_row ? friction_eval(P, c.z[1], c.z[2 + 2], c.z[2 + 3], nullptr, nullptr, false) : 0.0;

@@ -1039,7 +1039,11 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 // PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
 // of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
 // wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
-template <int NX> __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm);
+struct PrestartFromWs {
+    __device__ __forceinline__ double z(int, int, int) const { return 0.0; }
+    __device__ __forceinline__ double ref0(int, int) const { return 0.0; }
+};      // prestart_par_block reads the caller's guess and the reference from the workspace rows (k_ingest / a restart wrote them)
+template <int NX, class Src = PrestartFromWs> __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm, const Src src = Src{});
 
 // restart of the instance of a one-instance workgroup of k_solve_wg at a level of its second chance: warm start -> tile-major Z, start-point
 // safeguard, start iterate (what k_start does for a block) -- see k_solve_wg<.., RESC>
@@ -1472,8 +1476,11 @@ __global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
 // and (x, y, s) on (v, psi) -- so every transcendental is evaluated by the thread of its stage, and what is left sequential are
 // three short scans x_{k+1} = push_in(x_k + dt f_k) per state, run by the first two stage-threads of every instance from increments
 // parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
-template <int NX>
-__device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm) {
+// Src: where the raw guess z(k, i) (i < 2: input, else state i - 2 of stage k) and the reference of stage 0 come from -- the workspace rows, or
+// (k_start) the block's rows of the caller's buffers as they lie in LDS: then nothing here waits for the ingest's stores
+template <int NX, class Src>
+__device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm, const Src src) {
+    constexpr bool WS = std::is_same<Src, PrestartFromWs>::value;
     constexpr int NZ = NX + 2;
     const int N = P.N, S = N + 1, bx = P.bx, t = threadIdx.x, bl = t & (bx - 1);
     const int nb = S * NZ, SB = S * bx;
@@ -1493,7 +1500,8 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     double a0lb = 0.0, a0ub = 0.0;
     int frow = 1;
     if (valid && c.k == 0) {
-        frow = prestart_a0<NX>(P, c.b, a0lb, a0ub);
+        if (WS) frow = prestart_a0<NX>(P, c.b, a0lb, a0ub);
+        else frow = prestart_a0_of<NX>(P, src.ref0(bl, 2), src.ref0(bl, 3), a0lb, a0ub);
         A0[bl] = a0lb;
         A0[bx + bl] = a0ub;
     }
@@ -1504,11 +1512,11 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
         const int k = c.k;
         double g[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) g[i] = push_in((double)MPC_K(P.Z, NZ, 0, 2 + i), LBt[k * NZ + 2 + i], UBt[k * NZ + 2 + i]);
+        for (int i = 0; i < NX; ++i) g[i] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 2 + i) : src.z(bl, k, 2 + i), LBt[k * NZ + 2 + i], UBt[k * NZ + 2 + i]);
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const double r0 = MPC_K(P.REF, NX, 0, i);
+                const double r0 = WS ? (double)MPC_K(P.REF, NX, 0, i) : src.ref0(bl, i);
                 const double x0 = push_in(r0, LBt[2 + i], UBt[2 + i]);
                 PP_AT(XR, i, 0) = x0;
                 PP_AT(DR, i, 0) = fabs(x0 - r0);
@@ -1517,15 +1525,15 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
         }
         if (k < N) {
             double u[2], f[NX], sp, cp, td;
-            u[0] = push_in((double)MPC_K(P.Z, NZ, 0, 0), LBt[k * NZ], UBt[k * NZ]);
-            u[1] = push_in((double)MPC_K(P.Z, NZ, 0, 1), (k == 0) ? A0[bl] : LBt[k * NZ + 1], (k == 0) ? A0[bx + bl] : UBt[k * NZ + 1]);
+            u[0] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 0) : src.z(bl, k, 0), LBt[k * NZ], UBt[k * NZ]);
+            u[1] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 1) : src.z(bl, k, 1), (k == 0) ? A0[bl] : LBt[k * NZ + 1], (k == 0) ? A0[bx + bl] : UBt[k * NZ + 1]);
             PP_AT(IN, 0, k) = u[0];
             PP_AT(IN, 1, k) = u[1];
             ode_eval<NX>(P, g, u, f, sp, cp, td);
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double raw = f[i] * dt + g[i];
-                const double gn = push_in((double)MPC_K(P.Z, NZ, 1, 2 + i), LBt[(k + 1) * NZ + 2 + i], UBt[(k + 1) * NZ + 2 + i]);
+                const double gn = push_in(WS ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : src.z(bl, k + 1, 2 + i), LBt[(k + 1) * NZ + 2 + i], UBt[(k + 1) * NZ + 2 + i]);
                 PP_AT(DG, i, k + 1) = fabs(gn - raw);
             }
         }
@@ -1589,8 +1597,14 @@ __global__ void __launch_bounds__(1024) k_prestart_par(const Params Pk) {
 }
 // ingest + start-point safeguard + start iterate of a block of bx instances in ONE launch (the three have the same thread mapping; what one
 // leaves in the workspace -- rollout, per-instance bounds of a_0, the verdict -- comes back from this CU's own write-through L1 / the L2)
+#ifndef MPC_KSTART_STOP
+#define MPC_KSTART_STOP 0
+#endif
+#ifndef MPC_KSTART_OCC
+#define MPC_KSTART_OCC 2
+#endif
 template <int NX>
-__global__ void __launch_bounds__(256, 2) k_start(const Params Pk, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, const int n_mult, const int n_z, const int stash_rows) {
     const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -1602,8 +1616,11 @@ __global__ void __launch_bounds__(256, 2) k_start(const Params Pk, const int n_m
         //      workspace: what k_ingest does for a whole batch, here for the block's own bx instances (consecutive rows: coalesced reads)
         constexpr int NZ = NX + 2;
         const int N = P.N, nw = 2 * N + NX * (N + 1), bx = P.bx, t = threadIdx.x;
-        double* rx = lds;                        // [bx][nw]
-        double* rp = lds + bx * nw;              // [bx][nw - 2N]   (the U_ref part of p is not used by the NLP, optimizer.py:507-511)
+        // LDS: [the safeguard's tables and scan rows (prestart_par_block) | the block's rows of x0 | of the X_ref part of p]: the safeguard reads the
+        // guess and the reference from the last two, so it does not wait for the stores below
+        const size_t pre_doubles = (size_t)2 * (N + 1) * NZ + (size_t)(3 * NX + 2) * (N + 1) * bx + (size_t)3 * bx;
+        double* rx = lds + ((pre_doubles + 1) & ~(size_t)1);     // [bx][nw]
+        double* rp = rx + bx * nw;                               // [bx][nw - 2N]   (the U_ref part of p is not used by the NLP, optimizer.py:507-511)
         const int nrow = ((int)b0 + bx <= P.B) ? bx : (P.B > (int)b0 ? P.B - (int)b0 : 0);
         for (int q = t; q < nrow * nw; q += (int)blockDim.x) rx[q] = MPC_GP(P.x0, (size_t)b0 * nw + q);
         const int npx = nw - 2 * N;
@@ -1623,16 +1640,24 @@ __global__ void __launch_bounds__(256, 2) k_start(const Params Pk, const int n_m
             ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), z);
             ws_store_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 0, e)), r);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        struct FromLds {
+            const double *rx, *rp;
+            int nw, npx, N;
+            __device__ __forceinline__ double z(int bl, int k, int i) const { return i < 2 ? (k < N ? rx[bl * nw + 2 * k + i] : 0.0) : rx[bl * nw + 2 * N + NX * k + (i - 2)]; }
+            __device__ __forceinline__ double ref0(int bl, int i) const { return rp[bl * npx + i]; }
+        } src{rx, rp, nw, npx, N};
+        prestart_par_block<NX, FromLds>(P, b0, lds, src);
     }
-    prestart_par_block<NX>(P, b0, lds);
+#if MPC_KSTART_STOP == 1
+    return;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if MPC_KSTART_STOP == 2
+    return;
+#endif
     stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots);
 }
 
@@ -2812,11 +2837,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // stage-threads the scans need (otherwise the two-chain kernel)
         const size_t lds_pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx) * sizeof(double);
         const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
-        const bool fused = lds_pre <= 64 * 1024 && lds_in <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
+        // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
+        const bool fused = lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
         if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
         if (fused) {
             // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
-            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(std::max(lds_pre, lds_init), lds_in), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_pre + 16 + lds_in, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         } else {
             if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
                 hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
