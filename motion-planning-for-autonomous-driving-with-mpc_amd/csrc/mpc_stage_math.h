@@ -569,6 +569,16 @@ template <int CNT> MPC_HD void rec_store(mpc_lds_ptr r, const double* src) {
     for (int i = 0; i < CNT; ++i) r[i] = src[i];
 }
 
+// k_solve_wg keeps a copy of what its stage phases read of an instance EVERY round -- ten scalar rows, six integer rows, the filter -- in LDS
+// (slots of doubles; the integers are exact): the workspace rows are still written (whoever looks at the instance after the launch reads them),
+// but no round waits for them to come back from the L2 (2.6 k of a 56 k-tick round, and the filter entries inside the line search)
+struct WgScl {
+    static constexpr int MU = 0, TAU = 1, DF = 2, THETA = 3, FCOST = 4, LOGSUM = 5, THMAX = 6, THMIN = 7, A0LB = 8, A0UB = 9;
+    static constexpr int STATUS = 10, NFILT = 11, ITERS = 12, CONV = 13, FROW = 14, HAVETH0 = 15, FILT = 16, SIZE = 16 + 2 * FILTER_MAX;
+};
+// (a scalar row written by a phase instantiated with MB goes to both)
+#define MPC_SCW(arr, row, slot, val) do { MPC_S(P.arr, row) = (val); if (MB) c.scl[WgScl::slot] = (double)(val); } while (0)
+
 // per-thread context kept in registers across the phases of the stage kernel
 template <int NX>
 struct PreTmp { double pk[Dim<NX>::NPK], lam[NX]; };      // loaded by phase_preload, consumed by phase_premath
@@ -609,6 +619,7 @@ struct Ctx {
     mpc_lds_cptr bnd;                        // LDS copy of the bounds table [LB (N+1)*NZ | UB (N+1)*NZ] (device)
     int bnd_ub;
     mpc_lds_ptr rec;                         // k_solve_wg (the MB instantiations of the phases): the LDS record of this (instance, stage)
+    mpc_lds_ptr scl;                         // ... and the LDS copy of the instance's scalars and filter (WgScl)
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
@@ -1031,19 +1042,29 @@ MPC_HD void phase_init_scalars(const PRef& P, Ctx<NX>& c, const Red0& red) {
 // =========================================================================================================
 // Phase 1: load the Newton step, slack/dual steps, fraction-to-the-boundary candidates, d(phi)
 // =========================================================================================================
-template <int NX>
+template <int NX, bool MB = false>
 MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
     c.status = 0;
     c.active = false;
     c.ill = false;
     if (!c.valid) return;
-    // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
-    const int32_t status = MPC_S(P.ISC, IS_STATUS), nfilt = MPC_S(P.ISC, IS_NFILT), iters = MPC_S(P.ISC, IS_ITERS);
-    const int32_t convf = MPC_S(P.ISC, IS_CONV), frow = MPC_S(P.ISC, IS_FROW), haveth0 = MPC_S(P.ISC, IS_HAVETH0);
-    const double mu = MPC_S(P.SC, SC_MU), tau = MPC_S(P.SC, SC_TAU), df = MPC_S(P.SC, SC_DF), theta = MPC_S(P.SC, SC_THETA);
-    const double fcost = MPC_S(P.SC, SC_FCOST), logsum = MPC_S(P.SC, SC_LOGSUM);
-    const double thmax = MPC_S(P.SC, SC_THMAX), thmin = MPC_S(P.SC, SC_THMIN);
-    const double a0lb = MPC_S(P.SC, SC_A0LB), a0ub = MPC_S(P.SC, SC_A0UB);
+    int32_t status, nfilt, iters, convf, frow, haveth0;
+    double mu, tau, df, theta, fcost, logsum, thmax, thmin, a0lb, a0ub;
+    if (MB) {
+        mpc_lds_cptr q = c.scl;
+        status = (int32_t)q[WgScl::STATUS]; nfilt = (int32_t)q[WgScl::NFILT]; iters = (int32_t)q[WgScl::ITERS];
+        convf = (int32_t)q[WgScl::CONV]; frow = (int32_t)q[WgScl::FROW]; haveth0 = (int32_t)q[WgScl::HAVETH0];
+        mu = q[WgScl::MU]; tau = q[WgScl::TAU]; df = q[WgScl::DF]; theta = q[WgScl::THETA]; fcost = q[WgScl::FCOST]; logsum = q[WgScl::LOGSUM];
+        thmax = q[WgScl::THMAX]; thmin = q[WgScl::THMIN]; a0lb = q[WgScl::A0LB]; a0ub = q[WgScl::A0UB];
+    } else {
+        // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
+        status = MPC_S(P.ISC, IS_STATUS); nfilt = MPC_S(P.ISC, IS_NFILT); iters = MPC_S(P.ISC, IS_ITERS);
+        convf = MPC_S(P.ISC, IS_CONV); frow = MPC_S(P.ISC, IS_FROW); haveth0 = MPC_S(P.ISC, IS_HAVETH0);
+        mu = MPC_S(P.SC, SC_MU); tau = MPC_S(P.SC, SC_TAU); df = MPC_S(P.SC, SC_DF); theta = MPC_S(P.SC, SC_THETA);
+        fcost = MPC_S(P.SC, SC_FCOST); logsum = MPC_S(P.SC, SC_LOGSUM);
+        thmax = MPC_S(P.SC, SC_THMAX); thmin = MPC_S(P.SC, SC_THMIN);
+        a0lb = MPC_S(P.SC, SC_A0LB); a0ub = MPC_S(P.SC, SC_A0UB);
+    }
     c.status = status;
     c.active = status == ST_RUNNING;
     c.mu = mu; c.tau = tau; c.df = df; c.theta = theta;
@@ -1065,8 +1086,10 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
 // mailbox arrays instead of the tile-major ones (workgroup-resident path)
 // REC (MB only): also read what the sweeps left in the LDS record (step, cost-to-go); false: memory only -- k_solve_wg issues these
 // loads between its two sweeps and reads the record once the forward sweep is through (phase_preload_rec)
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool REC = true>
-MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
+// KEEPC (k_solve_wg, from a workgroup's second round on its instances): what does not change from round to round -- the reference of the next
+// stage, r_0, and whether any instance of the workgroup keeps its friction row at all -- is the caller's business (LDS / a register): no loads
+template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool REC = true, bool KEEPC = false>
+MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool fric_maybe = true) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
@@ -1095,17 +1118,19 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
         }
     }
     if (MPC_RA && k < N) {
-        ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
+        if (!KEEPC) ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
         if (MB) { if (REC) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); } else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
+        for (int i = 0; i < NX; ++i) { if (!KEEPC) c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
     }
     if (MPC_RA) {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
+        if (!KEEPC) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+            for (int i = 0; i < NX; ++i) c.r0[i] = (k == 0) ? (double)MPC_S(P.REF, i) : 0.0;
+        }
         if (MB) { if (REC) rec_load<D::NPK>(c.rec + Rec<NX>::PK, tmp.pk); } else ws_load_rows<D::NPK>(MPC_ROWS(MPC_K(P.PK, D::NPK, 0, e)), tmp.pk);
     }
     c.so[0] = c.so[1] = c.so[2] = 0.0;
@@ -1120,7 +1145,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
     }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
-    if (MPC_RA && k == 0) {                                // (fric_row is not known yet; the values are only used if it is set)
+    if (MPC_RA && k == 0 && fric_maybe) {                  // (fric_row is not known yet; the values are only used if it is set)
         c.sf = MPC_S(P.SC, SC_SF);
         c.nuf = MPC_S(P.SC, SC_NUF);
         c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
@@ -1321,7 +1346,7 @@ MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
 }
 
 // acceptance test of the trial point against the filter, the switching and the Armijo conditions
-template <int NX>
+template <int NX, bool MB = false>
 MPC_HD void phase_linesearch_decide(const PRef& P, Ctx<NX>& c, const Red2& red) {
     if (!(c.active && c.searching)) return;
     ++c.ntrial;
@@ -1329,7 +1354,7 @@ MPC_HD void phase_linesearch_decide(const PRef& P, Ctx<NX>& c, const Red2& red) 
     const double ph_t = red.bad > 0.0 ? INFINITY : c.df * red.fcost - c.mu * red.logsum;
     bool good = isfinite(th_t) && isfinite(ph_t) && th_t <= c.thmax;
     for (int q = 0; q < c.nfilt && good; ++q) {
-        const double tf = MPC_SD(P.FILT, 2 * q), pf = MPC_SD(P.FILT, 2 * q + 1);
+        const double tf = MB ? (double)c.scl[WgScl::FILT + 2 * q] : (double)MPC_SD(P.FILT, 2 * q), pf = MB ? (double)c.scl[WgScl::FILT + 2 * q + 1] : (double)MPC_SD(P.FILT, 2 * q + 1);
         if (!(cmp_le(fmax(th_t, THETA_FLOOR), fmax(tf, THETA_FLOOR), tf) || cmp_le(ph_t, pf, pf))) good = false;
     }
     if (good && c.conv) {
@@ -1363,7 +1388,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     const int N = P.N, k = c.k;
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
-        if (MPC_RA && k == 0) { MPC_S(P.ISC, IS_STATUS) = c.status; MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
+        if (MPC_RA && k == 0) { MPC_SCW(ISC, IS_STATUS, STATUS, c.status); MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
@@ -1453,18 +1478,20 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
                 for (int q = 1; q < FILTER_MAX; ++q) {          // (a cold path: unrolled, its 62 loads in flight set the register count of the kernel)
                     MPC_SD(P.FILT, 2 * (q - 1)) = MPC_SD(P.FILT, 2 * q);
                     MPC_SD(P.FILT, 2 * (q - 1) + 1) = MPC_SD(P.FILT, 2 * q + 1);
+                    if (MB) { c.scl[WgScl::FILT + 2 * (q - 1)] = c.scl[WgScl::FILT + 2 * q]; c.scl[WgScl::FILT + 2 * (q - 1) + 1] = c.scl[WgScl::FILT + 2 * q + 1]; }
                 }
                 --nf;
             }
             MPC_SD(P.FILT, 2 * nf) = (1 - GAMMA_THETA) * c.theta;
             MPC_STORE_FENCE();       // (the two rows of an entry are one row pair: through the shared descriptor the compiler would merge the stores)
             MPC_SD(P.FILT, 2 * nf + 1) = c.phi - GAMMA_PHI * c.theta;
-            MPC_S(P.ISC, IS_NFILT) = nf + 1;
+            if (MB) { c.scl[WgScl::FILT + 2 * nf] = (1 - GAMMA_THETA) * c.theta; c.scl[WgScl::FILT + 2 * nf + 1] = c.phi - GAMMA_PHI * c.theta; }
+            MPC_SCW(ISC, IS_NFILT, NFILT, nf + 1);
         }
-        MPC_S(P.ISC, IS_ITERS) = c.iters + 1;
-        MPC_S(P.ISC, IS_HAVETH0) = 1;
-        MPC_S(P.SC, SC_THMAX) = c.thmax;
-        MPC_S(P.SC, SC_THMIN) = c.thmin;
+        MPC_SCW(ISC, IS_ITERS, ITERS, c.iters + 1);
+        MPC_SCW(ISC, IS_HAVETH0, HAVETH0, 1);
+        MPC_SCW(SC, SC_THMAX, THMAX, c.thmax);
+        MPC_SCW(SC, SC_THMIN, THMIN, c.thmin);
         MPC_S(P.SC, SC_ALPHA) = al;
         MPC_S(P.SC, SC_ADU) = ad;
         MPC_S(P.SC, SC_PHI) = c.phi;
@@ -1741,9 +1768,9 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
                 if (D::hrow(i, j) >= 0) hh[D::hrow(i, j) >= 0 ? D::hrow(i, j) : 0] = H[D::sidx(i, j)];
         }
         if (MB) {
-            // (the copy in memory is what a repeated sweep rebuilds the records from; the sweeps themselves read the record: the defect negated)
-            ws_store_rows<8>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
-            ws_store_rows<NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
+            // (the copy in memory is what a repeated sweep rebuilds the records from -- the entries its cost-to-go went over: Ruu, gu, gx, H; A and
+            //  the defect are still in the record then; the sweeps themselves read the record: the defect negated)
+            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_RUU), head[6], head[7]);
             ws_store_rows<D::NH>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
             using RC = Rec<NX>;
             double ncn[NX];
@@ -1835,15 +1862,15 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
     }
     c.status = status;
     if (MPC_RA && k == 0) {
-        MPC_S(P.SC, SC_MU) = mu;
-        MPC_S(P.SC, SC_TAU) = tau;
-        MPC_S(P.SC, SC_THETA) = red.theta;
-        MPC_S(P.SC, SC_FCOST) = red.fcost;
-        MPC_S(P.SC, SC_LOGSUM) = red.logsum;
+        MPC_SCW(SC, SC_MU, MU, mu);
+        MPC_SCW(SC, SC_TAU, TAU, tau);
+        MPC_SCW(SC, SC_THETA, THETA, red.theta);
+        MPC_SCW(SC, SC_FCOST, FCOST, red.fcost);
+        MPC_SCW(SC, SC_LOGSUM, LOGSUM, red.logsum);
         MPC_S(P.SC, SC_E0) = E0;
-        MPC_S(P.ISC, IS_STATUS) = status;
-        if (mu_changed) MPC_S(P.ISC, IS_NFILT) = 0;       // the filter is reset whenever mu changes
-        if (P.fixed_iters > 0 && E0 <= P.tol) MPC_S(P.ISC, IS_CONV) = 1;
+        MPC_SCW(ISC, IS_STATUS, STATUS, status);
+        if (mu_changed) MPC_SCW(ISC, IS_NFILT, NFILT, 0);       // the filter is reset whenever mu changes
+        if (P.fixed_iters > 0 && E0 <= P.tol) MPC_SCW(ISC, IS_CONV, CONV, 1);
     }
 }
 

@@ -273,7 +273,11 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
 //   ill   out: bit g: a circle row of instance g carries a large weight (the sticky IS_ILL mark, also written to the workspace)
 //   c0    out: LDS, 8 doubles per instance: c_0 = x_0 - r_0 at the new iterate, the start of the next forward sweep
 // ---------------------------------------------------------------------------------------------------------------
-struct WgIo { uint32_t fail; uint32_t ill; double* c0; };
+//   rn, r0   : LDS, what a stage thread reads every round and nothing changes: the reference of its next stage (NX doubles per thread), r_0 (8
+//              per instance); fric: may any instance of the workgroup keep its friction row (else its eight scalar rows are not loaded);
+//              have: the three are valid (set by the first round after the instances were taken over)
+//   scl      : LDS, WgScl::SIZE doubles per instance: the scalars and the filter the phases read every round (filled when the instances are taken over)
+struct WgIo { uint32_t fail; uint32_t ill; double* c0; double* rn; double* r0; double* scl; bool fric, have; };
 template <int NX, uint32_t VM, class Mid>
 __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int ib1, double* lds_bnd, const mpc_lds_ptr rec_base, const int n_mult, const int n_z, const bool stamp,
                                          uint32_t* live_out, WgIo& io, Mid&& mid) {
@@ -292,11 +296,21 @@ __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int
     c.rec = rec_base + ((t & (bx - 1)) * (P.N + 1) + (c.k <= P.N ? c.k : 0)) * Rec<NX>::SIZE;
     c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_bnd;
     c.bnd_ub = (P.N + 1) * (NX + 2);
+    c.scl = (mpc_lds_ptr)(lds_ptr_t)(io.scl + c.bl * WgScl::SIZE);
     // (Measured: with mid() BEHIND the two calls below -- the loads requested under the forward sweep -- the sweep takes 2.9 k ticks longer and
     //  the phases start 2.5 k earlier: what the ~50 loads cost is their ISSUE, ~55 ticks each, wherever it happens, not their latency.)
     mid();
-    phase_load_scalars<NX>(P, c);
-    phase_preload<NX, true, ROLE_ALL, VM, false>(P, c, tmp);
+    phase_load_scalars<NX, true>(P, c);
+    if (io.have) {
+        phase_preload<NX, true, ROLE_ALL, VM, false, true>(P, c, tmp, io.fric);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { c.rn[i] = io.rn[t * NX + i]; c.r0[i] = c.k == 0 ? io.r0[c.bl * 8 + i] : 0.0; }
+    } else {
+        phase_preload<NX, true, ROLE_ALL, VM, false>(P, c, tmp);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { io.rn[t * NX + i] = c.rn[i]; if (c.k == 0 && c.valid) io.r0[c.bl * 8 + i] = c.r0[i]; }
+        io.fric = __ballot((c.valid && c.k == 0 && c.fric_row) ? 1 : 0) != 0ull;
+    }
 #define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
     if (((io.fail >> (t & (bx - 1))) & 1u) && c.valid) { c.status = -7; c.active = false; }      // (what the sweep has written to the status row)
@@ -315,7 +329,7 @@ __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int
         Red2 r2;
         phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
         block_reduce(r2, bx, nullptr);
-        phase_linesearch_decide<NX>(P, c, r2);
+        phase_linesearch_decide<NX, true>(P, c, r2);
     }
     MPC_STAMP(5);
     phase_apply_update<NX, true, ROLE_ALL, VM>(P, c);
@@ -1148,7 +1162,7 @@ __device__ __forceinline__ bool resc_last(int q) { return q == 2 || q == 7; }
 template <int NX>
 struct WgLds {
     static constexpr int PAD = Rec<NX>::SIZE > 64 ? Rec<NX>::SIZE : 64;
-    __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2) + (size_t)8 * bxw; }
+    __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2) + (size_t)16 * bxw + (size_t)64 * NX + (size_t)WgScl::SIZE * bxw; }
 };
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
@@ -1203,11 +1217,14 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     const mpc_lds_ptr dump = (mpc_lds_ptr)(lds_ptr_t)lds;
     double* const lds_bnd = lds + WgLds<NX>::PAD + (size_t)RC::SIZE * ((N + 1) * bx);
     double* const lds_c0 = lds_bnd + 2 * (N + 1) * D::NZ;       // 8 doubles per instance: c_0 of the last stage phases
+    double* const lds_r0 = lds_c0 + 8 * bx;                     // 8 per instance: r_0
+    double* const lds_rn = lds_r0 + 8 * bx;                     // NX per stage thread: the reference of its next stage
+    double* const lds_scl = lds_rn + 64 * NX;                   // WgScl::SIZE per instance: scalars and filter
     bool bounds_ok = false;
     // per instance (slot g of the workgroup), wave-uniform and in registers from round to round: the last inertia correction, the mark of
     // heavily weighted circle rows -- read from the workspace when the instances are taken over
     double dl0 = 0.0, dl1 = 0.0;
-    WgIo io{0u, 0u, lds_c0};
+    WgIo io{0u, 0u, lds_c0, lds_rn, lds_r0, lds_scl, true, false};
     const MfmaWords lane_words = mfma_lane_load<NX>(lane);
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
@@ -1280,7 +1297,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
             }
             fresh = true;
-            bounds_ok = false;                    // (the restart used the whole LDS)
+            bounds_ok = false;
+            io.have = false;                    // (the restart used the whole LDS)
             continue;
         }
         ++rounds;
@@ -1326,8 +1344,12 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 double hx0 = 0.0, hx1 = 0.0;
                 if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
                 const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
+                // (a rebuild from the mailbox copy restores what the cost-to-go went over; A and the defect never left the record -- and are not in the copy)
 #pragma unroll
-                for (int i = 0; i < D::NBLK; ++i) r[RC::slot(i)] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
+                for (int i = 0; i < D::NBLK; ++i) {
+                    const bool kept = i < D::B_RUU || (i >= D::B_CN && i < D::B_CN + NX);
+                    if (tiled || !kept) r[RC::slot(i)] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
+                }
                 r[RC::ZERO] = 0.0;
                 r[RC::ONE] = 1.0;
                 r[RC::DT] = P.dt;
@@ -1344,6 +1366,19 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             if (valid && c.k == 0) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) lds_c0[(t & (bx - 1)) * 8 + i] = MPC_S(P.SC, SC_C0 + i);
+                // the scalars the phases read every round (WgScl)
+                double* q = lds_scl + c.bl * WgScl::SIZE;
+                q[WgScl::MU] = MPC_S(P.SC, SC_MU); q[WgScl::TAU] = MPC_S(P.SC, SC_TAU); q[WgScl::DF] = MPC_S(P.SC, SC_DF); q[WgScl::THETA] = MPC_S(P.SC, SC_THETA);
+                q[WgScl::FCOST] = MPC_S(P.SC, SC_FCOST); q[WgScl::LOGSUM] = MPC_S(P.SC, SC_LOGSUM); q[WgScl::THMAX] = MPC_S(P.SC, SC_THMAX);
+                q[WgScl::THMIN] = MPC_S(P.SC, SC_THMIN); q[WgScl::A0LB] = MPC_S(P.SC, SC_A0LB); q[WgScl::A0UB] = MPC_S(P.SC, SC_A0UB);
+                q[WgScl::STATUS] = (double)(int32_t)MPC_S(P.ISC, IS_STATUS); q[WgScl::NFILT] = (double)(int32_t)MPC_S(P.ISC, IS_NFILT);
+                q[WgScl::ITERS] = (double)(int32_t)MPC_S(P.ISC, IS_ITERS); q[WgScl::CONV] = (double)(int32_t)MPC_S(P.ISC, IS_CONV);
+                q[WgScl::FROW] = (double)(int32_t)MPC_S(P.ISC, IS_FROW); q[WgScl::HAVETH0] = (double)(int32_t)MPC_S(P.ISC, IS_HAVETH0);
+            }
+            // ... and the filter: lane l fetches row l of each instance
+            for (int g = 0; g < bx; ++g) {
+                const int bg = g ? ib1 : ib0;
+                if (bg >= 0 && t < 2 * FILTER_MAX) lds_scl[g * WgScl::SIZE + WgScl::FILT + t] = ws_ref3(P, P.FILT, 0u, (uint32_t)bg, mpc_prow((uint32_t)t));
             }
         }
         if (!bounds_ok) {
@@ -1417,6 +1452,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 lds_barrier();                                       // (step and cost-to-go are in the records; nothing of the sweeps' went to memory that this round reads)
                 WG_STAMP(14);
             });
+            io.have = true;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's rows are in the L2
         lds_barrier();
