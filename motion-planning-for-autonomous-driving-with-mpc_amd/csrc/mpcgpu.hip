@@ -2709,6 +2709,8 @@ struct Prof {
     hipStream_t s;
     size_t used = 0;
     std::vector<int> kinds;     // kind per (start, stop) pair
+    std::vector<std::pair<size_t, size_t>> spans;      // the pair's events (indices into the pool)
+    bool open = false;
     hipEvent_t get() {
         if (used == h->ev_pool.size()) {
             hipEvent_t ev;
@@ -2717,15 +2719,43 @@ struct Prof {
         }
         return h->ev_pool[used++];
     }
-    void begin(int kind, hipStream_t st = nullptr) { if (h->profiling) { kinds.push_back(kind); (void)hipEventRecord(get(), st ? st : s); } }
-    void end(hipStream_t st = nullptr) { if (h->profiling) (void)hipEventRecord(get(), st ? st : s); }
+    void begin(int kind, hipStream_t st = nullptr) {
+        if (!h->profiling) return;
+        if (open) { next(kind, st); return; }          // (a span left open on purpose: its end is this one's start)
+        kinds.push_back(kind);
+        (void)hipEventRecord(get(), st ? st : s);
+        spans.push_back({used - 1, 0});
+        open = true;
+    }
+    void end(hipStream_t st = nullptr) {
+        if (!h->profiling || !open) return;
+        (void)hipEventRecord(get(), st ? st : s);
+        spans.back().second = used - 1;
+        open = false;
+    }
+    // end of one span = start of the next, ONE event (a marker between two kernels costs the stream a microsecond or two: the kernels of the
+    // iteration loop are measured back to back with a single marker between them)
+    void next(int kind, hipStream_t st = nullptr) {
+        if (!h->profiling) return;
+        if (!open) {
+            kinds.push_back(kind);
+            (void)hipEventRecord(get(), st ? st : s);
+            spans.push_back({used - 1, 0});
+            open = true;
+            return;
+        }
+        (void)hipEventRecord(get(), st ? st : s);
+        spans.back().second = used - 1;
+        kinds.push_back(kind);
+        spans.push_back({used - 1, 0});
+    }
     void collect() {
         for (int i = 0; i < 6; ++i) h->prof[i] = 0;
         if (!h->profiling) return;
         (void)hipDeviceSynchronize();
         for (size_t i = 0; i < kinds.size(); ++i) {
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
+            (void)hipEventElapsedTime(&ms, h->ev_pool[spans[i].first], h->ev_pool[spans[i].second]);
             if (kinds[i] == 0) { h->prof[0] += ms; h->prof[1] += 1; }
             else if (kinds[i] == 1) { h->prof[2] += ms; h->prof[3] += 1; }
             else if (kinds[i] == 3) h->pipe_prof[0] += ms;
@@ -2886,7 +2916,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
             launch_stage(q, true);
         }
-        prof.end(q.st);
+        if (G > 1) prof.end(q.st);          // (one stream: the span stays open, the first kernel of the loop starts where it ends)
     }
 
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
@@ -3118,16 +3148,16 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 HIP_TRY(h, hipMemsetAsync(d_pdbg, 0, sizeof(unsigned long long) * 16 * (size_t)h->n_cu, stream));
                 P.DBG = d_pdbg;
             }
-            prof.begin(3, stream);
+            prof.next(3, stream);
 #if MPC_WITH_PAIR
             if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else
 #endif
             if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
-            prof.end(stream);
+            if (hand <= 0) prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
-                prof.begin(5, stream);
+                prof.next(5, stream);
                 if (ho_list) {
                     // (the counters: words of the control block, zero at the start of every solve)
                     if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO);
@@ -3136,11 +3166,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
                 }
                 launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
-                prof.end(stream);
             }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
             // synchronisation of the call is the last thing that happens
-            prof.begin(2, stream);
+            prof.next(2, stream);
             // (instances that did not converge are counted into word 14 of the control block, which travels back with the abort word;
             //  an asynchronous closed loop accumulates them over its steps in d_fail instead)
             hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT),
