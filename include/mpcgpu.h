@@ -238,12 +238,20 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing",
  * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage),
  * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve),
- * "pair" (1: two threads per (instance, stage) in the stage phases; measured slower, profiles/r04_stage_split.txt),
+ * "pair" (1: two threads per (instance, stage) in the stage phases; measured slower, profiles/r04_stage_split.txt -- the variant is
+ * compiled only with -DMPC_WITH_PAIR=1; in the default build any value but 0 is MPC_ERR_INVALID),
+ * "wg_list" (default 1: at the hand-over of the hybrid solve the live instances of all tiles are dealt to the workgroups of k_solve_wg
+ * from lists ordered by how far from convergence they are -- a workgroup takes one near and one far instance; 0: a workgroup takes
+ * instances b, b + 1 of its tile and skips finished ones), "ho_inline" (default 1: those lists are written by the stage workers of the
+ * pipeline as they retire a tile; 0: by a small kernel between the two launches), "wg_trace" (1: k_solve_wg records per workgroup its
+ * first and last clock, rounds and sweeps; tools/wg_profile.py prints the distribution),
  * "bound_mask" (0: every bound side is looked up at run time -- variant 0 of the loop kernels; default 1: when the bounds handed to
  * mpc_set_bounds have the structure of the reference's NLPs (optimizer.py:421-491: only steering rate, acceleration, steering angle and speed
  * bounded, circle rows with a lower bound only, multiplicity 3, no per-instance obstacle) the kernels with that structure compiled in are
  * used; same algorithm and iteration counts, results agree at round-off), "rescue_wg" (0: the second chance of stalled instances only on
- * the host side, behind the launch; default 1: inside k_solve_wg where the batch runs one instance per workgroup -- bit-identical results)
+ * the host side, behind the launch; default 1: inside k_solve_wg where the batch runs one instance per workgroup -- same levels, same
+ * bookkeeping: a row whose levels fail gets back its FIRST result, status and iteration count plus the iterations of the levels tried,
+ * exactly as the host-side path reports it; tests/test_gpu_parity.py::test_second_chance_paths_agree_when_levels_fail)
  * (measurement and test aids);
  * "friction_lb" -- the lower bound lbg[0] = 0 of the reference's stage-0 friction row sqrt((a_0^2 + v_0^2 tan(delta_0)/2.578)^2)
  * (MPC_Planner/optimizer.py:378, 424-425): "nlp" / 0 (default) = implied by the absolute value, no barrier -- a solve returns the
