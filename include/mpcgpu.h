@@ -245,6 +245,9 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * instances b, b + 1 of its tile and skips finished ones), "ho_inline" (default 1: those lists are written by the stage workers of the
  * pipeline as they retire a tile; 0: by a small kernel between the two launches), "wg_trace" (1: k_solve_wg records per workgroup its
  * first and last clock, rounds and sweeps; tools/wg_profile.py prints the distribution),
+ * "pipe_help" (-1, the default: decided per batch; 1 / 0: the Riccati workers of the pipeline take / do not take one published stage item
+ * while their own tile is with the stage workers -- k_pipeline<.., HELP>; it pays when a round has more than three stage items per stage
+ * worker, e.g. N = 50 or B = 8192; same bits either way),
  * "bound_mask" (0: every bound side is looked up at run time -- variant 0 of the loop kernels; default 1: when the bounds handed to
  * mpc_set_bounds have the structure of the reference's NLPs (optimizer.py:421-491: only steering rate, acceleration, steering angle and speed
  * bounded, circle rows with a lower bound only, multiplicity 3, no per-instance obstacle) the kernels with that structure compiled in are

@@ -636,8 +636,8 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
         if (active) { delta_last = MPC_U(P.SC, (uint32_t)SC_DLAST); hux0 = MPC_U(P.SC, (uint32_t)SC_HUX0); hux1 = MPC_U(P.SC, (uint32_t)SC_HUX1); }
     }
     for (;;) {
-        if (wave == 2) {
-            for (int t = 0; t <= N; ++t) lds_barrier();             // second loader: idle in the backward sweep
+        if (wave >= 2) {
+            for (int t = 0; t <= N; ++t) lds_barrier();             // second loader: idle in the backward sweep (a fourth wave -- k_pipeline's helping workers -- in both)
         } else if (wave == 1) {
             // ---------------- loader: stages N, N-1, ... ; stage N-t lives in slot t % RIC_DEPTH
             for (int j = 0; j < RIC_DEPTH - 1 && j <= N; ++j) dma(blk_base + (uint32_t)(N - j) * BLK_BYTES, (uint32_t)j * SLOT, BLK_CHUNKS);
@@ -708,7 +708,9 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
     RIC_STAMP(1);
     // ================================================================ forward sweep
     const bool go = (wave == 0) && active && !failed;
-    if (wave >= 1) {
+    if (wave >= 3) {
+        for (int k = 0; k < N; ++k) lds_barrier();
+    } else if (wave >= 1) {
         // two loaders: wave 1 owns the even stages, wave 2 the odd ones.  Stage k lives in slot k % RIC_DEPTH_F; the slot
         // of stage k-1 is free once the compute wave has reached barrier k, and gets stage k-1+RIC_DEPTH_F.
         const int par = wave - 1;
@@ -871,7 +873,10 @@ __global__ void k_xcd_census(uint32_t* mask) {
 // VAR: 0 one thread per (instance, stage), bounds looked up at run time; 1 two threads per (instance, stage) (stage_pair); 2 one thread per
 // stage with the bound structure of the reference compiled in (PAIR_VM: only steering rate, acceleration, steering angle and speed carry
 // bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
-template <int NX, int VAR>
+// HELP: the Riccati workers take a stage item while their tile is with the stage workers (below) -- a variant of its own: the extra code in the
+// Riccati worker's loop costs the sweeps of the default kernel 3.5 % through its register allocation, and only batches whose stage items outnumber
+// the stage workers three to one gain from it (N = 50: 16 items per tile)
+template <int NX, int VAR, bool HELP = false>
 __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params Pk, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
     const PRef P(Pk);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -902,7 +907,11 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 #define PIPE_STAMP(i) do { if (P.DBG && t == 0 && n_pass == 5u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (slot < n_ric) {
         // ============================================================ Riccati worker: local tiles slot, slot + n_ric, ...
-        if (t >= 192) return;
+        // (option pipe_help: a Riccati worker whose tile has just gone to the stage workers takes ONE stage item of the queue itself instead of
+        //  idling through the item time -- a third more stage capacity per XCD; its fourth wavefront then stays, idle, through the sweeps)
+        constexpr bool helper = HELP && VAR != 1;
+        if (!helper && t >= 192) return;
+        uint32_t n_help = 0u;
         const uint32_t n_own = (n_tiles_x - slot + n_ric - 1u) / n_ric;
         uint32_t fin = 0u, round = 0u;
         for (;; ++round) {
@@ -951,10 +960,63 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 PIPE_STAMP(13);
                 ++n_pass;
                 lds_barrier();                     // the rings are free again
+                if constexpr (helper) if (mask != 0ull) {
+                    if (t == 0) {
+                        uint32_t item = PIPE_EXIT;
+                        unsigned long long bits = 0ull;
+                        // the tile this worker turns to next: still with the stage workers?  (else its Riccati pass goes first)
+                        uint32_t jn = j, rn = round;
+                        do { if (++jn == n_own) { jn = 0u; ++rn; } } while (((fin >> jn) & 1u) && jn != j);
+                        const uint32_t tile_n = (slot + jn * n_ric) * n_xcd + xcd;
+                        if (pipe_ld(stage_done + tile_n) < A.items * rn) {
+                            // a ticket only for an item that has been published (the stage workers draw theirs blindly and wait; this worker must not)
+                            uint32_t hd = pipe_ld(X + 16);
+                            bool got = false;
+                            while ((int32_t)(pipe_ld(X + 32) - hd) > 0) {
+                                uint32_t seen = hd;
+                                if (__hip_atomic_compare_exchange_strong(X + 16, &seen, hd + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = true; break; }
+                                hd = seen;
+                            }
+                            if (got) {
+                                const unsigned long long* sl = slots + (hd & (A.cap - 1u));
+                                const unsigned long long t0 = wall_clock64();
+                                for (;;) {
+                                    const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if ((uint32_t)(v >> 32) == hd + 1u) { item = (uint32_t)v; break; }
+                                    if (pipe_ld(abort_w)) break;
+                                    if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); break; }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                if (item != PIPE_EXIT) {
+                                    bits = __hip_atomic_load(P.tile_mask + (item >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    pipe_acquire((A.flags & 9u) == 0u);
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                }
+                            }
+                        }
+                        sh_word[1] = item;
+                        sh_word[2] = (uint32_t)bits;
+                        sh_word[3] = (uint32_t)(bits >> 32);
+                    }
+                    lds_barrier();
+                    const uint32_t item = sh_word[1];
+                    const unsigned long long bits = ((unsigned long long)sh_word[3] << 32) | sh_word[2];
+                    if (item != PIPE_EXIT) {
+                        stage_block<NX, false, 256, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, (item >> 8) * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, false, nullptr, false);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lds_barrier();
+                        if (t == 0) {
+                            if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                            pipe_add(stage_done + (item >> 8), 1u);
+                            ++n_help;
+                        }
+                    }
+                    lds_barrier();
+                }
             }
             if (all_done) break;
         }
-        if (t == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS) + 0, waited); pipe_add(A.ctl + PIPE_STATS + 11, 1u); }
+        if (t == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(A.ctl + PIPE_STATS) + 0, waited); pipe_add(A.ctl + PIPE_STATS + 11, 1u); if (n_help) pipe_add(A.ctl + PIPE_ABORT + 21, n_help); }   // (word 21: stage items served by helping Riccati workers; word 14 is the fail count of k_egest)
         return;
     }
     // ================================================================ stage worker: pulls (tile, sub-block) items of its XCD
@@ -2366,7 +2428,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2402,6 +2464,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "wg_trace") k.wg_trace = on != 0;
     else if (n == "wg_list") k.wg_list = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "ho_inline") k.ho_inline = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2435,6 +2498,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "wg_trace") *out = k.wg_trace;
     else if (n == "wg_list") *out = k.wg_list;
     else if (n == "ho_inline") *out = k.ho_inline;
+    else if (n == "pipe_help") *out = k.pipe_help;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2448,7 +2512,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2840,6 +2904,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -3119,6 +3185,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.cap = 1;
             while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
             A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
+            // the Riccati workers help with the stage items (k_pipeline<.., HELP>) where those are the bottleneck: more than three per stage worker and round
+            const bool pipe_help = !pipe_pair && (kn.pipe_help < 0 ? (int)A.items * tiles_x > 3 * (cu_x - n_ric) : kn.pipe_help != 0);
             A.handover = (uint32_t)hand;
             int32_t* ho_list = nullptr;
             A.ho_list = nullptr;
@@ -3153,7 +3221,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else
 #endif
-            if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (pipe_help && masked) hipLaunchKernelGGL((k_pipeline<NX, 2, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (pipe_help) hipLaunchKernelGGL((k_pipeline<NX, 0, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
+            else if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             if (hand <= 0) prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)

@@ -117,6 +117,32 @@ def test_optional_kernel_variants_are_bit_identical(env, monkeypatch):
         assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+@pytest.mark.parametrize("fam,B,masked", [("zamlf_n30_nx6", 4096, True), ("usalf_n50_nx5", 2500, True), ("zamlf_n30_nx6", 1500, False)])
+def test_riccati_workers_that_help_with_stage_items_change_nothing(fam, B, masked):
+    """Option pipe_help (k_pipeline<.., HELP>; default: on when a round has more than three stage items per stage worker, e.g. N = 50): a Riccati
+    worker whose tile has just gone to the stage workers takes one published stage item itself instead of idling.  Who serves an item does not
+    enter the arithmetic: rows, statuses and iteration counts are the bits of the launch without helpers, with the hybrid solve and without it,
+    run after run (a helper that drew a ticket for an item nobody publishes, or released a tile's arrival counter early, would show here as a
+    timeout / restart or as different bits)."""
+    cfg, kw = FAMILIES[fam]
+    x0, p = synthetic_batch(cfg, B, **kw)
+    s = make_solver(cfg)
+    if masked:
+        set_cfg_bounds(s, cfg)
+    assert s.get_option("pipe_help") == -1
+    for hyb in ("1", "0"):
+        s.set_option("hybrid", hyb)
+        s.set_option("pipe_help", "0")
+        ref = s.solve(x0, p)
+        piped = hyb == "0" or B > 2048                     # (the hybrid solve of a small batch has no pipeline launch at all)
+        assert s.get_pipeline_profile()["ran"] == piped and np.all(ref.status == 1)
+        s.set_option("pipe_help", "1")
+        for _ in range(3):
+            alt = s.solve(x0, p)
+            assert s.get_pipeline_profile()["ran"] == piped
+            assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
+
+
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5"])
 def test_compiled_in_bound_structure_against_the_run_time_lookup(fam):
     """Variant 2 of the kernels (option bound_mask, the default whenever the handle's bounds have the reference's structure: only steering
