@@ -245,6 +245,9 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * instances b, b + 1 of its tile and skips finished ones), "ho_inline" (default 1: those lists are written by the stage workers of the
  * pipeline as they retire a tile; 0: by a small kernel between the two launches), "wg_trace" (1: k_solve_wg records per workgroup its
  * first and last clock, rounds and sweeps; tools/wg_profile.py prints the distribution),
+ * "mb_pipe" (default 1: in the hybrid solve the pipeline's stage items of a tile that is about to leave write iterate, multipliers and stage block
+ * into the instance-major arrays of k_solve_wg as well, which then takes its instances over without copying them; 0: every workgroup of k_solve_wg
+ * copies its instances out of the tile-major rows -- 35 us at the head of the launch on the headline batch; same bits),
  * "pipe_help" (-1, the default: decided per batch; 1 / 0: the Riccati workers of the pipeline take / do not take one published stage item
  * while their own tile is with the stage workers -- k_pipeline<.., HELP>; it pays when a round has more than three stage items per stage
  * worker, e.g. N = 50 or B = 8192; same bits either way),

@@ -132,6 +132,7 @@ struct Params {
     uint32_t ws_bytes, iws_bytes;
     uint32_t tile_elems, itile_elems;   // elements per 64-instance tile of the double / int32 workspace
     int32_t tile0;                      // first 64-instance tile handled by this launch (sub-batch pipelining)
+    int32_t mbw_live;                   // k_pipeline: stage items of a tile with at most this many instances iterating write the mailbox arrays too (0: never)
     unsigned long long* DBG;            // optional [blocks][16] shader-clock stamps of the stage kernel (profiling aid), or null
     double* x_out;               // [B][n_w] row-major (ABI output)
     int32_t* status_out;
@@ -249,20 +250,18 @@ __device__ __forceinline__ WsRefI ws_ref3(const PRef& P, const int32_t* arr, uin
 //   MPC_KM(arr, R, dk, e) mailbox array (instance-major): row e of stage k + dk of thread c
 #define MPC_KM(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, ((uint32_t)(dk) * MPC_EV(R) + (uint32_t)(e)) * 8u, \
                                      (((uint32_t)c.b * (uint32_t)(P.N + 1) + (uint32_t)c.k) * MPC_EV(R)) * 8u}
-//   MPC_KI(arr, R, dk, e) mailbox array of the ITERATE (MZ ... MREF), stage-fastest inside the block of a workgroup's bx instances:
-//                         [workgroup][row pair][stage * bx + instance of the block][2] -- the same memory as the instance-major form (a
-//                         permutation inside the block), but the 16-byte pieces the stage threads of a wavefront touch with one instruction
-//                         are contiguous (8 cache lines per wave instruction instead of one per lane).  The layout belongs to the launch
-//                         (P.bx): k_solve_wg fills these arrays when it takes its instances over and reads them back when it leaves.
-//                         (c.mb: the block's first instance SLOT = workgroup index x bx, c.bl: this thread's slot in the block -- the
-//                         instances a workgroup works on need not be neighbours: k_solve_wg behind the pipeline takes them from a list)
+//   MPC_KI(arr, R, dk, e) mailbox array of the iterate (MZ ... MLAM) and of the stage blocks (MBLK), stage-fastest inside the block of ONE instance:
+//                         [instance][row pair][stage][2] -- the 16-byte pieces the stage threads of an instance touch with one instruction are
+//                         contiguous (4 - 5 cache lines per instance and wave instruction instead of one per lane).  The address depends on the
+//                         instance alone, not on who works on it: the stage workers of k_pipeline write these arrays for the tiles about to leave
+//                         (Ctx::mbw), any workgroup of k_solve_wg can take the instance over.
 #define MPC_KI(ptr, R, dk, e) WsRefD{P, (uint32_t)(uintptr_t)(ptr) - (uint32_t)(uintptr_t)P.WS, \
-                                     ((((uint32_t)(e) >> 1) * (uint32_t)(P.N + 1) + (uint32_t)(dk)) * (uint32_t)P.bx * 2u + ((uint32_t)(e) & 1u)) * 8u, \
-                                     ((uint32_t)c.mb * (uint32_t)(P.N + 1) * MPC_EV(R) + ((uint32_t)c.k * (uint32_t)P.bx + (uint32_t)c.bl) * 2u) * 8u}
+                                     ((((uint32_t)(e) >> 1) * (uint32_t)(P.N + 1) + (uint32_t)(dk)) * 2u + ((uint32_t)(e) & 1u)) * 8u, \
+                                     ((uint32_t)c.b * (uint32_t)(P.N + 1) * MPC_EV(R) + (uint32_t)c.k * 2u) * 8u}
 #else
 typedef Params PRef;
-#define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)c.mb * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * P.bx * 2 + \
-                                     ((size_t)(c.k + (dk)) * P.bx + (size_t)c.bl) * 2 + ((uint32_t)(e) & 1u)])
+#define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)c.b * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * 2 + \
+                                     (size_t)(c.k + (dk)) * 2 + ((uint32_t)(e) & 1u)])
 #define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
 #define MPC_K(ptr, R, dk, e) ((ptr)[ws_index(P, (ptr), ((uint32_t)c.k + (uint32_t)(dk)) * MPC_EV(R) + (uint32_t)(e), (uint32_t)c.b)])
 #define MPC_S(ptr, row) ((ptr)[ws_index(P, (ptr), (uint32_t)(row), (uint32_t)c.b)])
@@ -587,7 +586,8 @@ template <int NX>
 struct Ctx {
     static constexpr int NZ = NX + 2;
     int b, k;
-    int mb, bl;      // (k_solve_wg: first instance slot of the workgroup's block, this thread's slot in it -- MPC_KI)
+    int mb, bl;      // (k_solve_wg: first instance slot of the workgroup's block, this thread's slot in it)
+    bool mbw = false;    // (k_pipeline: the stage phases write iterate and stage block to the mailbox arrays as well -- the tile is about to leave)
     bool valid;      // b < B and k <= N
     bool active;     // valid and instance still iterating
     // --- iterate pieces live across the line search
@@ -1118,7 +1118,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
         }
     }
     if (MPC_RA && k < N) {
-        if (!KEEPC) ws_load_rows<NX>(MPC_ROWS(MPC_KX(REF, NX, 1, e)), c.rn);
+        if (!KEEPC) ws_load_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 1, e)), c.rn);           // (constant: read where the start kernel put it, MB or not)
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
         if (MB) { if (REC) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); } else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
     } else {
@@ -1406,6 +1406,8 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     }
     // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
     if (MPC_RA) ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
+    const bool mbw = !MB && ROLE == ROLE_ALL && c.mbw;           // (wave-uniform: a property of the tile)
+    if (mbw) ws_store_rows<NZ>(MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)), c.z);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         const bool a0 = (i == 0) && (k == 0);
@@ -1413,9 +1415,11 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         const bool mine = side_mine<ROLE, VM>(i) || (i + 1 < NZ && side_mine<ROLE, VM>(i + 1));
         if (mine && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KX(ZL, NZ, 0, i) = c.zl[i];
+            if (mbw) { if (i + 1 < NZ) MPC_ST2(MPC_KI(P.MZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KI(P.MZL, NZ, 0, i) = c.zl[i]; }
         }
         if (mine && (((P.hi_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_KX(ZU, NZ, 0, i) = c.zu[i];
+            if (mbw) { if (i + 1 < NZ) MPC_ST2(MPC_KI(P.MZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_KI(P.MZU, NZ, 0, i) = c.zu[i]; }
         }
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
@@ -1423,6 +1427,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
         ws_store_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), c.lam);
+        if (mbw) ws_store_rows<NX>(MPC_ROWS(MPC_KI(P.MLAM, NX, 0, e)), c.lam);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1448,6 +1453,12 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         if (MPC_HAS_OU) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
         ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
         ws_store_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
+        if (mbw) {
+            if (MPC_HAS_OL) ws_store_rows<3>(MPC_ROWS(MPC_KI(P.MZLO, 3, 0, e)), c.zlo);
+            if (MPC_HAS_OU) ws_store_rows<3>(MPC_ROWS(MPC_KI(P.MZUO, 3, 0, e)), c.zuo);
+            ws_store_rows<3>(MPC_ROWS(MPC_KI(P.MNUO, 3, 0, e)), c.nuo);
+            ws_store_rows<3>(MPC_ROWS(MPC_KI(P.MSO, 3, 0, e)), c.so);
+        }
     }
     if (MPC_RA && k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = s + al * ds;
@@ -1770,8 +1781,8 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
         if (MB) {
             // (the copy in memory is what a repeated sweep rebuilds the records from -- the entries its cost-to-go went over: Ruu, gu, gx, H; A and
             //  the defect are still in the record then; the sweeps themselves read the record: the defect negated)
-            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_RUU), head[6], head[7]);
-            ws_store_rows<D::NH>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
+            MPC_ST2(MPC_KI(P.MBLK, D::NBLK, 0, D::B_RUU), head[6], head[7]);
+            ws_store_rows<D::NH>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
             using RC = Rec<NX>;
             double ncn[NX];
 #pragma unroll
@@ -1785,6 +1796,11 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
             ws_store_rows<8>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_CN + e)), cn);
             ws_store_rows<D::NH>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_H + e)), hh);
+            if (ROLE == ROLE_ALL && c.mbw) {        // (the whole block: k_solve_wg builds its first records from this copy)
+                ws_store_rows<8>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
+                ws_store_rows<NX>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
+                ws_store_rows<D::NH>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
+            }
         }
     }
     red.dual_inf = dual; red.prim_inf = prim; red.cmin = cmin; red.cmax = cmax;
@@ -1851,13 +1867,17 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         if (ROLE == ROLE_B) {
         } else if (MB) {
             const double gu[2] = {c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]};
-            ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), gx);
-            MPC_ST2(MPC_KM(P.MBLK, D::NBLK, 0, D::B_GU), gu[0], gu[1]);
+            ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, e)), gx);
+            MPC_ST2(MPC_KI(P.MBLK, D::NBLK, 0, D::B_GU), gu[0], gu[1]);
             rec_store<NX>(c.rec + Rec<NX>::GX, gx);
             rec_store<2>(c.rec + Rec<NX>::GU, gu);
         } else {
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_K(P.BLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
+            if (c.mbw) {
+                ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, e)), gx);
+                MPC_ST2(MPC_KI(P.MBLK, D::NBLK, 0, D::B_GU), c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]);
+            }
         }
     }
     c.status = status;

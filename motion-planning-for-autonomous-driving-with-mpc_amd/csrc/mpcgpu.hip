@@ -170,6 +170,9 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     c.ill = false;
     c.status = 0;
     c.iters = 0;
+    // (hybrid solve: a tile with few instances left is about to go to k_solve_wg -- its items write the mailbox arrays as well, so that the workgroups
+    //  there find their instances in the layout they work on; a property of the tile's mask, the same for every item of the round)
+    c.mbw = !INIT && P.mbw_live > 0 && __popcll(tile_bits) <= P.mbw_live;
 #define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPC_STAMP(0);
     if (!INIT) {
@@ -942,6 +945,9 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 if (mask == 0ull) {
                     fin |= 1u << j;
                     if (t == 0) {
+                        // (bit 31 of the tile's arrival counter, for k_solve_wg: the items of its last round wrote the mailbox arrays -- same predicate as stage_block's)
+                        if (round > 0u && P.mbw_live > 0 && __popcll(__hip_atomic_load(P.tile_mask + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= P.mbw_live)
+                            __hip_atomic_fetch_or(stage_done + tile, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         atomicMax(A.ctl + PIPE_ABORT + 1, round);
                         pipe_add(X + 48, 1u);
                     }
@@ -1228,7 +1234,7 @@ struct WgLds {
 };
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
-                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
+                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n, const uint32_t* mb_flag) {
     PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1291,6 +1297,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
     const unsigned long long t_begin = wtrace ? wall_clock64() : 0ull;        // (option wg_trace: when did this workgroup start, how long did it run, how many rounds)
+    unsigned long long t_fresh = 0ull, t_round1 = 0ull;                        // (... when were its instances taken over, when was its first round done)
     if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
@@ -1369,7 +1376,9 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         // ---- taking the instances over: the iterate, its multipliers and the reference move from the tile-major arrays (where the
         //      pipeline / the start-iterate kernel left them) into the instance-major mailbox arrays the rounds below work on -- one
         //      wavefront reads all stages of its one or two instances, and only there are the pieces of a thread contiguous
-        if (fresh && valid) {
+        // (not for the instances of a tile whose last stage items in the pipeline wrote the mailbox arrays themselves: mb_flag, bit 31 of the tile's word)
+        const bool by_pipe = !RESC && mb_flag != nullptr && valid && (mb_flag[(uint32_t)c.b >> 6] >> 31) != 0u;
+        if (fresh && valid && !by_pipe) {
             auto move = [&](auto cnt, auto from, auto to) {
                 constexpr int CNT = decltype(cnt)::value;
                 double v[MPC_EV(CNT)];
@@ -1385,7 +1394,6 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZLO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MZLO, 3, 0, e)));
             move(std::integral_constant<int, 4>{}, MPC_ROWS(MPC_K(P.ZUO, 3, 0, e)), MPC_ROWS(MPC_KI(P.MZUO, 3, 0, e)));
             move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), MPC_ROWS(MPC_KI(P.MLAM, NX, 0, e)));
-            move(std::integral_constant<int, NX>{}, MPC_ROWS(MPC_K(P.REF, NX, 0, e)), MPC_ROWS(MPC_KI(P.MREF, NX, 0, e)));
         }
         if (fresh) {
             // (the rows just moved are read by OTHER lanes too -- the neighbour stage's --: they are in the L2 before anything loads them)
@@ -1397,12 +1405,12 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         //      instances have just been taken over (the blocks were written tile-major by the start-iterate kernel or the pipeline) and
         //      when a sweep has to be repeated (from the copy in the mailbox): the rounds' own blocks go from the stage phases straight
         //      into the records.
-        const bool tiled = fresh;
+        const bool whole = fresh, tiled = fresh && !by_pipe;
         auto build_records = [&]() {
             if (valid && ((mask >> (t & (bx - 1))) & 1u)) {
                 double blk[MPC_EV(D::NBLK)];
                 if (tiled) ws_load_rows<D::NBLK>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, e)), blk);
-                else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KM(P.MBLK, D::NBLK, 0, e)), blk);
+                else ws_load_rows<D::NBLK>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, e)), blk);
                 double hx0 = 0.0, hx1 = 0.0;
                 if (c.k == 0) { hx0 = MPC_S(P.SC, SC_HUX0); hx1 = MPC_S(P.SC, SC_HUX1); }
                 const mpc_lds_ptr r = recs + ((t & (bx - 1)) * (N + 1) + c.k) * RC::SIZE;
@@ -1410,7 +1418,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
 #pragma unroll
                 for (int i = 0; i < D::NBLK; ++i) {
                     const bool kept = i < D::B_RUU || (i >= D::B_CN && i < D::B_CN + NX);
-                    if (tiled || !kept) r[RC::slot(i)] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
+                    if (whole || !kept) r[RC::slot(i)] = (i >= D::B_CN && i < D::B_CN + NX) ? -blk[i] : blk[i];
                 }
                 r[RC::ZERO] = 0.0;
                 r[RC::ONE] = 1.0;
@@ -1449,6 +1457,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             bounds_ok = true;
         }
         lds_barrier();
+        if (wtrace != nullptr && fresh && t_fresh == 0ull) t_fresh = wall_clock64() - t_begin;
         fresh = false;
         WG_STAMP(13);
         // (per-lane operand offsets of the sweeps: unpacked every round from the lane's four table words -- opaque to the compiler here, so
@@ -1521,6 +1530,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG_STAMP(15);
+        if (wtrace != nullptr && rounds == 1u) t_round1 = wall_clock64() - t_begin;
     }
 #undef WG_STAMP
     // the iterate goes back to the tile-major rows k_egest reads (a workgroup that found nothing to do never moved it)
@@ -1533,7 +1543,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         wtrace[blockIdx.x * 4 + 0] = t_begin;
         wtrace[blockIdx.x * 4 + 1] = wall_clock64();
         wtrace[blockIdx.x * 4 + 2] = rounds;
-        wtrace[blockIdx.x * 4 + 3] = inst_rounds;
+        wtrace[blockIdx.x * 4 + 3] = (unsigned long long)(inst_rounds & 0xFFFFu) | ((t_fresh & 0xFFFFFFull) << 16) | ((t_round1 & 0xFFFFFFull) << 40);
     }
     if (stats != nullptr && t == 0) {
         atomicMax(stats + 0, rounds);
@@ -2428,7 +2438,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2465,6 +2475,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "wg_list") k.wg_list = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "ho_inline") k.ho_inline = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
+    else if (n == "mb_pipe") k.mb_pipe = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2499,6 +2510,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "wg_list") *out = k.wg_list;
     else if (n == "ho_inline") *out = k.ho_inline;
     else if (n == "pipe_help") *out = k.pipe_help;
+    else if (n == "mb_pipe") *out = k.mb_pipe;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2512,7 +2524,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2862,6 +2874,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (option resident: k_solve_wg alone, whatever the batch size -- the stage phases of the streaming paths + the wave-per-instance MFMA Riccati)
     const bool use_wg = kn.resident != 0 && small_wg && h->ws_mailbox && !trace && !kn.stage_timing && kn.groups <= 0;
     Params P;
+    P.mbw_live = 0;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB, h->ws_mailbox);
     P.x0 = d_x0; P.p = d_p; P.x_out = d_x_out; P.status_out = d_status; P.iters_out = d_iters; P.kkt_out = d_kkt;
     const WsLayout w = ws_layout(d.N, d.nx, Bp, h->ws_mailbox);
@@ -3039,6 +3052,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int n_wtrace = 0;
     const int32_t* wg_list = nullptr;                   // (behind the pipeline: the instances its retiring tiles left, see k_solve_wg)
     const uint32_t* wg_list_n = nullptr;
+    const uint32_t* wg_mb_flag = nullptr;               // (... and per tile, bit 31: its last stage items wrote the mailbox arrays)
     int wg_grid = 0;
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
         if (kn.wg_trace && !h->async_loop && !h->in_rescue) {
@@ -3056,11 +3070,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (wg_resc(bxw)) {
             rs.on = 1;
             h->resc_in_kernel = true;
-            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
-            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
+            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
         }
-        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
-        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
+        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
     };
     // option wg_trace: every workgroup of k_solve_wg leaves its start, its end (100 MHz wall clock) and its rounds: when did the long ones start?
     auto report_wtrace = [&]() {
@@ -3080,8 +3094,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         for (size_t i = 0; i < live.size() && i < 12; ++i) {
             const int w = live[i];
             const double st = (double)(hw[4 * w] - t0) * 1e-2, en = (double)(hw[4 * w + 1] - t0) * 1e-2;
-            fprintf(stderr, "    workgroup %5d: start %6.1f us  end %6.1f us  rounds %2d  instance-rounds %2d  -> %.1f us per round\n", w, st, en, (int)hw[4 * w + 2], (int)hw[4 * w + 3],
-                    (en - st) / (double)hw[4 * w + 2]);
+            const double tf = (double)((hw[4 * w + 3] >> 16) & 0xFFFFFFull) * 1e-2, tr1 = (double)((hw[4 * w + 3] >> 40) & 0xFFFFFFull) * 1e-2;
+            fprintf(stderr, "    workgroup %5d: start %6.1f us  end %6.1f us  rounds %2d  instance-rounds %2d  -> %.1f us per round; instances taken over after %.1f us, first round done after %.1f us, later rounds %.1f us each\n",
+                    w, st, en, (int)hw[4 * w + 2], (int)(hw[4 * w + 3] & 0xFFFFu), (en - st) / (double)hw[4 * w + 2], tf, tr1, hw[4 * w + 2] > 1 ? (en - st - tr1) / (double)(hw[4 * w + 2] - 1) : 0.0);
         }
     };
     // hybrid solve (option hybrid): the pipeline runs a tile while it has many instances iterating, then k_solve_wg finishes the
@@ -3221,6 +3236,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else
 #endif
+            // tiles about to leave the pipeline (at most hand + 16 instances left; never a full tile) write the mailbox arrays in their stage items
+            P.mbw_live = (hand > 0 && kn.mb_pipe) ? std::min(63, hand + 16) : 0;
             if (pipe_help && masked) hipLaunchKernelGGL((k_pipeline<NX, 2, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else if (pipe_help) hipLaunchKernelGGL((k_pipeline<NX, 0, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
@@ -3235,6 +3252,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                     // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
                 }
+                wg_mb_flag = P.mbw_live > 0 ? ctl + PIPE_HDR : nullptr;
                 launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
             }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one

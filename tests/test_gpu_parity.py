@@ -143,6 +143,32 @@ def test_riccati_workers_that_help_with_stage_items_change_nothing(fam, B, maske
             assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+@pytest.mark.parametrize("fam,B,masked", [("zamlf_n30_nx6", 4096, True), ("usalf_n50_nx5", 3000, True), ("zamlf_n30_nx5", 2600, False)])
+def test_mailbox_rows_written_by_the_pipeline_equal_the_ones_copied_at_the_hand_over(fam, B, masked):
+    """Option mb_pipe (default 1): the stage items of a tile that is about to leave the pipeline write iterate, multipliers and stage block into the
+    instance-major mailbox arrays as well (Ctx::mbw), and k_solve_wg takes those instances over without copying them out of the tile-major rows
+    (bit 31 of the tile's arrival counter tells it).  With mb_pipe = 0 every workgroup copies its instances itself.  Same values either way: rows,
+    statuses and iteration counts must be the same bits, run after run -- stale mailbox rows of an earlier solve (a different batch is solved in
+    between) or a tile flagged without its last items having written them would show here."""
+    cfg, kw = FAMILIES[fam]
+    x0, p = synthetic_batch(cfg, B, **kw)
+    x0b, pb = synthetic_batch(cfg, B, start=50000, **kw)
+    s = make_solver(cfg)
+    if masked:
+        set_cfg_bounds(s, cfg)
+    assert s.get_option("mb_pipe") == 1
+    s.set_option("mb_pipe", "0")
+    ref = s.solve(x0, p)
+    assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"] and np.all(ref.status == 1)
+    s.set_option("mb_pipe", "1")
+    for rep in range(3):
+        other = s.solve(x0b, pb)                                           # (leaves ITS rows in the mailbox)
+        assert np.all(other.status == 1)
+        alt = s.solve(x0, p)
+        assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+        assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status), rep
+
+
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5"])
 def test_compiled_in_bound_structure_against_the_run_time_lookup(fam):
     """Variant 2 of the kernels (option bound_mask, the default whenever the handle's bounds have the reference's structure: only steering
