@@ -530,6 +530,7 @@ __global__ void __launch_bounds__(MAXT, (INIT && MAXT <= 256) ? 2 : 1) k_stage(c
 // mpc_stage_math.h (shared with the CPU emulation harness).  Inertia correction: if some lane finds an indefinite
 // 2x2 block the wave repeats the sweep with delta_w added for those lanes (flag through LDS keeps the loader in step).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int32_t HO_IN_MB = 0x40000000;  // flag in an entry of the hand-over lists
 constexpr uint32_t HO_BUCKETS = 4;  // hand-over lists of the hybrid solve, by KKT error: >= 1e-3 | >= 1e-4 | >= 1e-5 | below (rank correlation with the iterations left: 0.9)
 constexpr int RIC_DEPTH = 4;        // backward ring (stage blocks, 17 KiB each at nx = 6)
 constexpr int RIC_DEPTH_F = 10;     // forward ring (gains + A + defect rows, 13 KiB each): stages are short, so look further ahead --
@@ -551,11 +552,13 @@ __device__ __forceinline__ void wait_dma_behind(int stages_behind) {
 // the default) or by a launch of its own between the two kernels (5.5 us).  (Appended by the retiring Riccati worker inside riccati_tile
 // the few instructions cost its sweeps 13 us per solve; as an out-of-line call they put the whole kernel on scratch.)
 // (one wavefront, lane = instance b of a tile)
-__device__ __forceinline__ void ho_lists(const PRef& P, const uint32_t bb, int32_t* ho_list, uint32_t* ho_count) {
+__device__ __forceinline__ void ho_lists(const PRef& P, const uint32_t bb, int32_t* ho_list, uint32_t* ho_count, const uint32_t* tile_word) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int lane = threadIdx.x & 63;
     const bool active = (int)bb < P.B && (int32_t)MPC_U(P.ISC, (uint32_t)IS_STATUS) == ST_RUNNING;
     if (__ballot(active ? 1 : 0) == 0ull) return;
+    // (bit 30 of an entry: the instance's rows are in the mailbox arrays already -- bit 31 of its tile's arrival counter, see k_pipeline)
+    const int32_t in_mb = (tile_word != nullptr && (__hip_atomic_load(tile_word + (bb >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 31)) ? HO_IN_MB : 0;
     const double e0 = active ? (double)MPC_U(P.SC, (uint32_t)SC_E0) : 0.0;
     const int bucket = e0 >= 1e-3 ? 0 : e0 >= 1e-4 ? 1 : e0 >= 1e-5 ? 2 : 3;
     for (int q = 0; q < (int)HO_BUCKETS; ++q) {
@@ -564,14 +567,14 @@ __device__ __forceinline__ void ho_lists(const PRef& P, const uint32_t bb, int32
         uint32_t base = 0u;
         if (lane == 0) base = __hip_atomic_fetch_add(ho_count + q, (uint32_t)__popcll(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (active && bucket == q) ho_list[(uint32_t)q * (uint32_t)P.Bp + base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = (int32_t)bb;
+        if (active && bucket == q) ho_list[(uint32_t)q * (uint32_t)P.Bp + base + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull))] = (int32_t)bb | in_mb;
     }
 #endif
 }
-__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count) {
+__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count, const uint32_t* tile_word) {
     const PRef P(Pk);
     if (skip_if != nullptr && *skip_if != 0u) return;
-    ho_lists(P, blockIdx.x * 64u + threadIdx.x, ho_list, ho_count);
+    ho_lists(P, blockIdx.x * 64u + threadIdx.x, ho_list, ho_count, tile_word);
 }
 
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
@@ -947,7 +950,9 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                     if (t == 0) {
                         // (bit 31 of the tile's arrival counter, for k_solve_wg: the items of its last round wrote the mailbox arrays -- same predicate as stage_block's)
                         if (round > 0u && P.mbw_live > 0 && __popcll(__hip_atomic_load(P.tile_mask + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= P.mbw_live)
-                            __hip_atomic_fetch_or(stage_done + tile, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        {   __hip_atomic_fetch_or(stage_done + tile, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (performed before this worker counts its tile as finished: the stage workers read it on their way out)
+                        }
                         atomicMax(A.ctl + PIPE_ABORT + 1, round);
                         pipe_add(X + 48, 1u);
                     }
@@ -1093,7 +1098,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
             if (t == 0) j = pipe_add(X + 56, 1u);
             j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
             if (j >= n_tiles_x) break;
-            ho_lists(P, (j * n_xcd + xcd) * 64u + (uint32_t)t, A.ho_list, A.ctl + PIPE_HO);
+            ho_lists(P, (j * n_xcd + xcd) * 64u + (uint32_t)t, A.ho_list, A.ctl + PIPE_HO, stage_done);
         }
     }
     if (t == 0) {
@@ -1234,7 +1239,7 @@ struct WgLds {
 };
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
-                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n, const uint32_t* mb_flag) {
+                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
     PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1257,6 +1262,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     // Workgroup i takes V[i]; the n - G entries beyond the G workgroups go, shortest last, to the workgroups from G - 1 downwards -- the
     // instances with the most iterations in front of them have a wavefront to themselves (a round with one live instance takes 25 us, with two 34).
     int ib0 = (int)b0 < P.B ? (int)b0 : -1, ib1 = (bx > 1 && (int)b0 + 1 < P.B) ? (int)b0 + 1 : -1;
+    uint32_t in_mb = 0u;
     if (list != nullptr) {
         uint32_t cnt[HO_BUCKETS], n = 0u;
 #pragma unroll
@@ -1271,6 +1277,10 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         ib0 = entry(blockIdx.x);
         ib1 = bx > 1 ? entry(2u * G - 1u - blockIdx.x) : -1;            // (V[G + m] belongs to workgroup G - 1 - m)
         if (ib0 < 0) return;
+        // (bit 30 of an entry: the pipeline's last stage items of the instance's tile wrote the mailbox arrays -- nothing to copy at the takeover)
+        in_mb = ((ib0 & HO_IN_MB) ? 1u : 0u) | ((ib1 >= 0 && (ib1 & HO_IN_MB)) ? 2u : 0u);
+        ib0 &= ~HO_IN_MB;
+        if (ib1 >= 0) ib1 &= ~HO_IN_MB;
     }
     struct { int b, k, mb, bl; } c;              // (the workspace accessors are written in terms of c.b / c.k; MPC_KI: c.mb / c.bl)
     c.k = t / bx;
@@ -1304,7 +1314,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         //      left the mask in sh_mask (an instance the sweeps gave up on is inactive there: phase_load_scalars reads its status)
         if (rounds == 0u && t < 64) {
             const int bb = t ? ib1 : ib0;
-            const bool run = t < bx && bb >= 0 && bb < P.B && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb >= 0 ? bb : 0) == ST_RUNNING;
+            // (the hand-over lists hold instances that were iterating when their tile left the pipeline: no look at the status row)
+            const bool run = t < bx && bb >= 0 && bb < P.B && (list != nullptr || (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb >= 0 ? bb : 0) == ST_RUNNING);
             const unsigned long long mk = __ballot(run ? 1 : 0);
             if (t == 0) sh_mask = (uint32_t)mk;
         }
@@ -1376,8 +1387,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         // ---- taking the instances over: the iterate, its multipliers and the reference move from the tile-major arrays (where the
         //      pipeline / the start-iterate kernel left them) into the instance-major mailbox arrays the rounds below work on -- one
         //      wavefront reads all stages of its one or two instances, and only there are the pieces of a thread contiguous
-        // (not for the instances of a tile whose last stage items in the pipeline wrote the mailbox arrays themselves: mb_flag, bit 31 of the tile's word)
-        const bool by_pipe = !RESC && mb_flag != nullptr && valid && (mb_flag[(uint32_t)c.b >> 6] >> 31) != 0u;
+        // (not for the instances of a tile whose last stage items in the pipeline wrote the mailbox arrays themselves: in_mb, from the list entry)
+        const bool by_pipe = !RESC && valid && ((in_mb >> c.bl) & 1u) != 0u;
         if (fresh && valid && !by_pipe) {
             auto move = [&](auto cnt, auto from, auto to) {
                 constexpr int CNT = decltype(cnt)::value;
@@ -3052,7 +3063,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     int n_wtrace = 0;
     const int32_t* wg_list = nullptr;                   // (behind the pipeline: the instances its retiring tiles left, see k_solve_wg)
     const uint32_t* wg_list_n = nullptr;
-    const uint32_t* wg_mb_flag = nullptr;               // (... and per tile, bit 31: its last stage items wrote the mailbox arrays)
     int wg_grid = 0;
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
         if (kn.wg_trace && !h->async_loop && !h->in_rescue) {
@@ -3070,11 +3080,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (wg_resc(bxw)) {
             rs.on = 1;
             h->resc_in_kernel = true;
-            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
-            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
+            if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+            else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
         }
-        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
-        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n, wg_mb_flag);
+        else if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
+        else hipLaunchKernelGGL((k_solve_wg<NX, false>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
     };
     // option wg_trace: every workgroup of k_solve_wg leaves its start, its end (100 MHz wall clock) and its rounds: when did the long ones start?
     auto report_wtrace = [&]() {
@@ -3115,7 +3125,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // the ones closest to convergence and start when the first wavefronts free up, while the tiles leave the pipeline a round earlier --
         // its rounds cost an instance 67 us, a straggler round 25 us (tools/hand_sweep.py: 3 - 5 % per batch on four instance sets at B = 4096,
         // B = 3000 / 8192 and N = 50 likewise; above ~50 of 64 the pipeline no longer carries the bulk)
-        hand = (base >= 64 || !kn.wg_list) ? base : std::max(base, std::min(50, 3 * base / 2));
+        hand = (base >= 64 || !kn.wg_list) ? base : std::max(base, std::min(50, base < 32 ? 7 * base / 4 : 3 * base / 2));
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
@@ -3247,12 +3257,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 prof.next(5, stream);
                 if (ho_list) {
                     // (the counters: words of the control block, zero at the start of every solve)
-                    if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO);
+                    if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO, (const uint32_t*)(ctl + PIPE_HDR));
                     wg_list = ho_list; wg_list_n = ctl + PIPE_HO;
                     // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
                 }
-                wg_mb_flag = P.mbw_live > 0 ? ctl + PIPE_HDR : nullptr;
                 launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
             }
             // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
