@@ -482,6 +482,24 @@ MPC_HD double push_in(double v, double lo, double hi) {
     return v;
 }
 
+// push_in(v, lo, hi) == fmin(fmax(v, L), H) with these limits (an absent side: -inf / +inf) -- for the callers that clip a CHAIN of values against
+// bounds known beforehand: the limits come out of the chain
+MPC_HD void push_limits(double lo, double hi, double& L, double& H) {
+    const bool hl = has_lo(lo), hu = has_hi(hi);
+    L = -__builtin_inf();
+    H = __builtin_inf();
+    if (hl && hu) {
+        const double pl = fmin(KAPPA_1 * fmax(1.0, fabs(lo)), KAPPA_2 * (hi - lo));
+        const double pu = fmin(KAPPA_1 * fmax(1.0, fabs(hi)), KAPPA_2 * (hi - lo));
+        L = lo + pl;
+        H = hi - pu;
+    } else if (hl) {
+        L = lo + KAPPA_1 * fmax(1.0, fabs(lo));
+    } else if (hu) {
+        H = hi - KAPPA_1 * fmax(1.0, fabs(hi));
+    }
+}
+
 // IPOPT's Compare_le (IpUtils.cpp): lhs <= rhs up to 10 machine epsilons of a reference magnitude
 MPC_HD bool cmp_le(double lhs, double rhs, double base) { return lhs - rhs <= EPS10 * fabs(base); }
 

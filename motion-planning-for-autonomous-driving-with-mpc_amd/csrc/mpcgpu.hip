@@ -53,6 +53,25 @@ constexpr int STAGE_MAX_THREADS = 512;
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// n values memory -> LDS by a group of NT threads (thread t of it): a thread's loads of one trip are ALL requested before its first LDS write.  (The
+// plain loop `for (q = t; q < n; q += NT) lds[q] = mem[q]` compiles to load, s_waitcnt vmcnt(0), ds_write per trip -- one memory round trip per
+// trip, eight in a row at the head of k_start.)
+template <int MAXJ, class Load, class Store>
+__device__ __forceinline__ void batched_fill(const int n, const int t, const int NT, Load ld, Store st) {
+    for (int q0 = 0; q0 < n; q0 += MAXJ * NT) {
+        double v[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) { const int q = q0 + j * NT + t; v[j] = (q < n) ? (double)ld(q) : 0.0; }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) { const int q = q0 + j * NT + t; if (q < n) st(q, v[j]); }
+    }
+}
+// the bounds table [LB | UB] of a batch, nb doubles each
+template <int MAXJ>
+__device__ __forceinline__ void fill_bounds(const PRef& P, double* tab, const int nb, const int t, const int NT) {
+    batched_fill<2 * MAXJ>(2 * nb, t, NT, [&](int q) { return q < nb ? (double)MPC_GP(P.LB, q) : (double)MPC_GP(P.UB, q - nb); }, [&](int q, double v) { tab[q] = v; });
+}
+
 // workgroup-wide OR of a predicate with one such barrier (slots double-buffered by call parity)
 __device__ __forceinline__ int block_or(int pred, int (*slots)[8], int& parity) {
     const int any = __any(pred) ? 1 : 0;
@@ -186,7 +205,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     // (a persistent stage worker of the pipeline copies the table -- the same for every item of the batch -- once: nothing else of
     //  its work items touches that part of the LDS)
     if (!bounds_in_lds)
-        for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
+        fill_bounds<2>(P, lds_b, nb, t, (int)blockDim.x);
     c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
     c.bnd_ub = nb;
     if (INIT) lds_barrier();
@@ -415,7 +434,7 @@ __device__ __forceinline__ void stage_pair_role(const PRef& P, const int n_mult,
     double* lds_x = lds_b + 2 * nb;
     double* lds_k = lds_x + 2 * NX * T;
     if (!bounds_in_lds)
-        for (int q = t; q < nb; q += (int)blockDim.x) { lds_b[q] = MPC_GP(P.LB, q); lds_b[nb + q] = MPC_GP(P.UB, q); }
+        fill_bounds<2>(P, lds_b, nb, t, (int)blockDim.x);
     c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
     c.bnd_ub = nb;
     phase_load_scalars<NX>(P, c);
@@ -1457,14 +1476,17 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 q[WgScl::FROW] = (double)(int32_t)MPC_S(P.ISC, IS_FROW); q[WgScl::HAVETH0] = (double)(int32_t)MPC_S(P.ISC, IS_HAVETH0);
             }
             // ... and the filter: lane l fetches row l of each instance
-            for (int g = 0; g < bx; ++g) {
-                const int bg = g ? ib1 : ib0;
-                if (bg >= 0 && t < 2 * FILTER_MAX) lds_scl[g * WgScl::SIZE + WgScl::FILT + t] = ws_ref3(P, P.FILT, 0u, (uint32_t)bg, mpc_prow((uint32_t)t));
+            {
+                const bool f0 = ib0 >= 0 && t < 2 * FILTER_MAX, f1 = bx > 1 && ib1 >= 0 && t < 2 * FILTER_MAX;
+                const double v0 = f0 ? (double)ws_ref3(P, P.FILT, 0u, (uint32_t)ib0, mpc_prow((uint32_t)t)) : 0.0;
+                const double v1 = f1 ? (double)ws_ref3(P, P.FILT, 0u, (uint32_t)ib1, mpc_prow((uint32_t)t)) : 0.0;
+                if (f0) lds_scl[WgScl::FILT + t] = v0;
+                if (f1) lds_scl[WgScl::SIZE + WgScl::FILT + t] = v1;
             }
         }
         if (!bounds_ok) {
             const int nb = (N + 1) * D::NZ;
-            for (int q = t; q < nb; q += 64) { lds_bnd[q] = MPC_GP(P.LB, q); lds_bnd[nb + q] = MPC_GP(P.UB, q); }
+            fill_bounds<8>(P, lds_bnd, nb, t, 64);
             bounds_ok = true;
         }
         lds_barrier();
@@ -1574,7 +1596,7 @@ __global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
     extern __shared__ __attribute__((aligned(16))) double bnd_tab[];            // [LB | UB], (N+1)*NZ doubles each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = (P.N + 1) * (NX + 2);
-    for (int q = threadIdx.x; q < nb; q += 128) { bnd_tab[q] = MPC_GP(P.LB, q); bnd_tab[nb + q] = MPC_GP(P.UB, q); }
+    fill_bounds<4>(P, bnd_tab, nb, (int)threadIdx.x, 128);
     __syncthreads();
     const mpc_lds_cptr bnd = (mpc_lds_cptr)(lds_ptr_t)bnd_tab;
     const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + lane;
@@ -1597,6 +1619,8 @@ __global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
 // parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
 // Src: where the raw guess z(k, i) (i < 2: input, else state i - 2 of stage k) and the reference of stage 0 come from -- the workspace rows, or
 // (k_start) the block's rows of the caller's buffers as they lie in LDS: then nothing here waits for the ingest's stores
+// LDS doubles of prestart_par_block: bounds table and its pushed limits [4][S][NZ], rollout / defects / increments [(3 NX + 2)][S][bx], 3 per instance
+__host__ __device__ constexpr size_t prestart_doubles(int NX, int S, int bx) { return (size_t)4 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx; }
 template <int NX, class Src>
 __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm, const Src src) {
     constexpr bool WS = std::is_same<Src, PrestartFromWs>::value;
@@ -1610,12 +1634,14 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     double* DG = DR + NX * SB;              // [NX][S][bx]  guess: dynamics defect of state i at stage k
     double* IN = DG + NX * SB;              // [2][S][bx]   increments f_i of the two states being scanned
     double* A0 = IN + 2 * SB;               // [3][bx]      a0lb, a0ub, defect of the guess
+    double* PLt = A0 + 3 * bx;              // [S][NZ]      the bounds pushed inwards as push_in does it: what the scans clip against
+    double* PHt = PLt + nb;
     struct { int b, k; } c;
     c.k = t / bx;
     c.b = (int)b0 + bl;
     const bool valid = c.k <= N && c.b < P.B;
     const uint32_t bb = (uint32_t)c.b;
-    for (int q = t; q < nb; q += (int)blockDim.x) { LBt[q] = MPC_GP(P.LB, q); UBt[q] = MPC_GP(P.UB, q); }
+    fill_bounds<2>(P, LBt, nb, t, (int)blockDim.x);                      // (UBt = LBt + nb)
     double a0lb = 0.0, a0ub = 0.0;
     int frow = 1;
     if (valid && c.k == 0) {
@@ -1625,6 +1651,7 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
         A0[bx + bl] = a0ub;
     }
     __syncthreads();
+    for (int q = t; q < nb; q += (int)blockDim.x) { double L, H; push_limits(LBt[q], UBt[q], L, H); PLt[q] = L; PHt[q] = H; }    // (read behind the next barrier)
     const double dt = P.dt;
 #define PP_AT(arr, i, k) (arr)[((i) * S + (k)) * bx + bl]
     if (valid) {
@@ -1664,12 +1691,26 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
             const int si = (c.k == 0) ? s0 : s1;
             const double* in = IN + c.k * SB;
             double x = PP_AT(XR, si, 0);
-            for (int k = 0; k < N; ++k) {
-                const double raw = in[k * bx + bl] * dt + x;
-                const double rn = push_in(raw, LBt[(k + 1) * NZ + 2 + si], UBt[(k + 1) * NZ + 2 + si]);
-                PP_AT(DR, si, k + 1) = fabs(rn - raw);
-                PP_AT(XR, si, k + 1) = rn;
-                x = rn;
+            // (the chain x -> fma -> clip is all that is sequential: increments and bounds of eight stages are fetched ahead of it -- left to itself
+            //  the loop waits for three LDS reads in every step)
+            for (int k0 = 0; k0 < N; k0 += 8) {
+                double inc[8], lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (k0 + j < N) ? k0 + j : N - 1;
+                    inc[j] = in[k * bx + bl]; lo[j] = PLt[(k + 1) * NZ + 2 + si]; hi[j] = PHt[(k + 1) * NZ + 2 + si];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j;
+                    if (k < N) {
+                        const double raw = inc[j] * dt + x;
+                        const double rn = fmin(fmax(raw, lo[j]), hi[j]);              // (= push_in(raw, lb, ub): the limits are push_limits')
+                        PP_AT(DR, si, k + 1) = fabs(rn - raw);
+                        PP_AT(XR, si, k + 1) = rn;
+                        x = rn;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1698,9 +1739,21 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     double th = 0.0;
     if (valid && c.k < 2) {                                   // stage-thread 0 sums the rollout's defects, stage-thread 1 the guess's
         const double* D = (c.k == 0) ? DR : DG;
-        for (int k = 0; k <= N; ++k) {
+        for (int k0 = 0; k0 <= N; k0 += 4) {          // (same order of additions; four stages' reads in flight)
+            double v[4][NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) th += PP_AT(D, i, k);
+            for (int j = 0; j < 4; ++j) {
+                const int k = (k0 + j <= N) ? k0 + j : N;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) v[j][i] = PP_AT(D, i, k);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k0 + j <= N) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) th += v[j][i];
+                }
+            }
         }
         if (c.k == 1) A0[2 * bx + bl] = th;
     }
@@ -1737,14 +1790,27 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
         const int N = P.N, nw = 2 * N + NX * (N + 1), bx = P.bx, t = threadIdx.x;
         // LDS: [the safeguard's tables and scan rows (prestart_par_block) | the block's rows of x0 | of the X_ref part of p]: the safeguard reads the
         // guess and the reference from the last two, so it does not wait for the stores below
-        const size_t pre_doubles = (size_t)2 * (N + 1) * NZ + (size_t)(3 * NX + 2) * (N + 1) * bx + (size_t)3 * bx;
+        const size_t pre_doubles = prestart_doubles(NX, N + 1, bx);
         double* rx = lds + ((pre_doubles + 1) & ~(size_t)1);     // [bx][nw]
         double* rp = rx + bx * nw;                               // [bx][nw - 2N]   (the U_ref part of p is not used by the NLP, optimizer.py:507-511)
         const int nrow = ((int)b0 + bx <= P.B) ? bx : (P.B > (int)b0 ? P.B - (int)b0 : 0);
-        for (int q = t; q < nrow * nw; q += (int)blockDim.x) rx[q] = MPC_GP(P.x0, (size_t)b0 * nw + q);
         const int npx = nw - 2 * N;
-        for (int q = t; q < nrow * npx; q += (int)blockDim.x) rp[q] = MPC_GP(P.p, ((size_t)b0 + q / npx) * nw + 2 * N + q % npx);
+        // (every load of a thread requested before its first LDS write: batched_fill; the rows of p one per trip element -- no division)
+        batched_fill<8>(nrow * nw, t, (int)blockDim.x, [&](int q) { return MPC_GP(P.x0, (size_t)b0 * nw + q); }, [&](int q, double v) { rx[q] = v; });
+        for (int r0 = 0; r0 < nrow; r0 += 8) {
+            for (int c0 = 0; c0 < npx; c0 += (int)blockDim.x) {
+                const int col = c0 + t;
+                double v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = (r0 + r < nrow && col < npx) ? (double)MPC_GP(P.p, ((size_t)b0 + r0 + r) * nw + 2 * N + col) : 0.0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (r0 + r < nrow && col < npx) rp[(r0 + r) * npx + col] = v[r];
+            }
+        }
         __syncthreads();
+#if MPC_KSTART_STOP == 3
+        return;
+#endif
         struct { int b, k; } c;
         c.k = t / bx;
         const int bl = t & (bx - 1);
@@ -1765,6 +1831,9 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
             __device__ __forceinline__ double z(int bl, int k, int i) const { return i < 2 ? (k < N ? rx[bl * nw + 2 * k + i] : 0.0) : rx[bl * nw + 2 * N + NX * k + (i - 2)]; }
             __device__ __forceinline__ double ref0(int bl, int i) const { return rp[bl * npx + i]; }
         } src{rx, rp, nw, npx, N};
+#if MPC_KSTART_STOP == 4
+        return;
+#endif
         prestart_par_block<NX, FromLds>(P, b0, lds, src);
     }
 #if MPC_KSTART_STOP == 1
@@ -2991,7 +3060,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const int n_w = 2 * d.N + NX * (d.N + 1);
         // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
         // stage-threads the scans need (otherwise the two-chain kernel)
-        const size_t lds_pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx) * sizeof(double);
+        const size_t lds_pre = prestart_doubles(NX, S, bx) * sizeof(double);
         const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
         // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
         const bool fused = lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
@@ -3051,7 +3120,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // LDS of a k_solve_wg workgroup (ONE wavefront, bxw = 1 or 2 instances): records + bounds table; a restart of the second chance runs the
     // start-point safeguard and the start iterate in the same memory
     auto wg_lds = [&](int bxw) {
-        const size_t pre = ((size_t)2 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bxw + (size_t)3 * bxw) * sizeof(double);
+        const size_t pre = prestart_doubles(NX, S, bxw) * sizeof(double);
         const size_t init = ((size_t)10 * bxw + (size_t)2 * S * (NX + 2) + (size_t)2 * NX * 64) * sizeof(double);
         return std::max(WgLds<NX>::doubles(S, bxw) * sizeof(double), bxw == 1 ? std::max(pre, init) : (size_t)0);
     };
