@@ -957,9 +957,9 @@ MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
         double raw = 0.0, lb = -INFINITY, ub = INFINITY;
         if (!(isu && k == N)) {
             raw = (!isu && roll) ? (double)MPC_K(P.ROLL, NX, 0, (i - 2)) : (double)MPC_K(P.Z, NZ, 0, i);    // raw x0 (ingested)
-            lb = MPC_GP(P.LB, k * NZ + i);
-            ub = MPC_GP(P.UB, k * NZ + i);
-            if (k == 0 && i == 1) { lb = c.a0lb; ub = c.a0ub; }
+            MPC_BOUNDS(k, i, lbt, ubt);               // (device: the workgroup's LDS table, like every other phase)
+            lb = lbt;
+            ub = ubt;
         }
         if (k < N) {
             // |grad f| at the user's start point (objective scaling, IPOPT section 3.8)
@@ -977,9 +977,15 @@ MPC_HD void phase_init_point(const PRef& P, Ctx<NX>& c, Red0& red) {
 #pragma unroll
         for (int i = 0; i < (int)MPC_EV(NZ); ++i) zero[i] = 0.0;
         ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.Z, NZ, 0, e)), c.z);
-        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.ZL, NZ, 0, e)), c.zl);
-        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.ZU, NZ, 0, e)), c.zu);
-        ws_store_rows<NZ>(MPC_ROWS(MPC_K(P.DZ, NZ, 0, e)), zero);
+        // (multiplier pairs of variables that have a bound nowhere are never loaded -- phase_preload's condition -- and not written here either;
+        //  the step DZ is written by the first Riccati sweep, whole, before anything reads it: no zeros for it)
+#pragma unroll
+        for (int i = 0; i < NZ; i += 2) {
+            const bool a0 = (i == 0) && (k == 0);
+            const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
+            if (((P.lo_mask >> i) & both) || a0) { if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_K(P.ZL, NZ, 0, i) = c.zl[i]; }
+            if (((P.hi_mask >> i) & both) || a0) { if (i + 1 < NZ) MPC_ST2(MPC_K(P.ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else MPC_K(P.ZU, NZ, 0, i) = c.zu[i]; }
+        }
         ws_store_rows<NX>(MPC_ROWS(MPC_K(P.LAM, NX, 0, e)), zero);
     }
 #pragma unroll

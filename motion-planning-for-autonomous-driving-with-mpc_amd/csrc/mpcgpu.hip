@@ -1783,6 +1783,8 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
     uint32_t blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
+#define KS_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    KS_STAMP(11);
     {
         // ---- the caller's rows of this block (x0, the X_ref part of p: row-major [B][n_w]) -> LDS -> the tile-major Z / REF rows of the
         //      workspace: what k_ingest does for a whole batch, here for the block's own bx instances (consecutive rows: coalesced reads)
@@ -1791,7 +1793,10 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
         // LDS: [the safeguard's tables and scan rows (prestart_par_block) | the block's rows of x0 | of the X_ref part of p]: the safeguard reads the
         // guess and the reference from the last two, so it does not wait for the stores below
         const size_t pre_doubles = prestart_doubles(NX, N + 1, bx);
-        double* rx = lds + ((pre_doubles + 1) & ~(size_t)1);     // [bx][nw]
+        // (the safeguard's region starts where stage_block keeps its bounds table -- behind the reduction scratch -- and begins with that table: the
+        //  start iterate finds it in place)
+        double* const pre = lds + (blockDim.x >> 6) * 10 * bx;
+        double* rx = pre + ((pre_doubles + 1) & ~(size_t)1);     // [bx][nw]
         double* rp = rx + bx * nw;                               // [bx][nw - 2N]   (the U_ref part of p is not used by the NLP, optimizer.py:507-511)
         const int nrow = ((int)b0 + bx <= P.B) ? bx : (P.B > (int)b0 ? P.B - (int)b0 : 0);
         const int npx = nw - 2 * N;
@@ -1808,6 +1813,7 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
             }
         }
         __syncthreads();
+        KS_STAMP(12);
 #if MPC_KSTART_STOP == 3
         return;
 #endif
@@ -1831,11 +1837,13 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
             __device__ __forceinline__ double z(int bl, int k, int i) const { return i < 2 ? (k < N ? rx[bl * nw + 2 * k + i] : 0.0) : rx[bl * nw + 2 * N + NX * k + (i - 2)]; }
             __device__ __forceinline__ double ref0(int bl, int i) const { return rp[bl * npx + i]; }
         } src{rx, rp, nw, npx, N};
+        KS_STAMP(13);
 #if MPC_KSTART_STOP == 4
         return;
 #endif
-        prestart_par_block<NX, FromLds>(P, b0, lds, src);
+        prestart_par_block<NX, FromLds>(P, b0, pre, src);
     }
+    KS_STAMP(14);
 #if MPC_KSTART_STOP == 1
     return;
 #endif
@@ -1843,10 +1851,12 @@ __global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, 
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KS_STAMP(15);
+#undef KS_STAMP
 #if MPC_KSTART_STOP == 2
     return;
 #endif
-    stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots);
+    stage_block<NX, true, 256>(P, n_mult, n_z, stash_rows, b0, ~0ull, lds, or_slots, true, nullptr, true);
 }
 
 
@@ -2518,7 +2528,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1, start_timing = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2556,6 +2566,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "ho_inline") k.ho_inline = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
     else if (n == "mb_pipe") k.mb_pipe = value == nullptr ? 1 : (v[0] != '0');
+    else if (n == "start_timing") k.start_timing = on != 0;
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2591,6 +2602,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "ho_inline") *out = k.ho_inline;
     else if (n == "pipe_help") *out = k.pipe_help;
     else if (n == "mb_pipe") *out = k.mb_pipe;
+    else if (n == "start_timing") *out = k.start_timing;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2604,7 +2616,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe", "start_timing"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -3063,11 +3075,35 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const size_t lds_pre = prestart_doubles(NX, S, bx) * sizeof(double);
         const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
         // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
-        const bool fused = lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
+        const size_t lds_red = (size_t)(threads / 64) * 10 * bx * sizeof(double);            // (stage_block's reduction scratch, in front of the safeguard's region)
+        const bool fused = lds_red + lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
         if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
         if (fused) {
             // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
-            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_pre + 16 + lds_in, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            DevTmp t_sdbg;
+            if (kn.start_timing && !h->async_loop && G == 1 && hipMalloc(&t_sdbg.p, sizeof(unsigned long long) * 16 * (size_t)q.nblk) == hipSuccess) {
+                (void)hipMemsetAsync(t_sdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)q.nblk, q.st);
+                Pg.DBG = t_sdbg.as<unsigned long long>();
+            }
+            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_red + lds_pre + 16 + lds_in, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
+            if (Pg.DBG) {          // (option start_timing: shader-clock stamps of every workgroup of k_start; synchronises)
+                std::vector<unsigned long long> hd((size_t)16 * q.nblk);
+                if (hipStreamSynchronize(q.st) == hipSuccess && hipMemcpy(hd.data(), Pg.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                    const int order[10] = {11, 12, 13, 14, 15, 0, 7, 8, 9, 10};
+                    static const char* names[9] = {"rows->LDS", "Z/REF stores", "safeguard", "fence", "enter", "init point+exchange", "eval+assemble", "reduce", "finish"};
+                    double acc[9] = {0};
+                    unsigned long long t0 = ~0ull, t1 = 0ull;
+                    for (int bq = 0; bq < q.nblk; ++bq) {
+                        const unsigned long long* r = hd.data() + (size_t)bq * 16;
+                        for (int j = 0; j < 9; ++j) acc[j] += (double)(long long)(r[order[j + 1]] - r[order[j]]);
+                        t0 = std::min(t0, r[11]); t1 = std::max(t1, r[10]);
+                    }
+                    fprintf(stderr, "[mpcgpu k_start timing, shader-clock ticks, mean over %d workgroups]", q.nblk);
+                    for (int j = 0; j < 9; ++j) fprintf(stderr, " %s=%.0f", names[j], acc[j] / q.nblk);
+                    fprintf(stderr, "; first start to last end %.0f\n", (double)(t1 - t0));
+                }
+                Pg.DBG = nullptr;
+            }
         } else {
             if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
                 hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
