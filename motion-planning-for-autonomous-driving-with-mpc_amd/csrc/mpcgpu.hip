@@ -1619,8 +1619,8 @@ __global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
 // parked in LDS.  Same arithmetic per element and the same left-to-right order of the defect sums as prestart_chain.
 // Src: where the raw guess z(k, i) (i < 2: input, else state i - 2 of stage k) and the reference of stage 0 come from -- the workspace rows, or
 // (k_start) the block's rows of the caller's buffers as they lie in LDS: then nothing here waits for the ingest's stores
-// LDS doubles of prestart_par_block: bounds table and its pushed limits [4][S][NZ], rollout / defects / increments [(3 NX + 2)][S][bx], 3 per instance
-__host__ __device__ constexpr size_t prestart_doubles(int NX, int S, int bx) { return (size_t)4 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)3 * bx; }
+// LDS doubles of prestart_par_block: bounds table and its pushed limits [4][S][NZ], rollout / defects / increments [(3 NX + 2)][S][bx], 4 per instance
+__host__ __device__ constexpr size_t prestart_doubles(int NX, int S, int bx) { return (size_t)4 * S * (NX + 2) + (size_t)(3 * NX + 2) * S * bx + (size_t)4 * bx; }
 template <int NX, class Src>
 __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t b0, double* sm, const Src src) {
     constexpr bool WS = std::is_same<Src, PrestartFromWs>::value;
@@ -1633,15 +1633,26 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     double* DR = XR + NX * SB;              // [NX][S][bx]  rollout: clipping defect of state i at stage k
     double* DG = DR + NX * SB;              // [NX][S][bx]  guess: dynamics defect of state i at stage k
     double* IN = DG + NX * SB;              // [2][S][bx]   increments f_i of the two states being scanned
-    double* A0 = IN + 2 * SB;               // [3][bx]      a0lb, a0ub, defect of the guess
-    double* PLt = A0 + 3 * bx;              // [S][NZ]      the bounds pushed inwards as push_in does it: what the scans clip against
+    double* A0 = IN + 2 * SB;               // [4][bx]      a0lb, a0ub, defect of the guess, 'a rolled-out state was clipped'
+    double* PLt = A0 + 4 * bx;              // [S][NZ]      the bounds pushed inwards as push_in does it: what the scans clip against
     double* PHt = PLt + nb;
     struct { int b, k; } c;
     c.k = t / bx;
     c.b = (int)b0 + bl;
     const bool valid = c.k <= N && c.b < P.B;
     const uint32_t bb = (uint32_t)c.b;
-    fill_bounds<2>(P, LBt, nb, t, (int)blockDim.x);                      // (UBt = LBt + nb)
+#define PS_STAMP(i) do { if (P.DBG && threadIdx.x == 0) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // the bounds table and, next to it, the bounds pushed inwards the way push_in does it (push_limits) -- every clip below is then fmax / fmin
+    for (int q0 = 0; q0 < nb; q0 += 2 * (int)blockDim.x) {
+        double lo[2], hi[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int q = q0 + j * (int)blockDim.x + t; lo[j] = q < nb ? (double)MPC_GP(P.LB, q) : 0.0; hi[j] = q < nb ? (double)MPC_GP(P.UB, q) : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + j * (int)blockDim.x + t;
+            if (q < nb) { double L, H; push_limits(lo[j], hi[j], L, H); LBt[q] = lo[j]; UBt[q] = hi[j]; PLt[q] = L; PHt[q] = H; }
+        }
+    }
     double a0lb = 0.0, a0ub = 0.0;
     int frow = 1;
     if (valid && c.k == 0) {
@@ -1651,19 +1662,19 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
         A0[bx + bl] = a0ub;
     }
     __syncthreads();
-    for (int q = t; q < nb; q += (int)blockDim.x) { double L, H; push_limits(LBt[q], UBt[q], L, H); PLt[q] = L; PHt[q] = H; }    // (read behind the next barrier)
+    PS_STAMP(1);
     const double dt = P.dt;
 #define PP_AT(arr, i, k) (arr)[((i) * S + (k)) * bx + bl]
     if (valid) {
         const int k = c.k;
         double g[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) g[i] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 2 + i) : src.z(bl, k, 2 + i), LBt[k * NZ + 2 + i], UBt[k * NZ + 2 + i]);
+        for (int i = 0; i < NX; ++i) g[i] = fmin(fmax(WS ? (double)MPC_K(P.Z, NZ, 0, 2 + i) : src.z(bl, k, 2 + i), PLt[k * NZ + 2 + i]), PHt[k * NZ + 2 + i]);
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double r0 = WS ? (double)MPC_K(P.REF, NX, 0, i) : src.ref0(bl, i);
-                const double x0 = push_in(r0, LBt[2 + i], UBt[2 + i]);
+                const double x0 = fmin(fmax(r0, PLt[2 + i]), PHt[2 + i]);
                 PP_AT(XR, i, 0) = x0;
                 PP_AT(DR, i, 0) = fabs(x0 - r0);
                 PP_AT(DG, i, 0) = fabs(g[i] - r0);
@@ -1671,51 +1682,101 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
         }
         if (k < N) {
             double u[2], f[NX], sp, cp, td;
-            u[0] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 0) : src.z(bl, k, 0), LBt[k * NZ], UBt[k * NZ]);
-            u[1] = push_in(WS ? (double)MPC_K(P.Z, NZ, 0, 1) : src.z(bl, k, 1), (k == 0) ? A0[bl] : LBt[k * NZ + 1], (k == 0) ? A0[bx + bl] : UBt[k * NZ + 1]);
+            u[0] = fmin(fmax(WS ? (double)MPC_K(P.Z, NZ, 0, 0) : src.z(bl, k, 0), PLt[k * NZ]), PHt[k * NZ]);
+            {
+                const double u1 = WS ? (double)MPC_K(P.Z, NZ, 0, 1) : src.z(bl, k, 1);
+                u[1] = (k == 0) ? push_in(u1, A0[bl], A0[bx + bl]) : fmin(fmax(u1, PLt[k * NZ + 1]), PHt[k * NZ + 1]);      // (a_0: per-instance bounds)
+            }
             PP_AT(IN, 0, k) = u[0];
             PP_AT(IN, 1, k) = u[1];
             ode_eval<NX>(P, g, u, f, sp, cp, td);
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double raw = f[i] * dt + g[i];
-                const double gn = push_in(WS ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : src.z(bl, k + 1, 2 + i), LBt[(k + 1) * NZ + 2 + i], UBt[(k + 1) * NZ + 2 + i]);
+                const double gn = fmin(fmax(WS ? (double)MPC_K(P.Z, NZ, 1, 2 + i) : src.z(bl, k + 1, 2 + i), PLt[(k + 1) * NZ + 2 + i]), PHt[(k + 1) * NZ + 2 + i]);
                 PP_AT(DG, i, k + 1) = fabs(gn - raw);
             }
         }
     }
     __syncthreads();
-    // one scan: lanes of stage-thread `which` (0 or 1) carry state s0 / s1 through the stages from the increments IN[which]
+    PS_STAMP(2);
+    // the sum of the guess's defects (its rows are complete): by the first stage-thread of the SECOND wavefront, which has nothing to do in the scans
+    // -- off the critical path; the same order of additions as ever (stage-major)
+    auto defect_sum = [&](const double* D, double th, const int ka, const int kb) {         // stages ka ... kb - 1 added to th
+        for (int k0 = ka; k0 < kb; k0 += 4) {          // (four stages' reads in flight)
+            double v[4][NX];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (k0 + j < kb) ? k0 + j : kb - 1;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) v[j][i] = PP_AT(D, i, k);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k0 + j < kb) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) th += v[j][i];
+                }
+            }
+        }
+        return th;
+    };
+    // (a third of the stages in front of each of the three scans, the running sum carried in a register: hidden behind the chains)
+    const int kdg = (64 / bx <= N) ? 64 / bx : 1;
+    const bool sums_dg = valid && c.k == kdg;
+    double th_g = 0.0;
+    int dg_part = 0;
+    if (valid && c.k == 0) A0[3 * bx + bl] = 0.0;              // (set to 1 by a stage thread that finds a rolled-out state clipped)
+    // one scan: lanes of stage-thread `which` (0 or 1) carry state s0 / s1 through the stages from the increments IN[which].  All that is sequential is
+    // the chain x -> fma -> clip against limits fetched eight stages ahead; the clipping defects are formed afterwards, every stage thread its own
+    // (the same two operations on the same operands: same bits as inside the chain).
+    bool clipped = false;
     auto scan = [&](int s0, int s1, int nwhich) {
+        if (sums_dg) {
+            th_g = defect_sum(DG, th_g, dg_part * S / 3, (dg_part + 1) * S / 3);
+            if (++dg_part == 3) A0[2 * bx + bl] = th_g;
+        }
         if (valid && c.k < nwhich) {
             const int si = (c.k == 0) ? s0 : s1;
             const double* in = IN + c.k * SB;
             double x = PP_AT(XR, si, 0);
-            // (the chain x -> fma -> clip is all that is sequential: increments and bounds of eight stages are fetched ahead of it -- left to itself
-            //  the loop waits for three LDS reads in every step)
-            for (int k0 = 0; k0 < N; k0 += 8) {
+            int k0 = 0;
+            for (; k0 + 8 <= N; k0 += 8) {
                 double inc[8], lo[8], hi[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = (k0 + j < N) ? k0 + j : N - 1;
-                    inc[j] = in[k * bx + bl]; lo[j] = PLt[(k + 1) * NZ + 2 + si]; hi[j] = PHt[(k + 1) * NZ + 2 + si];
-                }
+                for (int j = 0; j < 8; ++j) { const int k = k0 + j; inc[j] = in[k * bx + bl]; lo[j] = PLt[(k + 1) * NZ + 2 + si]; hi[j] = PHt[(k + 1) * NZ + 2 + si]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int k = k0 + j;
-                    if (k < N) {
-                        const double raw = inc[j] * dt + x;
-                        const double rn = fmin(fmax(raw, lo[j]), hi[j]);              // (= push_in(raw, lb, ub): the limits are push_limits')
-                        PP_AT(DR, si, k + 1) = fabs(rn - raw);
-                        PP_AT(XR, si, k + 1) = rn;
-                        x = rn;
+                    x = fmin(fmax(__builtin_fma(inc[j], dt, x), lo[j]), hi[j]);              // (= push_in(raw, lb, ub): the limits are push_limits')
+                    PP_AT(XR, si, k0 + j + 1) = x;
+                }
+            }
+            if (k0 < N) {
+                double inc[8], lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int k = (k0 + j < N) ? k0 + j : N - 1; inc[j] = in[k * bx + bl]; lo[j] = PLt[(k + 1) * NZ + 2 + si]; hi[j] = PHt[(k + 1) * NZ + 2 + si]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j < N) {
+                        x = fmin(fmax(__builtin_fma(inc[j], dt, x), lo[j]), hi[j]);
+                        PP_AT(XR, si, k0 + j + 1) = x;
                     }
                 }
             }
         }
         __syncthreads();
+        if (valid && c.k < N) {
+            for (int w = 0; w < nwhich; ++w) {
+                const int si = w ? s1 : s0;
+                const double raw = __builtin_fma(PP_AT(IN + w * SB, 0, c.k), dt, PP_AT(XR, si, c.k));
+                const double dr = fabs(PP_AT(XR, si, c.k + 1) - raw);
+                PP_AT(DR, si, c.k + 1) = dr;
+                clipped = clipped || dr != 0.0;
+            }
+        }
     };
     scan(2, 3, 2);                                            // delta, v from the controls
+    PS_STAMP(3);
     if (valid && c.k < N) {
         const double dl = PP_AT(XR, 2, c.k), v = PP_AT(XR, 3, c.k);
         PP_AT(IN, 0, c.k) = v / P.wheelbase * mpc_tan(dl);            // (the functions of ode_eval: same bits as the two-chain kernel)
@@ -1723,6 +1784,7 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     }
     __syncthreads();
     scan(4, 5, NX == 6 ? 2 : 1);                              // psi (and the progress state)
+    PS_STAMP(4);
     if (valid && c.k < N) {
         double sp, cp;
         mpc_sincos(PP_AT(XR, 4, c.k), sp, cp);
@@ -1732,34 +1794,26 @@ __device__ __forceinline__ void prestart_par_block(const PRef& P, const uint32_t
     }
     __syncthreads();
     scan(0, 1, 2);                                            // x, y
+    PS_STAMP(5);
     if (valid) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) MPC_K(P.ROLL, NX, 0, i) = PP_AT(XR, i, c.k);
-    }
-    double th = 0.0;
-    if (valid && c.k < 2) {                                   // stage-thread 0 sums the rollout's defects, stage-thread 1 the guess's
-        const double* D = (c.k == 0) ? DR : DG;
-        for (int k0 = 0; k0 <= N; k0 += 4) {          // (same order of additions; four stages' reads in flight)
-            double v[4][NX];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = (k0 + j <= N) ? k0 + j : N;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) v[j][i] = PP_AT(D, i, k);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k0 + j <= N) {
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) th += v[j][i];
-                }
-            }
-        }
-        if (c.k == 1) A0[2 * bx + bl] = th;
+        if (clipped) A0[3 * bx + bl] = 1.0;
     }
     __syncthreads();
-    if (valid && c.k == 0) prestart_decide<NX>(P, c.b, frow, a0lb, a0ub, A0[2 * bx + bl], th);
+    PS_STAMP(6);
+    if (valid && c.k == 0) {
+        // the rollout's defects: |x_0 - r_0| and what the clipping took -- zeros unless some stage thread said otherwise (adding them changes nothing)
+        double th = 0.0;
+        if (A0[3 * bx + bl] != 0.0) th = defect_sum(DR, 0.0, 0, S);
+        else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) th += PP_AT(DR, i, 0);
+        }
+        prestart_decide<NX>(P, c.b, frow, a0lb, a0ub, A0[2 * bx + bl], th);
+    }
 #undef PP_AT
+#undef PS_STAMP
 }
 template <int NX>
 __global__ void __launch_bounds__(1024) k_prestart_par(const Params Pk) {
@@ -3089,17 +3143,17 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             if (Pg.DBG) {          // (option start_timing: shader-clock stamps of every workgroup of k_start; synchronises)
                 std::vector<unsigned long long> hd((size_t)16 * q.nblk);
                 if (hipStreamSynchronize(q.st) == hipSuccess && hipMemcpy(hd.data(), Pg.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                    const int order[10] = {11, 12, 13, 14, 15, 0, 7, 8, 9, 10};
-                    static const char* names[9] = {"rows->LDS", "Z/REF stores", "safeguard", "fence", "enter", "init point+exchange", "eval+assemble", "reduce", "finish"};
-                    double acc[9] = {0};
+                    const int order[16] = {11, 12, 13, 1, 2, 3, 4, 5, 6, 14, 15, 0, 7, 8, 9, 10};
+                    static const char* names[15] = {"rows->LDS", "Z/REF stores", "bounds+a0", "defects", "scan1", "tan+scan2", "sincos+scan3", "ROLL+sums", "decide", "fence", "enter", "init point+exchange", "eval+assemble", "reduce", "finish"};
+                    double acc[15] = {0};
                     unsigned long long t0 = ~0ull, t1 = 0ull;
                     for (int bq = 0; bq < q.nblk; ++bq) {
                         const unsigned long long* r = hd.data() + (size_t)bq * 16;
-                        for (int j = 0; j < 9; ++j) acc[j] += (double)(long long)(r[order[j + 1]] - r[order[j]]);
+                        for (int j = 0; j < 15; ++j) acc[j] += (double)(long long)(r[order[j + 1]] - r[order[j]]);
                         t0 = std::min(t0, r[11]); t1 = std::max(t1, r[10]);
                     }
                     fprintf(stderr, "[mpcgpu k_start timing, shader-clock ticks, mean over %d workgroups]", q.nblk);
-                    for (int j = 0; j < 9; ++j) fprintf(stderr, " %s=%.0f", names[j], acc[j] / q.nblk);
+                    for (int j = 0; j < 15; ++j) fprintf(stderr, " %s=%.0f", names[j], acc[j] / q.nblk);
                     fprintf(stderr, "; first start to last end %.0f\n", (double)(t1 - t0));
                 }
                 Pg.DBG = nullptr;
