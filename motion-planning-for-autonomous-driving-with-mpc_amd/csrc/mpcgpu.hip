@@ -976,11 +976,16 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                         pipe_add(X + 48, 1u);
                     }
                 } else if (t < 64) {
+                    // (the tile's mask goes out with the sweep's last stores: ONE wait covers both -- it is read by a stage worker only after it has seen
+                    //  its queue slot, which is written behind that wait)
+                    if (t == 0 && !(A.flags & 1u)) __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // gains, cost-to-go and the step are in the L2
                     if (t == 0) {
-                        if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                        __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (A.flags & 1u) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
                         const uint32_t tk = pipe_add(X + 32, A.items);
                         for (uint32_t q = 0; q < A.items; ++q)
                             __hip_atomic_store(slots + ((tk + q) & (A.cap - 1u)), ((unsigned long long)(tk + q + 1u) << 32) | (unsigned long long)((tile << 8) | q),
