@@ -42,6 +42,9 @@
 #define MPC_GLOBAL_AS
 #endif
 // plain global-pointer access (small tables and the caller's row-major buffers)
+#ifndef MPC_EXP_PAIR
+#define MPC_EXP_PAIR 0     // 1: the paired-store experiment (odd row tails with their pad row, neighbouring scalar rows): profiles/r05_store_pairing.txt
+#endif
 #define MPC_GP(ptr, idx) (((MPC_GLOBAL_AS __typeof__(*(ptr))*)(ptr))[(uint32_t)(idx)])
 
 namespace mpc {
@@ -299,7 +302,12 @@ template <int CNT, class RefFn>
 MPC_HD void ws_store_rows(RefFn ref, const double* src) {
 #pragma unroll
     for (int i = 0; i + 1 < CNT; i += 2) MPC_ST2(ref(i), src[i], src[i + 1]);
+#if (MPC_EXP_PAIR & 1) && defined(__HIP_DEVICE_COMPILE__)
+    // (experiment of profiles/r05_store_pairing.txt: the odd last row together with the pad row behind it, one 16-byte store)
+    if (CNT & 1) MPC_ST2(ref(CNT - 1), src[CNT - 1], 0.0);
+#else
     if (CNT & 1) ref(CNT - 1) = src[CNT - 1];
+#endif
 }
 
 template <int NX>
@@ -1916,11 +1924,28 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
     }
     c.status = status;
     if (MPC_RA && k == 0) {
+#if (MPC_EXP_PAIR & 2) && defined(__HIP_DEVICE_COMPILE__)
+        // (experiment: neighbouring scalar rows of an instance with one 16-byte store)
+        static_assert(SC_MU % 2 == 0 && SC_TAU == SC_MU + 1 && SC_FCOST % 2 == 0 && SC_LOGSUM == SC_FCOST + 1, "row pairs");
+        if (MPC_EXP_PAIR & 512) { MPC_S(P.SC, SC_TAU) = tau; MPC_STORE_FENCE(); }
+        if (MPC_EXP_PAIR & 32) { double m_ = mu, t_ = tau; asm volatile("" : "+v"(m_), "+v"(t_)); MPC_ST2(MPC_S(P.SC, SC_MU), m_, t_); }
+        else if (!(MPC_EXP_PAIR & 16)) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
+        else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
+        if (MPC_EXP_PAIR & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
+        if (MPC_EXP_PAIR & 128) { MPC_S(P.SC, SC_TAU) = tau; }
+        if (MPC_EXP_PAIR & 256) { MPC_S(P.SC, SC_MU) = mu; }
+        if (!(MPC_EXP_PAIR & 8)) MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum);
+        else { MPC_S(P.SC, SC_FCOST) = red.fcost; MPC_STORE_FENCE(); MPC_S(P.SC, SC_LOGSUM) = red.logsum; }
+        if (MPC_EXP_PAIR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        if (MB) { c.scl[WgScl::MU] = mu; c.scl[WgScl::TAU] = tau; c.scl[WgScl::FCOST] = red.fcost; c.scl[WgScl::LOGSUM] = red.logsum; }
+        MPC_SCW(SC, SC_THETA, THETA, red.theta);
+#else
         MPC_SCW(SC, SC_MU, MU, mu);
         MPC_SCW(SC, SC_TAU, TAU, tau);
         MPC_SCW(SC, SC_THETA, THETA, red.theta);
         MPC_SCW(SC, SC_FCOST, FCOST, red.fcost);
         MPC_SCW(SC, SC_LOGSUM, LOGSUM, red.logsum);
+#endif
         MPC_S(P.SC, SC_E0) = E0;
         MPC_SCW(ISC, IS_STATUS, STATUS, status);
         if (mu_changed) MPC_SCW(ISC, IS_NFILT, NFILT, 0);       // the filter is reset whenever mu changes
