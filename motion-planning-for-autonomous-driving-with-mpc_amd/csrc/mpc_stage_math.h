@@ -1927,14 +1927,17 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
 #if (MPC_EXP_PAIR & 2) && defined(__HIP_DEVICE_COMPILE__)
         // (experiment: neighbouring scalar rows of an instance with one 16-byte store)
         static_assert(SC_MU % 2 == 0 && SC_TAU == SC_MU + 1 && SC_FCOST % 2 == 0 && SC_LOGSUM == SC_FCOST + 1, "row pairs");
+        if (MPC_EXP_PAIR & 1024) { MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum); MPC_STORE_FENCE(); }
         if (MPC_EXP_PAIR & 512) { MPC_S(P.SC, SC_TAU) = tau; MPC_STORE_FENCE(); }
         if (MPC_EXP_PAIR & 32) { double m_ = mu, t_ = tau; asm volatile("" : "+v"(m_), "+v"(t_)); MPC_ST2(MPC_S(P.SC, SC_MU), m_, t_); }
+        else if (MPC_EXP_PAIR & 2048) { }
         else if (!(MPC_EXP_PAIR & 16)) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
         else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
         if (MPC_EXP_PAIR & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
         if (MPC_EXP_PAIR & 128) { MPC_S(P.SC, SC_TAU) = tau; }
         if (MPC_EXP_PAIR & 256) { MPC_S(P.SC, SC_MU) = mu; }
-        if (!(MPC_EXP_PAIR & 8)) MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum);
+        if (MPC_EXP_PAIR & 1024) { }
+        else if (!(MPC_EXP_PAIR & 8)) MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum);
         else { MPC_S(P.SC, SC_FCOST) = red.fcost; MPC_STORE_FENCE(); MPC_S(P.SC, SC_LOGSUM) = red.logsum; }
         if (MPC_EXP_PAIR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         if (MB) { c.scl[WgScl::MU] = mu; c.scl[WgScl::TAU] = tau; c.scl[WgScl::FCOST] = red.fcost; c.scl[WgScl::LOGSUM] = red.logsum; }
@@ -1950,6 +1953,9 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         MPC_SCW(ISC, IS_STATUS, STATUS, status);
         if (mu_changed) MPC_SCW(ISC, IS_NFILT, NFILT, 0);       // the filter is reset whenever mu changes
         if (P.fixed_iters > 0 && E0 <= P.tol) MPC_SCW(ISC, IS_CONV, CONV, 1);
+#if (MPC_EXP_PAIR & 2048) && defined(__HIP_DEVICE_COMPILE__)
+        MPC_STORE_FENCE(); MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
+#endif
     }
 }
 
