@@ -1931,6 +1931,12 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         if (MPC_EXP_PAIR & 512) { MPC_S(P.SC, SC_TAU) = tau; MPC_STORE_FENCE(); }
         if (MPC_EXP_PAIR & 32) { double m_ = mu, t_ = tau; asm volatile("" : "+v"(m_), "+v"(t_)); MPC_ST2(MPC_S(P.SC, SC_MU), m_, t_); }
         else if (MPC_EXP_PAIR & 2048) { }
+        else if (MPC_EXP_PAIR & (4096 | 8192)) {
+            // the 16-byte store only in the start iterate's finish (4096) / only in the loop's (8192); 8-byte stores otherwise
+            const bool first = c.iters == 0;
+            if (((MPC_EXP_PAIR & 4096) != 0) == first) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
+            else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
+        }
         else if (!(MPC_EXP_PAIR & 16)) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
         else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
         if (MPC_EXP_PAIR & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
