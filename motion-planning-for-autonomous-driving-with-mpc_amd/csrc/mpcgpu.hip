@@ -3238,6 +3238,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         }
         Params Pw = P;
         Pw.bx = bxw;
+        if (skip_if != nullptr) Pw.DBG = nullptr;         // (behind the pipeline: a stamp buffer of option pipe_timing is sized for the PIPELINE's workgroups)
         const int thr = 64;                        // (S * bxw <= 64: checked where the path is chosen)
         WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
         const dim3 grid(wg_grid > 0 ? wg_grid : (B + bxw - 1) / bxw);
