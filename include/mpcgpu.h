@@ -274,6 +274,8 @@ int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value);
  * profiling is enabled: out[0] = total ms in the Riccati factor/solve kernel, out[1] = its launch count,
  * out[2] = total ms in the stage (line-search/assemble) kernel, out[3] = its launch count,
  * out[4] = ms in init + output kernels, out[5] = IPM iterations launched.                                 */
+/* enable = 2: the two kernels of a hybrid solve's iteration loop are timed as ONE span (mpc_get_pipeline_profile out[0] = the loop, the
+ * resident profile's out[0] = 0): no event between them -- a marker costs the stream a few microseconds that a production solve does not pay */
 int mpc_set_profiling(mpc_handle* h, int32_t enable);
 int mpc_get_profile(const mpc_handle* h, double out[6]);
 /* When the last call ran all its iterations in ONE persistent launch (k_pipeline: batches of 1024..8192 instances;

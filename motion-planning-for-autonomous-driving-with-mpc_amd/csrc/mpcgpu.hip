@@ -2567,6 +2567,7 @@ struct mpc_handle {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     // profiling
     bool profiling = false;
+    bool prof_span = false;             // (mpc_set_profiling(h, 2): the iteration loop of the hybrid solve as ONE span -- no marker between its two kernels)
     double prof[6] = {0, 0, 0, 0, 0, 0};
     double res_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // k_solve_wg: ms (profiling only), ran, rounds of the slowest workgroup, workgroups, workgroup-rounds, Riccati sweeps, instance-iterations
     double pipe_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // k_pipeline: ms (profiling only), launches, rounds, Riccati-wait / stage-wait / stage-busy ms summed over workers, items, stage workers + riccati workers / 1000
@@ -2833,6 +2834,7 @@ int mpc_set_bounds(mpc_handle* h, const double* lbx, const double* ubx, const do
 int mpc_set_profiling(mpc_handle* h, int32_t enable) {
     if (!h) return MPC_ERR_INVALID;
     h->profiling = enable != 0;
+    h->prof_span = enable == 2;
     return MPC_OK;
 }
 
@@ -3419,7 +3421,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             if (hand <= 0) prof.end(stream);
             if (hand > 0) {        // (its statistics words are part of the control block: no fill, no copy of their own)
-                prof.next(5, stream);
+                if (!h->prof_span) prof.next(5, stream);          // (span mode: the pipeline's span stays open over k_solve_wg)
                 if (ho_list) {
                     // (the counters: words of the control block, zero at the start of every solve)
                     if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO, (const uint32_t*)(ctl + PIPE_HDR));
