@@ -235,7 +235,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances), "loop_async" (0: closed loop with a host round trip per step),
  * "sync_spin" (0: block in the one synchronisation of a solve instead of polling the stream), "max_batch" (instances per chunk: a batch
  * whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway; this lowers the limit),
- * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing", "start_timing",
+ * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing", "start_timing", "poison" (1: NaN into every row of the workspace before a solve -- a debugging aid),
  * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage),
  * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve),
  * "pair" (1: two threads per (instance, stage) in the stage phases; measured slower, profiles/r04_stage_split.txt -- the variant is

@@ -1102,7 +1102,16 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
         // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
         status = MPC_S(P.ISC, IS_STATUS); nfilt = MPC_S(P.ISC, IS_NFILT); iters = MPC_S(P.ISC, IS_ITERS);
         convf = MPC_S(P.ISC, IS_CONV); frow = MPC_S(P.ISC, IS_FROW); haveth0 = MPC_S(P.ISC, IS_HAVETH0);
+#if (MPC_EXP_PAIR & 16384) && defined(__HIP_DEVICE_COMPILE__)
+        {   // (experiment: mu and tau with agent-scope loads -- sc1: not served from this CU's L1)
+            const WsRefD rm = MPC_S(P.SC, SC_MU), rt = MPC_S(P.SC, SC_TAU);
+            mu = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(P.rws, (int)rm.voff, mpc_uni(rm.aoff + rm.uoff), 16));
+            tau = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(P.rws, (int)rt.voff, mpc_uni(rt.aoff + rt.uoff), 16));
+        }
+        df = MPC_S(P.SC, SC_DF); theta = MPC_S(P.SC, SC_THETA);
+#else
         mu = MPC_S(P.SC, SC_MU); tau = MPC_S(P.SC, SC_TAU); df = MPC_S(P.SC, SC_DF); theta = MPC_S(P.SC, SC_THETA);
+#endif
         fcost = MPC_S(P.SC, SC_FCOST); logsum = MPC_S(P.SC, SC_LOGSUM);
         thmax = MPC_S(P.SC, SC_THMAX); thmin = MPC_S(P.SC, SC_THMIN);
         a0lb = MPC_S(P.SC, SC_A0LB); a0ub = MPC_S(P.SC, SC_A0UB);

@@ -865,7 +865,9 @@ __device__ __forceinline__ void pipe_acquire(bool l1_only) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (l1_only) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if !defined(MPC_EXP_NOINV)        // (experiment of profiles/r05_store_pairing.txt: the hand-offs without any invalidate)
         asm volatile("buffer_inv sc0" ::: "memory");
+#endif
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -885,6 +887,16 @@ __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, u
         dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
     }
     for (; i < n; i += 256) dst[i] = src[i];
+}
+
+// debugging aid (option poison): rows [r0, r1) of every tile of the double workspace set to NaN before a solve -- a read of memory the solve has not
+// written shows as status -6 instead of as a stale but plausible number
+__global__ void k_poison(double* ws, uint32_t tile_elems, uint32_t ntiles, uint32_t e0, uint32_t e1) {
+    const size_t n = (size_t)(e1 - e0) * ntiles;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = i / (e1 - e0), e = e0 + i % (e1 - e0);
+        ws[tile * tile_elems + e] = __builtin_nan("");
+    }
 }
 
 // which XCDs does this device have?  (one bit per HW_REG_XCC_ID that some workgroup of a grid of 4 x CUs ran on)
@@ -2588,7 +2600,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1, start_timing = 0;
+        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1, start_timing = 0, poison = 0, poison_r0 = 0, poison_r1 = 0;
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2627,6 +2639,9 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
     else if (n == "mb_pipe") k.mb_pipe = value == nullptr ? 1 : (v[0] != '0');
     else if (n == "start_timing") k.start_timing = on != 0;
+    else if (n == "poison") k.poison = on != 0;
+    else if (n == "poison_r0") k.poison_r0 = (int)iv;
+    else if (n == "poison_r1") k.poison_r1 = (int)iv;
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
@@ -2663,6 +2678,9 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "pipe_help") *out = k.pipe_help;
     else if (n == "mb_pipe") *out = k.mb_pipe;
     else if (n == "start_timing") *out = k.start_timing;
+    else if (n == "poison") *out = k.poison;
+    else if (n == "poison_r0") *out = k.poison_r0;
+    else if (n == "poison_r1") *out = k.poison_r1;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
@@ -2676,7 +2694,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe", "start_timing"};
+    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe", "start_timing", "poison", "poison_r0", "poison_r1"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -3124,6 +3142,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
+    if (kn.poison && !h->in_rescue) {           // (debugging aid: NaN into rows [poison_r0, poison_r1) -- 0, 0 = all -- of every tile before the solve)
+        const WsLayout wl = ws_layout(d.N, d.nx, Bp, h->ws_mailbox);
+        const uint32_t r0 = (uint32_t)std::max(0, kn.poison_r0) & ~1u, r1 = kn.poison_r1 > 0 ? std::min((uint32_t)kn.poison_r1, (uint32_t)wl.rows) : (uint32_t)wl.rows;
+        if (r1 > r0) hipLaunchKernelGGL(k_poison, dim3(1024), dim3(256), 0, stream, h->d_ws, (uint32_t)wl.tile_elems, (uint32_t)wl.ntiles, r0 * 64u, r1 * 64u);
+        if (kn.poison_r0 < 0) fprintf(stderr, "[mpcgpu poison] rows of a tile: Z %zu ZL %zu ZU %zu SO %zu NUO %zu ZLO %zu ZUO %zu LAM %zu REF %zu DZ %zu PK %zu KK %zu BLK %zu ROLL %zu SC %zu FILT %zu OBST %zu end %zu\n",
+                                      wl.Z, wl.ZL, wl.ZU, wl.SO, wl.NUO, wl.ZLO, wl.ZUO, wl.LAM, wl.REF, wl.DZ, wl.PK, wl.KK, wl.BLK, wl.ROLL, wl.SC, wl.FILT, wl.OBST, wl.rows);
+    }
     for (int g = 0; g < G; ++g) {
         const Group& q = grp[g];
         if (!q.running) continue;
