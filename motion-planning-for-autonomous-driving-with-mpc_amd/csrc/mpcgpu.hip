@@ -3387,6 +3387,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // two threads per (instance, stage) in the stage workers (option pair): 512-thread workgroups
         const size_t lds_pair = ((size_t)(2 * nw) * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * threads) * sizeof(double);
         const bool pipe_pair = MPC_WITH_PAIR && kn.pair != 0 && pair_vm_ok && 2 * threads <= 512 && lds_pair <= lds_max;
+        // (threads >= 192 is also what the hand-offs' cache argument rests on: a stage item then loads >= 130 KB at its top -- ~90 rows x 8 bytes per stage
+        //  thread -- and pushes the lines of the worker's previous item out of its 32 KB L1; DESIGN.md section 4, invariant (I1))
         const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                               ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                               std::max(lds_bytes, ric_lds) <= lds_max;
