@@ -703,9 +703,14 @@ def other_configs(torch, wl, local_rank, dev, stream):
         else:
             once()
         torch.cuda.synchronize(dev)
+        paths = []
         for d in items:
             ab = algorithmic_bytes(d["fam"].N, d["fam"].nx)
             pr, pp, rp = d["s"].get_profile(), d["s"].get_pipeline_profile(), d["s"].get_resident_profile()
+            # (which kernels served the family's last solve -- a pipeline launch that had to be abandoned, e.g. two persistent launches starving each
+            #  other, leaves the handle on one launch per kernel for good: that must not go unnoticed)
+            paths.append("%s: %s%s" % (d["fam"].name, "+".join((["k_pipeline"] if pp["ran"] else []) + (["k_solve_wg"] if rp["ran"] else [])) or "one launch per kernel",
+                                       " (PIPELINE ABANDONED)" if d["s"].get_option("pipe_disabled") else ""))
             loop_ms += pp["ms"] + rp["ms"] + pr["riccati_ms"] + pr["stage_ms"]
             loop_bytes += float(d["it"].sum().item()) * ab["b_iter"]
             d["s"].set_profiling(False)
@@ -717,7 +722,7 @@ def other_configs(torch, wl, local_rank, dev, stream):
         out.append(dict(config=label, batch=Bt, ms_per_batch=dt * 1e3, steps_per_s=Bt / dt, converged_frac=float((st == 1).mean()),
                         mean_iters=float(it.mean()), max_iters=int(it.max()), loop_launch_ms=loop_ms if loop_ms == loop_ms else None,
                         roofline_frac=(loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if loop_ms > 0 else None,
-                        rescued=int(sum(d["s"].last_rescued() for d in items))))
+                        rescued=int(sum(d["s"].last_rescued() for d in items)), paths=paths))
     try:
         f2, f3, f4 = wl.FAMILIES["zamlf_n30_nx6"], wl.FAMILIES["zamca_n30_nx5"], wl.FAMILIES["usalf_n50_nx5"]
         run("2: N=30 nx=6 lane following, batch=256", [(f2,) + tuple(wl.batch(f2, 256))])

@@ -2867,6 +2867,8 @@ int mpc_set_option(mpc_handle* h, const char* name, const char* value) {
 int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value) {
     if (!h || !name || !value) return MPC_ERR_INVALID;
     long v = 0;
+    // (not a switch, a state: 1 after a pipeline launch of this handle had to be abandoned -- it then stays on one launch per kernel)
+    if (std::string(name) == "pipe_disabled") { *value = h->pipe_disabled ? 1 : 0; return MPC_OK; }
     const int rc = get_knob(h->knobs, name, &v);
     if (rc == MPC_OK) *value = (int64_t)v;
     return rc;
