@@ -143,6 +143,27 @@ def test_riccati_workers_that_help_with_stage_items_change_nothing(fam, B, maske
             assert np.array_equal(alt.x, ref.x) and np.array_equal(alt.iters, ref.iters) and np.array_equal(alt.status, ref.status)
 
 
+@pytest.mark.parametrize("opts", [(("hybrid", "0"),), (("hybrid", "0"), ("pipeline", "0")), ()])
+def test_poisoned_workspace_changes_nothing_on_single_tile_xcds(opts):
+    """Option poison: NaN into every row of every tile of the workspace before a solve.  (a) A solve reads nothing it has not written itself -- no
+    NaN comes out, every row is the bits of the unpoisoned solve; (b) at B = 600 six of the eight XCDs hold ONE tile, 31 stage workers share its 8 items
+    per round and idle for rounds with their L1 untouched: the configuration in which a stage worker was found to read its own stale copy of a line when a
+    16-byte store re-created that line at the end of a stage item (profiles/r05_store_pairing.txt; invariants (I1) / (I2) of DESIGN.md section 4) --
+    repeated, every repetition must be the same bits."""
+    cfg, kw = FAMILIES["zamlf_n30_nx6"]
+    x0, p = synthetic_batch(cfg, 600, **kw)
+    s = make_solver(cfg)
+    for k, v in opts:
+        s.set_option(k, v)
+    ref = s.solve(x0, p)
+    assert np.all(ref.status == 1)
+    s.set_option("poison", "1")
+    for rep in range(4):
+        a = s.solve(x0, p)
+        assert np.all(np.isfinite(a.x)) and np.array_equal(a.status, ref.status), rep
+        assert np.array_equal(a.x, ref.x) and np.array_equal(a.iters, ref.iters), rep
+
+
 @pytest.mark.parametrize("fam,B,masked", [("zamlf_n30_nx6", 4096, True), ("usalf_n50_nx5", 3000, True), ("zamlf_n30_nx5", 2600, False)])
 def test_mailbox_rows_written_by_the_pipeline_equal_the_ones_copied_at_the_hand_over(fam, B, masked):
     """Option mb_pipe (default 1): the stage items of a tile that is about to leave the pipeline write iterate, multipliers and stage block into the
