@@ -224,6 +224,7 @@ inline void fill_params(Params& P, const HostProblem& hp, int B, size_t Bp, int 
     P.WS = base; P.IWS = ibase;
     P.ws_bytes = (uint32_t)(w.total * sizeof(double)); P.iws_bytes = (uint32_t)(w.itotal * sizeof(int32_t));
     P.x_out = nullptr; P.status_out = nullptr; P.iters_out = nullptr; P.kkt_out = nullptr;
+    P.emit = 0; P.fail_count = nullptr; P.fin_ctl = nullptr; P.fin_host = nullptr;
     P.DBG = nullptr;
     P.tile0 = 0;
 }

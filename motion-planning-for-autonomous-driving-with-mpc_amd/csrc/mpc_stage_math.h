@@ -42,9 +42,6 @@
 #define MPC_GLOBAL_AS
 #endif
 // plain global-pointer access (small tables and the caller's row-major buffers)
-#ifndef MPC_EXP_PAIR
-#define MPC_EXP_PAIR 0     // 1: the paired-store experiment (odd row tails with their pad row, neighbouring scalar rows): profiles/r05_store_pairing.txt
-#endif
 #define MPC_GP(ptr, idx) (((MPC_GLOBAL_AS __typeof__(*(ptr))*)(ptr))[(uint32_t)(idx)])
 
 namespace mpc {
@@ -58,6 +55,9 @@ constexpr double DW_MIN = 1e-20, DW_0 = 1e-4, DW_MAX = 1e40, KW_MINUS = 1.0 / 3.
 constexpr double SCALING_MAX_GRAD = 100.0;
 constexpr int FILTER_MAX = 32;
 constexpr int ST_RUNNING = 99;          // internal status while iterating
+constexpr int ST_SWEEP_FAILED = -70;    // internal, launches that write the caller's rows themselves (Params::emit): the Riccati sweep of the pipeline gave the
+                                        // instance up (no admissible inertia correction) and its row is not out yet -- the next stage item of its block
+                                        // writes it with status -7 (the sweep's lane holds one instance, not its stages)
 constexpr double BIG = 1e300;
 constexpr double ROLLOUT_FACTOR = 10.0;   // start-point safeguard, see prestart_instance()
 // constraint violations (1-norm) below this are round-off, two orders under the 1e-8 feasibility tolerance: the
@@ -141,6 +141,14 @@ struct Params {
     int32_t* status_out;
     int32_t* iters_out;
     double* kkt_out;
+    // emit != 0: an instance's row of x_out / status / iterations / KKT error is written by its own stage threads at the moment its status becomes
+    // final (emit_result) -- the loop kernels are then the last to touch the batch, no output transpose (k_egest) behind them; fail_count (optional)
+    // += instances that end with status 0 / -7 (the host decides from it whether a second chance is due)
+    int32_t emit;
+    uint32_t* fail_count;
+    // k_solve_wg as the last kernel of a solve: the workgroup that leaves last copies the head of the solve's control block (fin_ctl) into the
+    // handle's pinned host block (fin_host) -- see its epilogue; null: nobody does
+    uint32_t *fin_ctl, *fin_host;
 };
 
 // Layout of a tile of 64 instances: rows come in PAIRS, interleaved per instance -- rows 2j and 2j+1 of an array are
@@ -173,18 +181,35 @@ __device__ __forceinline__ int mpc_uni(uint32_t v) { return __builtin_amdgcn_rea
 // kernel.  (Before, every access site rebuilt its descriptor from the base pointer and the size -- values the register allocator had
 // spilled with the rest of their kernel-argument tuple: k_solve_wg reloaded those eight words at 46 places, four v_readlane + three
 // s_mov + one s_and per site.)
+// `xcu`: the kernel reads workspace rows that ANOTHER compute unit wrote earlier IN THE SAME LAUNCH (k_pipeline: tiles travel between Riccati and
+// stage workers of one XCD).  A CU's vector L1 is never refreshed by another CU's stores and `buffer_inv sc0` / workgroup-scope fences do not
+// drop its lines (measured: profiles/r05_store_pairing.txt, tools/ubench/stale_l1.hip), so every workspace load of such a kernel carries the
+// sc1 bit: served by the XCD's L2, where the producer's plain stores are once `s_waitcnt vmcnt(0)` has returned.  A literal of the kernel
+// (`const PRef P(Pk, true)`), folded into every load after inlining; tests/test_isa_hazards.py proves from the ISA that no buffer load of
+// k_pipeline is without the bit.
+constexpr int MPC_AUX_SC1 = 16;         // cache-policy operand of the gfx940+ buffer instructions: bit 0 sc0, bit 1 nt, bit 4 sc1
 struct DevParams : Params {
     __amdgpu_buffer_rsrc_t rws, riws;
+    bool xcu;
     // (host + device: host functions of a translation unit are type-checked in the device pass too, e.g. the host-side reference of tools/ubench)
-    __host__ __device__ __forceinline__ explicit DevParams(const Params& q) : Params(q), rws(mpc_rsrc(q.WS, q.ws_bytes)), riws(mpc_rsrc(q.IWS, q.iws_bytes)) {}
+    __host__ __device__ __forceinline__ explicit DevParams(const Params& q, const bool xcu_ = false)
+        : Params(q), rws(mpc_rsrc(q.WS, q.ws_bytes)), riws(mpc_rsrc(q.IWS, q.iws_bytes)), xcu(xcu_) {}
 };
 typedef DevParams PRef;
+// (the parameter block of a kernel, `xcu` a literal of the call site -- also how an out-of-line device function rebuilds its own copy)
+__device__ __forceinline__ PRef mpc_pref(const Params& q, const bool xcu) { return DevParams(q, xcu); }
+__device__ __forceinline__ mpc_v2u mpc_bload64(const DevParams& P, const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+    return P.xcu ? __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, MPC_AUX_SC1) : __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+__device__ __forceinline__ unsigned mpc_bload32(const DevParams& P, const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+    return P.xcu ? __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, MPC_AUX_SC1) : __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
 struct WsRefD {          // element of the double workspace: converts to double (load) / assigns from double (store)
     const PRef& P;
     uint32_t aoff, uoff, voff;     // array offset (uniform), uniform row offset, per-lane offset; bytes
     __device__ __forceinline__ operator double() const {
         const __amdgpu_buffer_rsrc_t r = P.rws;
-        const mpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, mpc_uni(aoff + uoff), 0);
+        const mpc_v2u v = mpc_bload64(P, r, (int)voff, mpc_uni(aoff + uoff));
         return __builtin_bit_cast(double, v);
     }
     __device__ __forceinline__ double operator=(double x) const {
@@ -198,7 +223,7 @@ struct WsRefI {          // element of the int32 workspace
     uint32_t soff, voff;
     __device__ __forceinline__ operator int32_t() const {
         const __amdgpu_buffer_rsrc_t r = P.riws;
-        return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, mpc_uni(soff), 0);
+        return (int32_t)mpc_bload32(P, r, (int)voff, mpc_uni(soff));
     }
     __device__ __forceinline__ int32_t operator=(int32_t x) const {
         const __amdgpu_buffer_rsrc_t r = P.riws;
@@ -210,7 +235,8 @@ struct WsRefI {          // element of the int32 workspace
 typedef unsigned int mpc_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ws_load2(const WsRefD& r, double& lo, double& hi) {
     const __amdgpu_buffer_rsrc_t d = r.P.rws;
-    const mpc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(d, (int)r.voff, mpc_uni(r.aoff + r.uoff), 0);
+    const mpc_v4u v = r.P.xcu ? __builtin_amdgcn_raw_buffer_load_b128(d, (int)r.voff, mpc_uni(r.aoff + r.uoff), MPC_AUX_SC1)
+                              : __builtin_amdgcn_raw_buffer_load_b128(d, (int)r.voff, mpc_uni(r.aoff + r.uoff), 0);
     lo = __builtin_bit_cast(double, mpc_v2u{v.x, v.y});
     hi = __builtin_bit_cast(double, mpc_v2u{v.z, v.w});
 }
@@ -263,6 +289,7 @@ __device__ __forceinline__ WsRefI ws_ref3(const PRef& P, const int32_t* arr, uin
                                      ((uint32_t)c.b * (uint32_t)(P.N + 1) * MPC_EV(R) + (uint32_t)c.k * 2u) * 8u}
 #else
 typedef Params PRef;
+MPC_HD PRef mpc_pref(const Params& q, bool) { return q; }
 #define MPC_KI(ptr, R, dk, e) ((ptr)[(size_t)c.b * (size_t)(P.N + 1) * MPC_EV(R) + (size_t)((uint32_t)(e) >> 1) * (size_t)(P.N + 1) * 2 + \
                                      (size_t)(c.k + (dk)) * 2 + ((uint32_t)(e) & 1u)])
 #define MPC_KM(ptr, R, dk, e) ((ptr)[((size_t)c.b * (size_t)(P.N + 1) + (size_t)c.k + (size_t)(dk)) * MPC_EV(R) + (size_t)(e)])
@@ -302,12 +329,7 @@ template <int CNT, class RefFn>
 MPC_HD void ws_store_rows(RefFn ref, const double* src) {
 #pragma unroll
     for (int i = 0; i + 1 < CNT; i += 2) MPC_ST2(ref(i), src[i], src[i + 1]);
-#if (MPC_EXP_PAIR & 1) && defined(__HIP_DEVICE_COMPILE__)
-    // (experiment of profiles/r05_store_pairing.txt: the odd last row together with the pad row behind it, one 16-byte store)
-    if (CNT & 1) MPC_ST2(ref(CNT - 1), src[CNT - 1], 0.0);
-#else
     if (CNT & 1) ref(CNT - 1) = src[CNT - 1];
-#endif
 }
 
 template <int NX>
@@ -355,21 +377,13 @@ MPC_HD void red_combine(Red3& a, const Red3& b) {
 
 // ---- elementary functions of the phases, in one place -------------------------------------------------------------------------------
 // A stage thread spends ~2 400 of its ~8 100 instructions per iteration inside the math library's division, pow, sincos, tan, log and sqrt
-// (counted by stubbing each out, MPC_XP) -- at one wavefront per SIMD every instruction is an issue slot.  The device versions below
+// (counted in round 4 by stubbing each out, profiles/r04_instruction_diet.txt) -- at one wavefront per SIMD every instruction is an issue slot.  The device versions below
 // are accurate to 1-2 ulp on the ranges the phases call them with (the host versions are libm: the emulation harness and the oracle
 // agree with the kernels to round-off, never bit for bit -- as before, the device library is not libm either).
-#ifndef MPC_XP
-#define MPC_XP 0          // (experiments: bit q set = function q replaced by a stub, to COUNT what it costs -- never in a product build)
-#endif
-#ifndef MPC_FAST_MATH
-#define MPC_FAST_MATH 1   // 0: the device library's division / sincos / tan and the literal pow of the switching condition
-#endif
 // 1 / x for a positive, normal x (gaps to bounds, circle distances, cos of the steering angle): hardware estimate + two Newton steps
 // (5 instructions; the IEEE division sequence is 11)
 MPC_HD double mpc_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 1)
-    return __builtin_amdgcn_rcp(x);
-#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+#if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(x);
     y = fma(y, fma(-x, y, 1.0), y);
     y = fma(y, fma(-x, y, 1.0), y);
@@ -378,22 +392,13 @@ MPC_HD double mpc_rcp(double x) {
     return 1.0 / x;
 #endif
 }
-MPC_HD double mpc_pow(double x, double y) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 2)
-    return x * y;
-#else
-    return pow(x, y);
-#endif
-}
 // sin and cos of a heading / steering angle: Cody-Waite reduction by pi/2 in three parts (exact products by fma: good to 1 ulp for
 // |x| < ~1e5), then the two minimax kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos); ~35 instructions
 // against ~200 of the library's sincos, which carries the Payne-Hanek reduction for huge arguments (no fallback to it: its code next to
 // this one costs 40 registers; the reduction stays exact in its products for any finite x, the quadrant is meaningless beyond 2^31 pi/2 --
 // a heading of that size is a diverged iterate, and the values stay finite).
 MPC_HD void mpc_sincos(double x, double& s, double& c) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 4)
-    s = x; c = 1.0 - 0.5 * x * x;
-#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+#if defined(__HIP_DEVICE_COMPILE__)
     const double fn = rint(x * 6.36619772367581382433e-01);
     double r = fma(-fn, 1.57079632679489655800e+00, x);           // pi/2 = hi + mid + lo
     r = fma(-fn, 6.12323399573676603587e-17, r);
@@ -409,17 +414,13 @@ MPC_HD void mpc_sincos(double x, double& s, double& c) {
     const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
-#elif defined(__HIP_DEVICE_COMPILE__)
-    sincos(x, &s, &c);
 #else
     s = sin(x); c = cos(x);
 #endif
 }
 // tan of a steering angle (|x| well inside pi/2: the variable is bounded): sin / cos from the reduction above
 MPC_HD double mpc_tan(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 8)
-    return x + x * x * x * (1.0 / 3.0);
-#elif defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH
+#if defined(__HIP_DEVICE_COMPILE__)
     double sn, cs;
     mpc_sincos(x, sn, cs);
     double t = sn * mpc_rcp(cs);
@@ -429,24 +430,12 @@ MPC_HD double mpc_tan(double x) {
     return tan(x);
 #endif
 }
-MPC_HD double mpc_log(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 16)
-    return x - 1.0;
-#else
-    return log(x);
-#endif
-}
-MPC_HD double mpc_sqrt(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && (MPC_XP & 32)
-    return __builtin_amdgcn_sqrt(x);
-#else
-    return sqrt(x);
-#endif
-}
+MPC_HD double mpc_log(double x) { return log(x); }
+MPC_HD double mpc_sqrt(double x) { return sqrt(x); }
 // r = sqrt(q) and 1 / r of a positive, normal q (circle distances) in one coupled iteration: hardware rsq estimate, two Goldschmidt steps
 // on (g, h) -> (sqrt q, 1 / (2 sqrt q)) and one correction of g -- 12 instructions against the 19 + 5 of sqrt and the reciprocal
 MPC_HD void mpc_sqrt_rcp(double q, double& r, double& ir) {
-#if defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH && !(MPC_XP & 32)
+#if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(q);
     double g = q * y, h = 0.5 * y;
     double e = fma(-h, g, 0.5);
@@ -464,10 +453,10 @@ MPC_HD void mpc_sqrt_rcp(double q, double& r, double& ir) {
 // theta^s_theta / (-dphi)^s_phi of the switching condition and of alpha_min (Waechter & Biegler eq. (19), (23)): one exp of two logs on
 // the device (the two pow cost ~420 instructions); 0 for theta = 0
 MPC_HD double mpc_switch_ratio(double theta, double mdphi) {
-#if defined(__HIP_DEVICE_COMPILE__) && MPC_FAST_MATH && !(MPC_XP & 2)
+#if defined(__HIP_DEVICE_COMPILE__)
     return exp(S_THETA * log(theta) - S_PHI * log(mdphi));
 #else
-    return mpc_pow(theta, S_THETA) / mpc_pow(mdphi, S_PHI);
+    return pow(theta, S_THETA) / pow(mdphi, S_PHI);
 #endif
 }
 
@@ -649,6 +638,34 @@ struct Ctx {
     // --- pieces of the condensed gradient held across the KKT-error reduction (gx = gx_a + mu * gx_b)
     double gxa[NX], gxb[NX], gua[2], gub[2];
 };
+
+// The caller's row of an instance (optimizer.py:550 order: [u_0 .. u_{N-1} | x_0 .. x_N]), written by the instance's own stage threads -- every
+// one its two inputs and NX states -- when the status becomes final; the stage-0 thread adds status, iteration count and KKT error.
+struct EmitDst { double* x_out; int32_t* status_out; int32_t* iters_out; double* kkt_out; uint32_t* fail_count; };
+MPC_HD EmitDst emit_dst(const Params& P) { return EmitDst{P.x_out, P.status_out, P.iters_out, P.kkt_out, P.fail_count}; }
+template <int NX>
+MPC_HD void emit_row(const EmitDst& d, const int N, const int b, const int k, const double* z, const int status, const int iters, const double e0) {
+    const uint32_t nw = (uint32_t)(2 * N + NX * (N + 1)), row = (uint32_t)b * nw;
+    if (k < N) { MPC_GP(d.x_out, row + 2u * (uint32_t)k) = z[0]; MPC_GP(d.x_out, row + 2u * (uint32_t)k + 1u) = z[1]; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) MPC_GP(d.x_out, row + (uint32_t)(2 * N + NX * k + i)) = z[2 + i];
+    if (k == 0) {
+        if (d.status_out) MPC_GP(d.status_out, b) = status;
+        if (d.iters_out) MPC_GP(d.iters_out, b) = iters;
+        if (d.kkt_out) MPC_GP(d.kkt_out, b) = e0;
+        if (d.fail_count != nullptr && (status == 0 || status == -7)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __hip_atomic_fetch_add(d.fail_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            ++*d.fail_count;
+#endif
+        }
+    }
+}
+template <int NX>
+MPC_HD void emit_result(const PRef& P, const Ctx<NX>& c, const int status, const int iters, const double e0) {
+    emit_row<NX>(emit_dst(P), P.N, c.b, c.k, c.z, status, iters, e0);
+}
 
 // ---- two threads per (instance, stage): the ROLE template parameter of the phases ---------------------------------------
 // ROLE_ALL  one thread does all the work of its (instance, stage) -- k_stage, the start-iterate kernel, the emulation harness
@@ -1102,16 +1119,7 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
         // every load is issued before anything is consumed: one memory round trip for all per-instance scalars
         status = MPC_S(P.ISC, IS_STATUS); nfilt = MPC_S(P.ISC, IS_NFILT); iters = MPC_S(P.ISC, IS_ITERS);
         convf = MPC_S(P.ISC, IS_CONV); frow = MPC_S(P.ISC, IS_FROW); haveth0 = MPC_S(P.ISC, IS_HAVETH0);
-#if (MPC_EXP_PAIR & 16384) && defined(__HIP_DEVICE_COMPILE__)
-        {   // (experiment: mu and tau with agent-scope loads -- sc1: not served from this CU's L1)
-            const WsRefD rm = MPC_S(P.SC, SC_MU), rt = MPC_S(P.SC, SC_TAU);
-            mu = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(P.rws, (int)rm.voff, mpc_uni(rm.aoff + rm.uoff), 16));
-            tau = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(P.rws, (int)rt.voff, mpc_uni(rt.aoff + rt.uoff), 16));
-        }
-        df = MPC_S(P.SC, SC_DF); theta = MPC_S(P.SC, SC_THETA);
-#else
         mu = MPC_S(P.SC, SC_MU); tau = MPC_S(P.SC, SC_TAU); df = MPC_S(P.SC, SC_DF); theta = MPC_S(P.SC, SC_THETA);
-#endif
         fcost = MPC_S(P.SC, SC_FCOST); logsum = MPC_S(P.SC, SC_LOGSUM);
         thmax = MPC_S(P.SC, SC_THMAX); thmin = MPC_S(P.SC, SC_THMIN);
         a0lb = MPC_S(P.SC, SC_A0LB); a0ub = MPC_S(P.SC, SC_A0UB);
@@ -1440,6 +1448,8 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
         if (MPC_RA && k == 0) { MPC_SCW(ISC, IS_STATUS, STATUS, c.status); MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
+        // (the iterate the search started from; MB -- k_solve_wg -- writes the rows of an instance when it leaves the workgroup's mask)
+        if (!MB && ROLE == ROLE_ALL && P.emit) emit_result<NX>(P, c, c.status, c.iters, k == 0 ? (double)MPC_S(P.SC, SC_E0) : 0.0);
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
@@ -1932,45 +1942,17 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         }
     }
     c.status = status;
+    if (!MB && ROLE == ROLE_ALL && P.emit && status != ST_RUNNING) emit_result<NX>(P, c, status, c.iters, E0);
     if (MPC_RA && k == 0) {
-#if (MPC_EXP_PAIR & 2) && defined(__HIP_DEVICE_COMPILE__)
-        // (experiment: neighbouring scalar rows of an instance with one 16-byte store)
-        static_assert(SC_MU % 2 == 0 && SC_TAU == SC_MU + 1 && SC_FCOST % 2 == 0 && SC_LOGSUM == SC_FCOST + 1, "row pairs");
-        if (MPC_EXP_PAIR & 1024) { MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum); MPC_STORE_FENCE(); }
-        if (MPC_EXP_PAIR & 512) { MPC_S(P.SC, SC_TAU) = tau; MPC_STORE_FENCE(); }
-        if (MPC_EXP_PAIR & 32) { double m_ = mu, t_ = tau; asm volatile("" : "+v"(m_), "+v"(t_)); MPC_ST2(MPC_S(P.SC, SC_MU), m_, t_); }
-        else if (MPC_EXP_PAIR & 2048) { }
-        else if (MPC_EXP_PAIR & (4096 | 8192)) {
-            // the 16-byte store only in the start iterate's finish (4096) / only in the loop's (8192); 8-byte stores otherwise
-            const bool first = c.iters == 0;
-            if (((MPC_EXP_PAIR & 4096) != 0) == first) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
-            else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
-        }
-        else if (!(MPC_EXP_PAIR & 16)) MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
-        else { MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
-        if (MPC_EXP_PAIR & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MPC_S(P.SC, SC_MU) = mu; MPC_STORE_FENCE(); MPC_S(P.SC, SC_TAU) = tau; }
-        if (MPC_EXP_PAIR & 128) { MPC_S(P.SC, SC_TAU) = tau; }
-        if (MPC_EXP_PAIR & 256) { MPC_S(P.SC, SC_MU) = mu; }
-        if (MPC_EXP_PAIR & 1024) { }
-        else if (!(MPC_EXP_PAIR & 8)) MPC_ST2(MPC_S(P.SC, SC_FCOST), red.fcost, red.logsum);
-        else { MPC_S(P.SC, SC_FCOST) = red.fcost; MPC_STORE_FENCE(); MPC_S(P.SC, SC_LOGSUM) = red.logsum; }
-        if (MPC_EXP_PAIR & 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        if (MB) { c.scl[WgScl::MU] = mu; c.scl[WgScl::TAU] = tau; c.scl[WgScl::FCOST] = red.fcost; c.scl[WgScl::LOGSUM] = red.logsum; }
-        MPC_SCW(SC, SC_THETA, THETA, red.theta);
-#else
         MPC_SCW(SC, SC_MU, MU, mu);
         MPC_SCW(SC, SC_TAU, TAU, tau);
         MPC_SCW(SC, SC_THETA, THETA, red.theta);
         MPC_SCW(SC, SC_FCOST, FCOST, red.fcost);
         MPC_SCW(SC, SC_LOGSUM, LOGSUM, red.logsum);
-#endif
         MPC_S(P.SC, SC_E0) = E0;
         MPC_SCW(ISC, IS_STATUS, STATUS, status);
         if (mu_changed) MPC_SCW(ISC, IS_NFILT, NFILT, 0);       // the filter is reset whenever mu changes
         if (P.fixed_iters > 0 && E0 <= P.tol) MPC_SCW(ISC, IS_CONV, CONV, 1);
-#if (MPC_EXP_PAIR & 2048) && defined(__HIP_DEVICE_COMPILE__)
-        MPC_STORE_FENCE(); MPC_ST2(MPC_S(P.SC, SC_MU), mu, tau);
-#endif
     }
 }
 
@@ -2024,14 +2006,7 @@ MPC_HD double sym(const double* Ps, int i, int j) { return Ps[(i <= j) ? Dim<NX>
 // writes them as 16-byte row pairs once both halves are done -- a global store holds the issuing wave for ~25-30 cycles
 // whatever its width (tools/ubench/store_cost.hip), so 21 wide stores cost half of 41 narrow ones.
 // a b + c d with the fused operation spelled out (which of the two products the compiler fuses is otherwise its choice, per instantiation)
-#ifndef MPC_FMA2_ORDER
-#define MPC_FMA2_ORDER 0
-#endif
-#if MPC_FMA2_ORDER == 0
 #define MPC_FMA2(a, b, c, d) fma((a), (b), (c) * (d))
-#else
-#define MPC_FMA2(a, b, c, d) fma((c), (d), (a) * (b))
-#endif
 template <int NX>
 struct RicGain {
     double G0[NX], G1[NX], i00, i01, i11;       // G = B'(P+ A) (+ Hux at stage 0), Lam^-1
@@ -2206,15 +2181,8 @@ MPC_HD void ric_store_stage(const PRef& P, uint32_t bb, int k, const double* Ps,
     for (int i = 0; i < D::NS; ++i) pk[i] = Ps[i];
 #pragma unroll
     for (int i = 0; i < NX; ++i) pk[D::NS + i] = pv[i];
-    // (measurement aid, profiles/r04_riccati_chain.txt: -DMPC_RIC_STORE_VARIANT=1 stores the gains only, =2 nothing -- wrong results, the
-    //  time of the sweep without its stores; never defined in a product build)
-#if !defined(MPC_RIC_STORE_VARIANT) || MPC_RIC_STORE_VARIANT < 2
     ws_store_rows<D::NKK>(MPC_ROWS(MPC_UK(P.KK, D::NKK, k, e)), kk);
-#endif
-#if !defined(MPC_RIC_STORE_VARIANT) || MPC_RIC_STORE_VARIANT < 1
     ws_store_rows<D::NPK>(MPC_ROWS(MPC_UK(P.PK, D::NPK, k, e)), pk);
-#endif
-    (void)kk; (void)pk;
 }
 
 // both halves on one thread: consumes stage block `s`, updates (Ps, pv) IN PLACE, stores gains and cost-to-go
@@ -2339,7 +2307,7 @@ MPC_HD void riccati_instance(const PRef& P, int b) {
         else delta *= (delta_last == 0.0) ? KW_PLUS_BAR : KW_PLUS;
         if (delta > DW_MAX) break;
     }
-    if (!ok) { MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7; return; }
+    if (!ok) { MPC_U(P.ISC, (uint32_t)IS_STATUS) = P.emit ? ST_SWEEP_FAILED : -7; return; }
     if (delta > 0.0) MPC_U(P.SC, (uint32_t)SC_DLAST) = delta;
     MPC_U(P.SC, (uint32_t)SC_DELTA) = delta;
     // forward sweep (same software pipeline)

@@ -162,14 +162,14 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 
 // the variables that carry bounds in the reference's NLP (optimizer.py:421-491: steering rate, acceleration, steering angle, speed):
 // the pair kernels are instantiated for this mask (a handle whose bounds touch other variables runs one thread per stage)
-constexpr uint32_t PAIR_VM = 0x33u;
+constexpr uint32_t REF_BOUND_VM = 0x33u;
 // variant 2 of k_pipeline / k_solve_wg: that mask, the bounds of its variables at every stage, circle rows with a lower bound only and
 // multiplicity 3, one obstacle per batch -- the structure of every NLP the reference builds
 constexpr uint32_t REF_DENSE_LO = 0x31u, REF_DENSE_HI = 0x33u;      // (no lower bound on the acceleration)
 #ifndef MPC_REF_FLAGS
 #define MPC_REF_FLAGS (VM_OSPEC | vm_dense(REF_DENSE_LO, REF_DENSE_HI))
 #endif
-constexpr uint32_t REF_VM = PAIR_VM | MPC_REF_FLAGS;
+constexpr uint32_t REF_VM = REF_BOUND_VM | MPC_REF_FLAGS;
 // One stage workgroup's share of an iteration: the bx instance columns starting at b0.  `tile_bits` is the activity mask
 // of b0's tile (bit l: instance l was iterating when the last Riccati sweep started); a block without such an instance
 // leaves before touching HBM.  Called once per launch by k_stage and once per work item by k_pipeline.
@@ -220,6 +220,11 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         phase_preload<NX, false, ROLE_ALL, VM>(P, c, tmp);           // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
+        // (launches that write the caller's rows themselves: an instance the Riccati sweep has just given up leaves here -- its iterate is in c.z)
+        if (P.emit && c.valid && c.status == ST_SWEEP_FAILED) {
+            emit_result<NX>(P, c, -7, c.iters, c.k == 0 ? (double)MPC_S(P.SC, SC_E0) : 0.0);
+            if (c.k == 0) MPC_S(P.ISC, IS_STATUS) = -7;
+        }
         // (the bounds table is read from here on: a block that has just copied it passes a barrier -- behind its loads, which are in flight;
         //  a persistent stage worker that copied it for an earlier item has nothing to wait for)
         if (!bounds_in_lds) lds_barrier();
@@ -392,133 +397,6 @@ __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int
 #undef MPC_STAMP
 }
 
-#ifndef MPC_WITH_PAIR
-#define MPC_WITH_PAIR 0     // 1: also build variant 1 of k_pipeline / k_solve_wg (two threads per (instance, stage), option pair) -- measured 40-70 % slower
-#endif                      //    (profiles/r04_stage_split.txt); kept as source for the record, not part of the default library
-#if MPC_WITH_PAIR
-// ---------------------------------------------------------------------------------------------------------------
-// stage_pair: the same share of an iteration as stage_block<NX, false>, with TWO threads per (instance, stage) -- the model thread
-// (ROLE_A: threads [0, T) of the workgroup) and the barrier thread (ROLE_B: threads [T, 2 T)); T is a multiple of 64, so the role is
-// wave-uniform and each role is its own instruction stream.  Why: a stage thread of stage_block executes ~10 k instructions per
-// iteration at 450+ registers, ONE wavefront per SIMD -- and a SIMD issues at most one instruction per wavefront and 4-cycle turn,
-// whatever its kind (fp64, moves, the 2.7 k scalar instructions of address / exec-mask bookkeeping, LDS, waits).  Half the state per
-// thread fits 256 registers, two wavefronts share a SIMD, and the scalar / LDS / memory instructions of one issue under the fp64
-// instructions of the other (tools/ubench/issue_mix.hip).  The pair meets in the reductions the phases have anyway and hands over
-// once per iteration through LDS, in front of a barrier that is there already: what the inequality rows add to the condensed
-// system, B -> A, before the neighbour exchange (IneqOut of mpc_stage_math.h).
-// LDS (doubles): [reduction scratch (waves x 10 x bx) | bounds table 2 nb | neighbour exchange 2 NX x T | IneqOut (3 NZ + 15) x T]
-// ---------------------------------------------------------------------------------------------------------------
-template <int NX> __host__ __device__ constexpr int pair_rows() { return 2 * NX + 3 * (NX + 2) + 15; }
-template <int NX, bool MB, int ROLE>
-__device__ __forceinline__ void stage_pair_role(const PRef& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits,
-                                                double* lds, int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
-    constexpr int NZ = NX + 2;
-    constexpr uint32_t VM = PAIR_VM;
-    int or_parity = 0;
-    Ctx<NX> c;
-    const int bx = P.bx, t = threadIdx.x, tt = (ROLE == ROLE_B) ? t - T : t;
-    c.k = tt / bx;
-    c.b = (int)b0 + (tt & (bx - 1));
-    c.valid = (c.k <= P.N) && (c.b < P.B);
-    c.active = false;
-    c.status = 0;
-    c.iters = 0;
-#define MPC_STAMP(i) do { if (P.DBG && t == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    MPC_STAMP(0);
-    {
-        const unsigned long long m = tile_bits >> (b0 & 63u);
-        if ((m & ((bx >= 64) ? ~0ull : ((1ull << bx) - 1ull))) == 0ull) return;
-    }
-    double* lds_b = lds + (blockDim.x >> 6) * 10 * bx;
-    const int nb = (P.N + 1) * NZ;
-    double* lds_x = lds_b + 2 * nb;
-    double* lds_k = lds_x + 2 * NX * T;
-    if (!bounds_in_lds)
-        fill_bounds<2>(P, lds_b, nb, t, (int)blockDim.x);
-    c.bnd = (mpc_lds_cptr)(lds_ptr_t)lds_b;
-    c.bnd_ub = nb;
-    phase_load_scalars<NX>(P, c);
-    {
-        PreTmp<NX> tmp;
-        phase_preload<NX, MB, ROLE, VM>(P, c, tmp);      // every array load of the item is in flight before the first wait
-        phase_premath<NX, ROLE>(P, c, tmp);
-    }
-    MPC_STAMP(1);
-    if (!block_or(c.active ? 1 : 0, or_slots, or_parity)) return;
-    MPC_STAMP(2);
-    Red1 r1;
-    phase_step_candidates<NX, ROLE, VM>(P, c, r1);
-    MPC_STAMP(3);
-    block_reduce(r1, bx, lds);
-    phase_linesearch_begin<NX>(P, c, r1);
-    MPC_STAMP(4);
-    while (block_or((c.active && c.searching) ? 1 : 0, or_slots, or_parity)) {
-        Red2 r2;
-        phase_trial_eval<NX, ROLE, VM>(P, c, r2);
-        block_reduce(r2, bx, lds);
-        phase_linesearch_decide<NX>(P, c, r2);
-    }
-    MPC_STAMP(5);
-    phase_apply_update<NX, MB, ROLE, VM>(P, c);
-    MPC_STAMP(6);
-    // the hand-over of the pair: one LDS column per pair, rows of IneqRows (put by B, read by A behind the second barrier -- one row
-    // at a time, so that neither thread holds the values at once)
-    struct LdsCol {
-        double* col; int T;
-        __device__ __forceinline__ void put(int r, double x) { col[r * T] = x; }
-        __device__ __forceinline__ double get(int r) const { return col[r * T]; }
-    } xk{lds_k + tt, T};
-    Red3 r3;
-    if (ROLE == ROLE_A) {
-        // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { lds_x[i * T + tt] = c.z[2 + i]; lds_x[(NX + i) * T + tt] = c.lam[i]; }
-        lds_barrier();
-        const int tn = tt + bx;
-        if (tn < T) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { c.xn[i] = lds_x[i * T + tn]; c.lamn[i] = lds_x[(NX + i) * T + tn]; }
-        }
-        MPC_STAMP(7);
-        EvalTmp<NX> et;
-        phase_eval_model<NX, true, ROLE_A, false, VM>(P, c, et, kkt_part_neutral());
-        lds_barrier();                                   // the inequality thread's rows are in LDS
-        phase_eval_finish<NX, MB, ROLE_A, LdsCol, VM>(P, c, r3, xk, et);
-    } else {
-        lds_barrier();
-        KktPart kp;
-        phase_ineq_assemble<NX, true, LdsCol, ROLE_B, VM>(P, c, xk, kp, psi_trig(c.z[2 + 4]));
-        lds_barrier();
-        phase_eval_red_b(c.active, r3, kp);
-    }
-    MPC_STAMP(8);
-    block_reduce(r3, bx, lds);
-    MPC_STAMP(9);
-    phase_finish<NX, MB, ROLE>(P, c, r3, n_mult, n_z);
-    MPC_STAMP(10);
-    if (ROLE == ROLE_A) {
-        if (live_out != nullptr && t < 64) {
-            const unsigned long long m = __ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0);
-            if (t == 0) *live_out = (uint32_t)m;
-        }
-        if (P.run_counter != nullptr && t < 64) {
-            const int cnt = __popcll(__ballot((c.valid && c.k == 0 && c.active && c.status == ST_RUNNING) ? 1 : 0));
-            if (t == 0 && cnt) atomicAdd(P.run_counter, cnt);
-        }
-    }
-#undef MPC_STAMP
-}
-template <int NX, bool MB>
-__device__ __forceinline__ void stage_pair(const PRef& P, const int n_mult, const int n_z, const uint32_t b0, const unsigned long long tile_bits, double* lds,
-                                           int (*or_slots)[8], const bool stamp, uint32_t* live_out, const bool bounds_in_lds, const int T) {
-    // (wave-uniform, and visibly so: a scalar branch, not an exec mask)
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < T) stage_pair_role<NX, MB, ROLE_A>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
-    else stage_pair_role<NX, MB, ROLE_B>(P, n_mult, n_z, b0, tile_bits, lds, or_slots, stamp, live_out, bounds_in_lds, T);
-}
-
-#else
-template <int NX> __host__ __device__ constexpr int pair_rows() { return 0; }
-#endif
 // VM: bound structure compiled into the phases (0xFF: looked up at run time; REF_VM: the reference's -- every path of a handle uses the
 // same instantiation of the phases, so that the pipeline, its fallback of one launch per kernel and the closed loop's replay give the same bits)
 template <int NX, bool INIT, int MAXT, uint32_t VM = 0xFFu>
@@ -633,7 +511,10 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
         const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)src_), dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst_);
 #pragma unroll
         for (int c = 0; c < nchunks; ++c)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + dst + (uint32_t)c * 1024u), 16, lane * 16, (int)(src + (uint32_t)c * 1024u), 0, 0);
+        {   // (P.xcu: the rows were written by stage workers on other CUs of this XCD in this launch -- sc1, past this CU's vector L1; see DevParams)
+            if (P.xcu) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + dst + (uint32_t)c * 1024u), 16, lane * 16, (int)(src + (uint32_t)c * 1024u), 0, MPC_AUX_SC1);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + dst + (uint32_t)c * 1024u), 16, lane * 16, (int)(src + (uint32_t)c * 1024u), 0, 0);
+        }
     };
     // row r of an LDS image that starts at `off` (the DMA copies the row pairs verbatim)
     auto lds_r = [&](uint32_t off, uint32_t r) { return *reinterpret_cast<const double*>(smem + off + mpc_prow(r) * 8u + (uint32_t)lane * 16u); };
@@ -756,7 +637,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
             if (kn < N && (kn & 1) == par) dma_fwd(kn, (uint32_t)(kn % RIC_DEPTH_F) * FSLOT);
         }
     } else {
-        if (active && failed) MPC_U(P.ISC, (uint32_t)IS_STATUS) = -7;
+        if (active && failed) MPC_U(P.ISC, (uint32_t)IS_STATUS) = P.emit ? ST_SWEEP_FAILED : -7;
         if (go) {
             if (delta > 0.0) MPC_U(P.SC, (uint32_t)SC_DLAST) = delta;
             MPC_U(P.SC, (uint32_t)SC_DELTA) = delta;
@@ -864,10 +745,7 @@ __host__ __device__ inline size_t pipe_ctl_words(uint32_t ntiles, uint32_t cap) 
 __device__ __forceinline__ void pipe_acquire(bool l1_only) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (l1_only) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#if !defined(MPC_EXP_NOINV)        // (experiment of profiles/r05_store_pairing.txt: the hand-offs without any invalidate)
-        asm volatile("buffer_inv sc0" ::: "memory");
-#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (compiler ordering only: every workspace load of the kernel is an sc1 load)
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -908,14 +786,14 @@ __global__ void k_xcd_census(uint32_t* mask) {
 
 // PAIR: the stage workers run two threads per (instance, stage) (stage_pair: 512-thread workgroups, two wavefronts per SIMD)
 // VAR: 0 one thread per (instance, stage), bounds looked up at run time; 1 two threads per (instance, stage) (stage_pair); 2 one thread per
-// stage with the bound structure of the reference compiled in (PAIR_VM: only steering rate, acceleration, steering angle and speed carry
+// stage with the bound structure of the reference compiled in (REF_BOUND_VM: only steering rate, acceleration, steering angle and speed carry
 // bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
 // HELP: the Riccati workers take a stage item while their tile is with the stage workers (below) -- a variant of its own: the extra code in the
 // Riccati worker's loop costs the sweeps of the default kernel 3.5 % through its register allocation, and only batches whose stage items outnumber
 // the stage workers three to one gain from it (N = 50: 16 items per tile)
 template <int NX, int VAR, bool HELP = false>
 __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params Pk, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
-    const PRef P(Pk);
+    const PRef P = mpc_pref(Pk, true);  // (xcu: rows travel between the CUs of an XCD inside this launch -- every workspace load is an sc1 load)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
@@ -964,7 +842,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                     const unsigned long long t0 = wall_clock64();
                     while (pipe_ld(stage_done + tile) < need) {
                         if (pipe_ld(abort_w)) { ok = 0u; break; }
-                        if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); ok = 0u; break; }
+                        if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, (tile << 16) | (round & 0xFFFFu)); pipe_st(abort_w + 23, pipe_ld(stage_done + tile)); pipe_st(abort_w, 2u); ok = 0u; break; }
                         __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
                     }
                     waited += wall_clock64() - t0;
@@ -1031,7 +909,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                                     const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     if ((uint32_t)(v >> 32) == hd + 1u) { item = (uint32_t)v; break; }
                                     if (pipe_ld(abort_w)) break;
-                                    if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); break; }
+                                    if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, hd); pipe_st(abort_w + 23, pipe_ld(X + 32)); pipe_st(abort_w, 3u); break; }
                                     __builtin_amdgcn_s_sleep(1);
                                 }
                                 if (item != PIPE_EXIT) {
@@ -1081,7 +959,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(v >> 32) == tk + 1u) { item = (uint32_t)v; break; }
                 if (pipe_ld(X + 48) >= n_tiles_x || pipe_ld(abort_w)) break;             // every tile of this XCD is finished: nothing can arrive
-                if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w, 1u); break; }
+                if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, tk); pipe_st(abort_w + 23, pipe_ld(X + 32)); pipe_st(abort_w, 4u); break; }
                 __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
             }
             const unsigned long long t1 = wall_clock64();
@@ -1104,10 +982,6 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
-#if MPC_WITH_PAIR
-        if (VAR == 1) stage_pair<NX, false>(P, n_mult, n_z, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds, (int)(blockDim.x >> 1));
-        else
-#endif
         stage_block<NX, false, 256, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, tile * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, n_pass == 5u, nullptr, have_bounds);
         // (an item whose instance columns have all finished leaves stage_block before the copy)
         have_bounds = have_bounds || ((bits >> (((item & 255u) * (uint32_t)P.bx) & 63u)) & ((P.bx >= 64) ? ~0ull : ((1ull << P.bx) - 1ull))) != 0ull;
@@ -1171,8 +1045,9 @@ template <int NX, class Src = PrestartFromWs> __device__ __forceinline__ void pr
 // restart of the instance of a one-instance workgroup of k_solve_wg at a level of its second chance: warm start -> tile-major Z, start-point
 // safeguard, start iterate (what k_start does for a block) -- see k_solve_wg<.., RESC>
 template <int NX>
-__device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0, double* lds,
+__device__ __attribute__((noinline)) void wg_restart(const PRef& Pin, const int n_mult, const int n_z, const int stash_rows, const uint32_t b0, double* lds,
                                                      int (*or_slots)[8], uint32_t* live_out, const bool carry, const bool from_xs, const bool keep_first, const bool first_tiled) {
+    const PRef P = mpc_pref(static_cast<const Params&>(Pin), false);      // (a copy in registers, its cache policy a literal again: the reference points into the caller's stack)
     using D = Dim<NX>;
     const int t = threadIdx.x, N = P.N, bx = P.bx;
     struct { int b, k, mb, bl; } c;
@@ -1230,7 +1105,8 @@ __device__ __attribute__((noinline)) void wg_restart(const PRef& P, const int n_
 // every level of the second chance has failed: the instance goes back to the caller as its FIRST attempt left it (row, status, iteration
 // count, KKT error) -- what rescue_dev does by writing back converged rows only
 template <int NX>
-__device__ __attribute__((noinline)) void wg_restore_first(const PRef& P, const uint32_t b0, const int st0, const int it0) {
+__device__ __attribute__((noinline)) void wg_restore_first(const PRef& Pin, const uint32_t b0, const int st0, const int it0) {
+    const PRef P = mpc_pref(static_cast<const Params&>(Pin), false);
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     const int t = threadIdx.x, bx = P.bx;
@@ -1273,11 +1149,33 @@ struct WgLds {
     static constexpr int PAD = Rec<NX>::SIZE > 64 ? Rec<NX>::SIZE : 64;
     __host__ __device__ static constexpr size_t doubles(int S, int bxw) { return (size_t)PAD + (size_t)Rec<NX>::SIZE * S * bxw + (size_t)2 * S * (NX + 2) + (size_t)16 * bxw + (size_t)64 * NX + (size_t)WgScl::SIZE * bxw; }
 };
-template <int NX, int VAR, bool RESC = false>
-__global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
-                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
+// k_solve_wg: the caller's output pointers (and the pointers of its epilogue) are read from the kernel-argument segment WHERE THEY ARE USED -- behind
+// an opaque copy of the segment pointer, so that the compiler does not load them at the kernel's entry and carry ten scalar registers through the
+// rounds (the stage phases run at 450+ vector registers with ~400 scalar values spilled into lanes; with the pointers live the kernel went from 456
+// to 469 registers and onto scratch).  Params is the kernel's first argument: offset 0 of the segment.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) Params* mpc_kernarg_params;
+__device__ __forceinline__ mpc_kernarg_params wg_kernarg() {
+    mpc_kernarg_params kp = (mpc_kernarg_params)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+__device__ __forceinline__ EmitDst wg_emit_dst() {
+    const mpc_kernarg_params kp = wg_kernarg();
+    return EmitDst{kp->x_out, kp->status_out, kp->iters_out, kp->kkt_out, kp->fail_count};
+}
+#else
+inline EmitDst wg_emit_dst() { return EmitDst{}; }
+#endif
+template <int NX, int VAR, bool RESC>
+__device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
+                                              const WgRescue& resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
     PRef P(Pk);                                   // (RESC: ol and tol of the level an instance is at)
 #if defined(__HIP_DEVICE_COMPILE__)
+    // RESC + emit: the row that counts is the one the instance ends with after all its levels (an intermediate level converges to a relaxed problem,
+    // a failed pass gives the first attempt's row back): written once, when the workgroup leaves -- not by the phases
+    const bool emit_exit = RESC && resc.on && Pk.emit != 0;
+    if (RESC && emit_exit) P.emit = 0;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
     __shared__ uint32_t sh_mask;
@@ -1341,10 +1239,10 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
     WgIo io{0u, 0u, lds_c0, lds_rn, lds_r0, lds_scl, true, false};
     const MfmaWords lane_words = mfma_lane_load<NX>(lane);
 #define WG_STAMP(i) do { if (P.DBG && t == 0 && rounds == 3u) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    uint32_t rounds = 0, sweeps = 0, inst_rounds = 0;
+    uint32_t rounds = 0, sweeps = 0, inst_rounds = 0, prev_mask = 0u;
     const unsigned long long t_begin = wtrace ? wall_clock64() : 0ull;        // (option wg_trace: when did this workgroup start, how long did it run, how many rounds)
     unsigned long long t_fresh = 0ull, t_round1 = 0ull;                        // (... when were its instances taken over, when was its first round done)
-    if (RESC && resc.on && t == 0 && (int)b0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, (int)b0) = 0;       // the first attempt
+    if (RESC && resc.on && t == 0 && ib0 >= 0 && ib0 < P.B) MPC_UB(P.ISC, (uint32_t)IS_RLEV, ib0) = 0;       // the first attempt (ib0: with one instance per workgroup, THE instance -- b0 only without a list)
     for (;;) {
         // ---- which of my instances are iterating: the status rows of the workspace in the first round; after that stage_block has
         //      left the mask in sh_mask (an instance the sweeps gave up on is inactive there: phase_load_scalars reads its status)
@@ -1357,13 +1255,28 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         }
         lds_barrier();
         const uint32_t mask = sh_mask;
+        // ---- launches that write the caller's rows themselves (Params::emit): an instance that has just left the mask -- converged, out of iterations,
+        //      stalled, given up by the sweeps -- goes out now, from the rows and scalars its last round left in memory (this wavefront's own stores,
+        //      drained at the end of that round).  Here and not in the phases: they run at 450+ registers, this is six loads and stores per lane.
+        if (Pk.emit != 0 && !emit_exit) {
+            const uint32_t gone = prev_mask & ~mask;
+            if (gone != 0u && valid && ((gone >> c.bl) & 1u)) {
+                double z[MPC_EV(D::NZ)];
+                ws_load_rows<D::NZ>(MPC_ROWS(MPC_KI(P.MZ, D::NZ, 0, e)), z);
+                int st = 0, it = 0;
+                double e0 = 0.0;
+                if (c.k == 0) { st = (int32_t)MPC_S(P.ISC, IS_STATUS); it = (int32_t)MPC_S(P.ISC, IS_ITERS); e0 = MPC_S(P.SC, SC_E0); }
+                emit_row<NX>(wg_emit_dst(), N, c.b, c.k, z, st, it, e0);
+            }
+            prev_mask = mask;
+        }
         if (mask == 0u) {
             if (!RESC || !resc.on) break;
             // ---- the instance of this workgroup has stopped: is a (further) level of the second chance due?
             if (t == 0) {
-                const int bb = (int)b0;
+                const int bb = ib0;
                 int next = -1, carry = 0;
-                if (bb < P.B) {
+                if (bb >= 0 && bb < P.B) {
                     const int st = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_STATUS, bb), it = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ITERS, bb);
                     const int lev = (int32_t)MPC_UB(P.ISC, (uint32_t)IS_RLEV, bb);
                     const int q = lev & 0xFF;
@@ -1395,7 +1308,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
             if (nx_lev <= -2) {
                 const int code = -2 - nx_lev;
                 const PRef Pc = P;
-                wg_restore_first<NX>(Pc, b0, (code & 1) ? -7 : 0, code >> 1);
+                wg_restore_first<NX>(Pc, (uint32_t)ib0, (code & 1) ? -7 : 0, code >> 1);
             }
             if (nx_lev < 0) break;
             const int q = nx_lev & 0xFF;
@@ -1410,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
                 // (out of line, on a copy of the parameters: the start-point safeguard and the start iterate inlined here put the hot loop at 512
                 //  registers with scratch -- B = 256 lane following paid 1.7 % for a path it never takes)
                 const PRef Pc = P;
-                wg_restart<NX>(Pc, n_mult, n_z, stash_rows, b0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
+                wg_restart<NX>(Pc, n_mult, n_z, stash_rows, (uint32_t)ib0, lds, or_slots, &sh_mask, carry != 0, from_xs, q == 1, rounds == 0u);
             }
             fresh = true;
             bounds_ok = false;
@@ -1583,11 +1496,22 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         if (wtrace != nullptr && rounds == 1u) t_round1 = wall_clock64() - t_begin;
     }
 #undef WG_STAMP
-    // the iterate goes back to the tile-major rows k_egest reads (a workgroup that found nothing to do never moved it)
-    if (rounds > 0u && valid) {
+    // the iterate goes back to the tile-major rows k_egest reads (a workgroup that found nothing to do never moved it) -- unless the launch writes
+    // the caller's rows itself (Params::emit: the phases have, at the moment the status became final)
+    if (rounds > 0u && valid && !Pk.emit) {
         double v[D::NZ];
         ws_load_rows<D::NZ>(MPC_ROWS(MPC_KI(P.MZ, D::NZ, 0, e)), v);
         ws_store_rows<D::NZ>(MPC_ROWS(MPC_K(P.Z, D::NZ, 0, e)), v);
+    }
+    if (RESC && emit_exit && valid) {
+        // (one instance per workgroup: what it ends with -- the last level's row, or the first attempt's that wg_restore_first put back)
+        double z[MPC_EV(D::NZ)];
+        if (rounds > 0u) ws_load_rows<D::NZ>(MPC_ROWS(MPC_KI(P.MZ, D::NZ, 0, e)), z);
+        else ws_load_rows<D::NZ>(MPC_ROWS(MPC_K(P.Z, D::NZ, 0, e)), z);
+        int st = 0, it = 0;
+        double e0 = 0.0;
+        if (c.k == 0) { st = (int32_t)MPC_S(P.ISC, IS_STATUS); it = (int32_t)MPC_S(P.ISC, IS_ITERS); e0 = MPC_S(P.SC, SC_E0); if (st == ST_RUNNING) st = 0; }
+        emit_row<NX>(wg_emit_dst(), N, c.b, c.k, z, st, it, e0);
     }
     if (wtrace != nullptr && t == 0) {
         wtrace[blockIdx.x * 4 + 0] = t_begin;
@@ -1600,6 +1524,35 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
         atomicAdd(stats + 1, rounds);
         atomicAdd(stats + 2, sweeps);
         atomicAdd(stats + 3, inst_rounds);
+    }
+#endif
+}
+// Params::fin_ctl: the launch is the last of its solve -- the workgroup that leaves LAST copies the solve's statistics block (abort word, rounds,
+// counters of both loop kernels, instances that did not converge: PIPE_FIN_WORDS words at fin_ctl) into the handle's pinned host block (fin_host),
+// so that the host reads it when the stream has drained: no copy command, no kernel of its own behind the loop.  fin_ctl[PIPE_FIN_TICKET] counts the
+// workgroups that have left.
+constexpr uint32_t PIPE_FIN_WORDS = 24, PIPE_FIN_TICKET = 22;
+template <int NX, int VAR, bool RESC = false>
+__global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
+                                                                   const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
+    solve_wg_body<NX, VAR, RESC>(Pk, n_mult, n_z, stash_rows, stats, skip_if, resc, wtrace, list, list_n);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x < 64) {           // (one wavefront per workgroup)
+        const mpc_kernarg_params kp = wg_kernarg();
+        uint32_t* const ctl = kp->fin_ctl;
+        if (ctl == nullptr) return;
+        uint32_t tk = 0u;
+        if (threadIdx.x == 0) {
+            // (this workgroup's counters are agent-scope atomics: performed once acknowledged -- no cache write-back needed for the last workgroup to
+            //  read them with agent-scope loads; the caller's rows become visible with the end of the kernel)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tk = __hip_atomic_fetch_add(ctl + PIPE_FIN_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counted as gone
+        }
+        tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        if (tk == gridDim.x - 1u && threadIdx.x < PIPE_FIN_WORDS) {
+            const uint32_t v = __hip_atomic_load(ctl + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(kp->fin_host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 #endif
 }
@@ -1846,11 +1799,15 @@ __global__ void __launch_bounds__(1024) k_prestart_par(const Params Pk) {
 #ifndef MPC_KSTART_OCC
 #define MPC_KSTART_OCC 2
 #endif
+// zero_p / zero_n: the OTHER control block of the loop kernels, zeroed here for the next solve (the two blocks alternate: a solve in steady state has
+// no fill of its own anywhere on its stream)
 template <int NX>
-__global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(256, MPC_KSTART_OCC) k_start(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* zero_p, const uint32_t zero_n) {
     const PRef P(Pk);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int or_slots[2][8];
+    if (zero_p != nullptr && blockIdx.x == 0)
+        for (uint32_t q = threadIdx.x; q < zero_n; q += blockDim.x) zero_p[q] = 0u;
     uint32_t blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
     const uint32_t b0 = (blk + (uint32_t)P.tile0 * (64u / (uint32_t)P.bx)) * (uint32_t)P.bx;
@@ -2593,7 +2550,8 @@ struct mpc_handle {
     int loop_replayed = 0;              // the last closed loop had to be replayed with host synchronisation per step
     int rescued_last = 0;               // instances the last solve handed to the second chance (rescue_dev)
     bool in_rescue = false;             // rescue_dev is solving its levels: they get no second chance of their own
-    bool resc_in_kernel = false;        // the last solve ran k_solve_wg with the second chance inside (RESC): rescue_dev has nothing to add
+    bool resc_in_kernel = false;        // the last solve ran k_solve_wg with the second chance inside (RESC) over EVERY instance of the batch: rescue_dev has nothing to add
+    bool resc_ran = false;              // ... or at least over the instances the pipeline handed over (what stalled inside the pipeline is rescue_dev's)
     bool attr_set_fq = false;
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
@@ -2645,7 +2603,6 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
-    else if (n == "pair") { if (iv != 0 && value != nullptr && !MPC_WITH_PAIR) return MPC_ERR_INVALID; k.pair = value == nullptr ? 0 : (int)iv; }   // (variant 1 is only there in a -DMPC_WITH_PAIR=1 build)
     else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
     else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
     else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
@@ -2684,7 +2641,6 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
-    else if (n == "pair") *out = k.pair;
     else if (n == "fuse_start") *out = k.fuse_start;
     else if (n == "bound_mask") *out = k.bound_mask;
     else if (n == "rescue_wg") *out = k.rescue_wg;
@@ -3083,10 +3039,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-#if MPC_WITH_PAIR
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-#endif
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -3111,9 +3063,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (G < 1) G = 1;
         if (G > mpc_handle::MAX_GROUPS) G = mpc_handle::MAX_GROUPS;
     }
-    const bool pair_vm_ok = ((P.lo_mask | P.hi_mask) & ~PAIR_VM) == 0u;        // the pair kernels are compiled for the reference's bound structure
+    const bool ref_vm_ok = ((P.lo_mask | P.hi_mask) & ~REF_BOUND_VM) == 0u;    // bounds on the reference's four variables only
     // one thread per stage with the reference's bound structure compiled in (option bound_mask, default on): same arithmetic, same bits
-    const bool masked = kn.bound_mask != 0 && pair_vm_ok && (P.dense_mask & REF_DENSE_LO) == REF_DENSE_LO && ((P.dense_mask >> 8) & REF_DENSE_HI) == REF_DENSE_HI && P.has_ol && !P.has_ou && P.obst_mult == 3 && !P.per_inst_obst;
+    const bool masked = kn.bound_mask != 0 && ref_vm_ok && (P.dense_mask & REF_DENSE_LO) == REF_DENSE_LO && ((P.dense_mask >> 8) & REF_DENSE_HI) == REF_DENSE_HI && P.has_ol && !P.has_ou && P.obst_mult == 3 && !P.per_inst_obst;
     struct Group { int tile0, ntl, blk0, nblk, b0, b1; hipStream_t st; bool running; };
     Group grp[mpc_handle::MAX_GROUPS];
     for (int g = 0; g < G; ++g) {
@@ -3151,57 +3103,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (kn.poison_r0 < 0) fprintf(stderr, "[mpcgpu poison] rows of a tile: Z %zu ZL %zu ZU %zu SO %zu NUO %zu ZLO %zu ZUO %zu LAM %zu REF %zu DZ %zu PK %zu KK %zu BLK %zu ROLL %zu SC %zu FILT %zu OBST %zu end %zu\n",
                                       wl.Z, wl.ZL, wl.ZU, wl.SO, wl.NUO, wl.ZLO, wl.ZUO, wl.LAM, wl.REF, wl.DZ, wl.PK, wl.KK, wl.BLK, wl.ROLL, wl.SC, wl.FILT, wl.OBST, wl.rows);
     }
-    for (int g = 0; g < G; ++g) {
-        const Group& q = grp[g];
-        if (!q.running) continue;
-        Params Pg = P;
-        Pg.tile0 = q.tile0;
-        prof.begin(2, q.st);
-        const int n_w = 2 * d.N + NX * (d.N + 1);
-        // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
-        // stage-threads the scans need (otherwise the two-chain kernel)
-        const size_t lds_pre = prestart_doubles(NX, S, bx) * sizeof(double);
-        const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
-        // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
-        const size_t lds_red = (size_t)(threads / 64) * 10 * bx * sizeof(double);            // (stage_block's reduction scratch, in front of the safeguard's region)
-        const bool fused = lds_red + lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
-        if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
-        if (fused) {
-            // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
-            DevTmp t_sdbg;
-            if (kn.start_timing && !h->async_loop && G == 1 && hipMalloc(&t_sdbg.p, sizeof(unsigned long long) * 16 * (size_t)q.nblk) == hipSuccess) {
-                (void)hipMemsetAsync(t_sdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)q.nblk, q.st);
-                Pg.DBG = t_sdbg.as<unsigned long long>();
-            }
-            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_red + lds_pre + 16 + lds_in, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
-            if (Pg.DBG) {          // (option start_timing: shader-clock stamps of every workgroup of k_start; synchronises)
-                std::vector<unsigned long long> hd((size_t)16 * q.nblk);
-                if (hipStreamSynchronize(q.st) == hipSuccess && hipMemcpy(hd.data(), Pg.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                    const int order[16] = {11, 12, 13, 1, 2, 3, 4, 5, 6, 14, 15, 0, 7, 8, 9, 10};
-                    static const char* names[15] = {"rows->LDS", "Z/REF stores", "bounds+a0", "defects", "scan1", "tan+scan2", "sincos+scan3", "ROLL+sums", "decide", "fence", "enter", "init point+exchange", "eval+assemble", "reduce", "finish"};
-                    double acc[15] = {0};
-                    unsigned long long t0 = ~0ull, t1 = 0ull;
-                    for (int bq = 0; bq < q.nblk; ++bq) {
-                        const unsigned long long* r = hd.data() + (size_t)bq * 16;
-                        for (int j = 0; j < 15; ++j) acc[j] += (double)(long long)(r[order[j + 1]] - r[order[j]]);
-                        t0 = std::min(t0, r[11]); t1 = std::max(t1, r[10]);
-                    }
-                    fprintf(stderr, "[mpcgpu k_start timing, shader-clock ticks, mean over %d workgroups]", q.nblk);
-                    for (int j = 0; j < 15; ++j) fprintf(stderr, " %s=%.0f", names[j], acc[j] / q.nblk);
-                    fprintf(stderr, "; first start to last end %.0f\n", (double)(t1 - t0));
-                }
-                Pg.DBG = nullptr;
-            }
-        } else {
-            if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
-                hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
-            else
-                hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
-            launch_stage(q, true);
-        }
-        if (G > 1) prof.end(q.st);          // (one stream: the span stays open, the first kernel of the loop starts where it ends)
-    }
-
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     const int chunk = d.fixed_iters > 0 ? cap : 4;
     DevTmp t_trace, t_dbg, t_pdbg;
@@ -3257,7 +3158,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int32_t* wg_list = nullptr;                   // (behind the pipeline: the instances its retiring tiles left, see k_solve_wg)
     const uint32_t* wg_list_n = nullptr;
     int wg_grid = 0;
-    auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats) {
+    auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats, uint32_t* fin_ctl) {
         if (kn.wg_trace && !h->async_loop && !h->in_rescue) {
             n_wtrace = (B + bxw - 1) / bxw;
             if (hipMalloc(&t_wtrace.p, sizeof(unsigned long long) * 4 * (size_t)n_wtrace) == hipSuccess) {
@@ -3267,13 +3168,17 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         }
         Params Pw = P;
         Pw.bx = bxw;
+        Pw.fin_ctl = fin_ctl; Pw.fin_host = h->h_pipe;
         if (skip_if != nullptr) Pw.DBG = nullptr;         // (behind the pipeline: a stamp buffer of option pipe_timing is sized for the PIPELINE's workgroups)
         const int thr = 64;                        // (S * bxw <= 64: checked where the path is chosen)
         WgRescue rs{h->hp.ol_raw, BOUND_RELAX, 0};
         const dim3 grid(wg_grid > 0 ? wg_grid : (B + bxw - 1) / bxw);
         if (wg_resc(bxw)) {
             rs.on = 1;
-            h->resc_in_kernel = true;
+            h->resc_ran = true;
+            // (behind the pipeline the launch sees the instances on the hand-over lists only: one that stalled INSIDE the pipeline is on none of
+            //  them and keeps its status for rescue_dev)
+            h->resc_in_kernel = wg_list == nullptr;
             if (masked) hipLaunchKernelGGL((k_solve_wg<NX, 2, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
             else hipLaunchKernelGGL((k_solve_wg<NX, 0, true>), grid, dim3(thr), wg_lds(bxw), stream, Pw, h->hp.n_mult, h->hp.n_z, stash_rows, stats, skip_if, rs, d_wtrace, wg_list, wg_list_n);
         }
@@ -3323,11 +3228,109 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
-    if ((use_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4) || wg_only) {
+    // ---- which path serves the iteration loop (decided before anything is launched: the kernels of the loop write the caller's rows themselves)
+    uint32_t xcd_mask = h->xcd_mask;
+    if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
+        const uint32_t m = kn.pipe_xcd_mask & h->xcd_mask;
+        if (m) xcd_mask = m;
+    }
+    const int n_xcd = __builtin_popcount(xcd_mask);
+    const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
+    const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
+    int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
+    if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
+    // (threads >= 192: a stage item then covers at least six stages per wavefront and instance column -- the shapes the hand-off timing was measured on)
+    const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
+                          ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
+                          std::max(lds_bytes, ric_lds) <= lds_max;
+    const bool res_path = (use_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4) || wg_only;
+    const bool pipe_path = !res_path && eligible && !h->pipe_disabled && kn.pipeline;
+    // Both get a control block (abort word, round count, statistics of both loop kernels, count of instances that did not converge, hand-over
+    // lists' counters; the pipeline's queues behind them) -- one of two that alternate: the start kernel of a solve zeroes the other one for the
+    // next solve, the last workgroup of the loop copies the head of this one into the handle's pinned block.
+    uint32_t *ctl = nullptr, *zero_next = nullptr;
+    size_t ctl_words = 0;
+    bool next_zeroed = false;
+    uint32_t pipe_cap = 1;
+    if (res_path || pipe_path) {
+        while (pipe_path && pipe_cap < 2u * (64u / (uint32_t)bx) * (uint32_t)tiles_x) pipe_cap <<= 1;
+        ctl_words = pipe_ctl_words((uint32_t)ntiles, pipe_cap);
+        if (h->pipe_words < ctl_words) {
+            if (h->d_pipe) (void)hipFree(h->d_pipe);
+            h->d_pipe = nullptr; h->pipe_words = 0;
+            HIP_TRY(h, hipMalloc(&h->d_pipe, 2 * ctl_words * sizeof(uint32_t)));
+            h->pipe_words = ctl_words;
+            h->pipe_clean[0] = h->pipe_clean[1] = 0;
+        }
+        if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, PIPE_FIN_WORDS * sizeof(uint32_t)));
+        ctl = h->d_pipe + (size_t)h->pipe_flip * h->pipe_words;
+        zero_next = h->d_pipe + (size_t)(h->pipe_flip ^ 1) * h->pipe_words;
+        if (h->pipe_clean[h->pipe_flip] < ctl_words) HIP_TRY(h, hipMemsetAsync(ctl, 0, ctl_words * sizeof(uint32_t), stream));      // (first use, or a larger batch than the last)
+        h->pipe_clean[h->pipe_flip] = 0;
+        P.emit = 1;
+        // (instances that did not converge are counted into word 14 of the block; an asynchronous closed loop accumulates them over its steps in d_fail instead)
+        P.fail_count = h->async_loop ? h->d_fail : ctl + PIPE_ABORT + 14;
+    }
+    // ---- the front of the solve: caller's rows -> workspace, start-point safeguard, start iterate
+    for (int g = 0; g < G; ++g) {
+        const Group& q = grp[g];
+        if (!q.running) continue;
+        Params Pg = P;
+        Pg.tile0 = q.tile0;
+        prof.begin(2, q.st);
+        const int n_w = 2 * d.N + NX * (d.N + 1);
+        // start-point safeguard: stage-parallel form when its LDS footprint fits the default limit and the horizon has the two
+        // stage-threads the scans need (otherwise the two-chain kernel)
+        const size_t lds_pre = prestart_doubles(NX, S, bx) * sizeof(double);
+        const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
+        // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
+        const size_t lds_red = (size_t)(threads / 64) * 10 * bx * sizeof(double);            // (stage_block's reduction scratch, in front of the safeguard's region)
+        const bool fused = lds_red + lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
+        if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
+        if (fused) {
+            // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
+            DevTmp t_sdbg;
+            if (kn.start_timing && !h->async_loop && G == 1 && hipMalloc(&t_sdbg.p, sizeof(unsigned long long) * 16 * (size_t)q.nblk) == hipSuccess) {
+                (void)hipMemsetAsync(t_sdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)q.nblk, q.st);
+                Pg.DBG = t_sdbg.as<unsigned long long>();
+            }
+            hipLaunchKernelGGL((k_start<NX>), dim3(q.nblk), dim3(threads), std::max(lds_red + lds_pre + 16 + lds_in, lds_init), q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows,
+                               g == 0 ? zero_next : (uint32_t*)nullptr, (uint32_t)ctl_words);
+            if (g == 0 && zero_next != nullptr) next_zeroed = true;
+            if (Pg.DBG) {          // (option start_timing: shader-clock stamps of every workgroup of k_start; synchronises)
+                std::vector<unsigned long long> hd((size_t)16 * q.nblk);
+                if (hipStreamSynchronize(q.st) == hipSuccess && hipMemcpy(hd.data(), Pg.DBG, hd.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                    const int order[16] = {11, 12, 13, 1, 2, 3, 4, 5, 6, 14, 15, 0, 7, 8, 9, 10};
+                    static const char* names[15] = {"rows->LDS", "Z/REF stores", "bounds+a0", "defects", "scan1", "tan+scan2", "sincos+scan3", "ROLL+sums", "decide", "fence", "enter", "init point+exchange", "eval+assemble", "reduce", "finish"};
+                    double acc[15] = {0};
+                    unsigned long long t0 = ~0ull, t1 = 0ull;
+                    for (int bq = 0; bq < q.nblk; ++bq) {
+                        const unsigned long long* r = hd.data() + (size_t)bq * 16;
+                        for (int j = 0; j < 15; ++j) acc[j] += (double)(long long)(r[order[j + 1]] - r[order[j]]);
+                        t0 = std::min(t0, r[11]); t1 = std::max(t1, r[10]);
+                    }
+                    fprintf(stderr, "[mpcgpu k_start timing, shader-clock ticks, mean over %d workgroups]", q.nblk);
+                    for (int j = 0; j < 15; ++j) fprintf(stderr, " %s=%.0f", names[j], acc[j] / q.nblk);
+                    fprintf(stderr, "; first start to last end %.0f\n", (double)(t1 - t0));
+                }
+                Pg.DBG = nullptr;
+            }
+        } else {
+            if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
+                hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
+            else
+                hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
+            launch_stage(q, true);
+        }
+        if (G > 1) prof.end(q.st);          // (one stream: the span stays open, the first kernel of the loop starts where it ends)
+    }
+
+    if (ctl != nullptr) {
+        h->pipe_clean[h->pipe_flip ^ 1] = next_zeroed ? ctl_words : 0;
+        h->pipe_flip ^= 1;
+    }
+    if (res_path) {
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
-        // (one fill: outside an asynchronous closed loop word 1, its sticky abort word, means nothing)
-        if (!h->async_loop) HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 7 * sizeof(uint32_t), stream));
-        else HIP_TRY(h, hipMemsetAsync(h->d_fail + 2, 0, 5 * sizeof(uint32_t), stream));
         const int nblk_dbg = (B + hyb_bx - 1) / hyb_bx;
         DevTmp t_rdbg;
         if (kn.res_timing && !h->async_loop) {
@@ -3335,11 +3338,8 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipMemsetAsync(t_rdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg, stream));
             P.DBG = t_rdbg.as<unsigned long long>();
         }
-        prof.begin(5, stream);
-        launch_wg(hyb_bx, nullptr, h->d_fail + 2);
-        prof.end(stream);
-        prof.begin(2, stream);
-        hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)nullptr, h->d_fail, (uint32_t*)nullptr, 0u);
+        prof.next(5, stream);
+        launch_wg(hyb_bx, nullptr, ctl + PIPE_WG, h->async_loop ? nullptr : ctl + PIPE_ABORT);
         prof.end(stream);
         h->last_mode = 2;
         if (h->async_loop) {             // closed-loop driver: nothing comes back to the host per step (this path has no abort word)
@@ -3347,9 +3347,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             h->async_ok = true;
             return MPC_OK;
         }
-        HIP_TRY(h, hipMemcpyAsync(h->h_fail, h->d_fail, 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(h, wait_stream(h, stream));
-        if (h->resc_in_kernel) h->rescued_last = (int)h->h_fail[6];
+        HIP_TRY(h, wait_stream(h, stream));          // (the last workgroup to leave has put the block's head into h_pipe)
+        h->h_fail[0] = h->h_pipe[14];
+        for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
+        if (h->resc_ran) h->rescued_last = (int)h->h_pipe[20];
         report_wtrace();
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
             std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
@@ -3376,38 +3377,19 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         it = (int)h->h_fail[2];
         h->res_prof[1] = 1; h->res_prof[2] = it; h->res_prof[3] = nblk_dbg; h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
     } else {
-        uint32_t xcd_mask = h->xcd_mask;
-        if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave
-            const uint32_t m = kn.pipe_xcd_mask & h->xcd_mask;
-            if (m) xcd_mask = m;
-        }
-        const int n_xcd = __builtin_popcount(xcd_mask);
-        const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
-        const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
-        int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
-        if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
-        // two threads per (instance, stage) in the stage workers (option pair): 512-thread workgroups
-        const size_t lds_pair = ((size_t)(2 * nw) * 10 * bx + (size_t)2 * S * (NX + 2) + (size_t)pair_rows<NX>() * threads) * sizeof(double);
-        const bool pipe_pair = MPC_WITH_PAIR && kn.pair != 0 && pair_vm_ok && 2 * threads <= 512 && lds_pair <= lds_max;
-        // (threads >= 192 is also what the hand-offs' cache argument rests on: a stage item then loads >= 130 KB at its top -- ~90 rows x 8 bytes per stage
-        //  thread -- and pushes the lines of the worker's previous item out of its 32 KB L1; DESIGN.md section 4, invariant (I1))
-        const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
-                              ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
-                              std::max(lds_bytes, ric_lds) <= lds_max;
         // (measured: 7-11 % faster than one launch per kernel at B = 64 ... 1024, 31 % at B = 4096; at B = 8192 the early
         //  finishers of converged mode still gain 15 %, a fixed iteration count loses 8 % -- with two tiles per Riccati
         //  worker both roles are throughput bound and the split of the CUs only costs)
-        if (eligible && !h->pipe_disabled && kn.pipeline) {
+        if (pipe_path) {
             PipeArgs A;
             A.ntiles = (uint32_t)ntiles;
             A.n_ric = (uint32_t)n_ric;
             A.xcd_mask = xcd_mask;
             A.items = 64u / (uint32_t)bx;
-            A.cap = 1;
-            while (A.cap < 2u * A.items * (uint32_t)tiles_x) A.cap <<= 1;
+            A.cap = pipe_cap;
             A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
             // the Riccati workers help with the stage items (k_pipeline<.., HELP>) where those are the bottleneck: more than three per stage worker and round
-            const bool pipe_help = !pipe_pair && (kn.pipe_help < 0 ? (int)A.items * tiles_x > 3 * (cu_x - n_ric) : kn.pipe_help != 0);
+            const bool pipe_help = (kn.pipe_help < 0 ? (int)A.items * tiles_x > 3 * (cu_x - n_ric) : kn.pipe_help != 0);
             A.handover = (uint32_t)hand;
             int32_t* ho_list = nullptr;
             A.ho_list = nullptr;
@@ -3416,20 +3398,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 if (!ho_list) { h->err = "out of device memory"; return MPC_ERR_HIP; }
                 if (kn.ho_inline) A.ho_list = ho_list;
             }
-            const size_t words = pipe_ctl_words(A.ntiles, A.cap);
-            if (h->pipe_words < words) {
-                if (h->d_pipe) (void)hipFree(h->d_pipe);
-                h->d_pipe = nullptr; h->pipe_words = 0;
-                HIP_TRY(h, hipMalloc(&h->d_pipe, 2 * words * sizeof(uint32_t)));
-                h->pipe_words = words;
-                h->pipe_clean[0] = h->pipe_clean[1] = 0;
-            }
-            if (!h->h_pipe) HIP_TRY(h, hipHostMalloc(&h->h_pipe, 24 * sizeof(uint32_t)));
-            uint32_t* const ctl = h->d_pipe + (size_t)h->pipe_flip * h->pipe_words;
-            uint32_t* const ctl_next = h->d_pipe + (size_t)(h->pipe_flip ^ 1) * h->pipe_words;
             A.ctl = ctl;
-            if (h->pipe_clean[h->pipe_flip] < words) HIP_TRY(h, hipMemsetAsync(ctl, 0, words * sizeof(uint32_t), stream));      // (first use, or a larger batch than the last)
-            h->pipe_clean[h->pipe_flip] = 0;
             unsigned long long* d_pdbg = nullptr;
             if (kn.pipe_timing) {
                 HIP_TRY(h, hipMalloc(&t_pdbg.p, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
@@ -3438,10 +3407,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 P.DBG = d_pdbg;
             }
             prof.next(3, stream);
-#if MPC_WITH_PAIR
-            if (pipe_pair) hipLaunchKernelGGL((k_pipeline<NX, true>), dim3(h->n_cu), dim3(2 * threads), std::max(lds_pair, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else
-#endif
             // tiles about to leave the pipeline (at most hand + 16 instances left; never a full tile) write the mailbox arrays in their stage items
             P.mbw_live = (hand > 0 && kn.mb_pipe) ? std::min(63, hand + 16) : 0;
             if (pipe_help && masked) hipLaunchKernelGGL((k_pipeline<NX, 2, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
@@ -3458,17 +3423,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                     // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
                 }
-                launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG);
+                // (the last kernel of the solve: its last workgroup copies the head of the control block into the pinned host block)
+                launch_wg(hyb_bx, (const uint32_t*)(ctl + PIPE_ABORT), ctl + PIPE_WG, h->async_loop ? nullptr : ctl + PIPE_ABORT);
             }
-            // the output transpose is enqueued behind it at once (it looks at the abort word itself), so that the one
-            // synchronisation of the call is the last thing that happens
-            prof.next(2, stream);
-            // (instances that did not converge are counted into word 14 of the control block, which travels back with the abort word;
-            //  an asynchronous closed loop accumulates them over its steps in d_fail instead)
-            hipLaunchKernelGGL((k_egest<NX>), dim3(ntiles, (2 * d.N + NX * (d.N + 1) + 63) / 64), dim3(256), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT),
-                               h->async_loop ? h->d_fail : ctl + PIPE_ABORT + 14, ctl_next, (uint32_t)words);
-            h->pipe_clean[h->pipe_flip ^ 1] = words;
-            h->pipe_flip ^= 1;
             prof.end(stream);
             if (h->async_loop) {
                 // closed-loop driver: nothing comes back to the host per step -- a launch that had to be abandoned leaves its mark
@@ -3479,22 +3436,27 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 h->last_mode = 1;
                 return MPC_OK;
             }
-            HIP_TRY(h, hipMemcpyAsync(h->h_pipe, ctl + PIPE_ABORT, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            // (no kernel behind the loop: the rows are out -- Params::emit -- and k_solve_wg has left the block's head in h_pipe; a pipeline that
+            //  runs its tiles to the end, option hybrid = 0, has no such epilogue: a copy command)
+            if (hand <= 0) HIP_TRY(h, hipMemcpyAsync(h->h_pipe, ctl + PIPE_ABORT, PIPE_FIN_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(h, wait_stream(h, stream));
             h->h_fail[0] = h->h_pipe[14];
             report_wtrace();
             for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
-            if (h->resc_in_kernel) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
+            if (h->resc_ran) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
             if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
-                h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = (B + hyb_bx - 1) / hyb_bx;
+                h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = wg_grid > 0 ? wg_grid : (B + hyb_bx - 1) / hyb_bx;      // (workgroups launched: what the machine holds when they are dealt from the hand-over lists)
                 h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];
             }
             if (h->h_pipe[0] != 0u) {
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
                 // through an iteration, so start over with one launch per kernel -- and stay there for this handle
                 h->pipe_disabled = true;
-                h->resc_in_kernel = false;         // (the k_solve_wg behind the abandoned launch returned at once: no instance has had its second chance)
-                fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired); re-running with one launch per kernel\n");
+                h->resc_in_kernel = h->resc_ran = false;         // (the k_solve_wg behind the abandoned launch returned at once: no instance has had its second chance)
+                // (abort word: 1 option pipe_test_abort, 2 a Riccati worker waited for its tile's stage items [tile << 16 | round; arrivals], 3 a helping
+                //  Riccati worker / 4 a stage worker waited for its queue slot [ticket; queue tail])
+                fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired: code %u, %u / %u); re-running with one launch per kernel\n",
+                        h->h_pipe[0], h->h_pipe[15], h->h_pipe[23]);
                 return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
             }
             P.DBG = nullptr;
@@ -3757,7 +3719,7 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
             return MPC_OK;
         }
     }
-    h->resc_in_kernel = false;
+    h->resc_in_kernel = h->resc_ran = false;
     const int rc = solve_dev_any(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
     // (converged mode: the solve has synchronised the stream; a launch of k_solve_wg with the second chance inside has given every stalled
     //  instance its levels already)
@@ -3766,7 +3728,9 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
     const int mode_keep = h->last_mode;
     memcpy(prof_keep, h->prof, sizeof prof_keep);
     memcpy(pipe_keep, h->pipe_prof, sizeof pipe_keep);
+    const int in_kernel = h->rescued_last;                  // (instances that had their second chance inside k_solve_wg already)
     const int rr = rescue_dev(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream);
+    h->rescued_last += in_kernel;
     memcpy(h->prof, prof_keep, sizeof prof_keep);          // the measurement helpers describe the main solve
     memcpy(h->pipe_prof, pipe_keep, sizeof pipe_keep);
     h->last_mode = mode_keep;

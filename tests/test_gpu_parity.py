@@ -950,7 +950,11 @@ def test_instances_per_wavefront_follow_the_batch_size():
         rp, pp = s.get_resident_profile(), s.get_pipeline_profile()
         assert (r.status == 1).all() and rp["ran"]
         bx = 1 if B <= 4 * n_cu else 2
-        assert rp["workgroups"] == (B + bx - 1) // bx
+        # (behind the pipeline the workgroups are dealt from the hand-over lists: as many as the machine holds at once, or the lists' capacity)
+        if pp["ran"]:
+            assert 4 * n_cu <= rp["workgroups"] <= (B + bx - 1) // bx
+        else:
+            assert rp["workgroups"] == (B + bx - 1) // bx
         # every iteration of every instance is served by exactly one of the two kernels (k_solve_wg counts its own)
         assert rp["instance_iterations"] <= int(r.iters.sum()) and rp["sweeps"] >= rp["workgroup_rounds"] > 0
         assert pp["ran"] == (B > 2048) and (not pp["ran"] or rp["instance_iterations"] < int(r.iters.sum()))

@@ -53,6 +53,36 @@ def scan(text):
     return stores, sgpr_soffset, overwritten
 
 
+def functions(text):
+    """{mangled name: [instruction lines]} of an assembly listing"""
+    out, cur = {}, None
+    for l in text.split("\n"):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur is not None and l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;"):
+            out[cur].append(l.strip())
+    return out
+
+
+def scan_xcu_loads(text):
+    """The hand-off protocol of k_pipeline (csrc/mpcgpu.hip, DevParams::xcu): a workgroup reads workspace rows that ANOTHER compute unit of its XCD wrote
+    earlier in the same launch, and neither `buffer_inv sc0` nor a workgroup-scope fence drops a stale line of its own vector L1 -- so EVERY workspace
+    load of that kernel (the workspace is only ever addressed through the buffer descriptor) must carry the sc1 bit, the LDS-DMA loads of the Riccati
+    workers included, and no other kernel needs it.  Returns {kernel: (buffer loads, of them sc1, global/flat loads without sc1)}."""
+    res = {}
+    for f, body in functions(text).items():
+        if "k_pipeline" not in f and "k_solve_wg" not in f and "k_stage" not in f:
+            continue
+        bl = [l for l in body if re.match(r"buffer_load", l)]
+        gl = [l for l in body if re.match(r"(global|flat)_load", l) and " sc1" not in l]
+        res[f] = (len(bl), sum(1 for l in bl if " sc1" in l), len(gl))
+    return res
+
+
 if __name__ == "__main__":
     text = open(sys.argv[1]).read() if len(sys.argv) > 1 else isa_text()
     stores, sgpr, over = scan(text)
