@@ -695,6 +695,7 @@ def other_configs(torch, wl, local_rank, dev, stream):
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / reps
         loop_ms = loop_bytes = 0.0
+        whole_call = False
         for d in items:                              # one profiled batch: launch durations of the iteration loop
             d["s"].set_profiling(True)
         if len(items) > 1:                           # (launch durations of the loop: the handles one after the other, nothing else on the machine)
@@ -714,14 +715,16 @@ def other_configs(torch, wl, local_rank, dev, stream):
             loop_ms += pp["ms"] + rp["ms"] + pr["riccati_ms"] + pr["stage_ms"]
             loop_bytes += float(d["it"].sum().item()) * ab["b_iter"]
             d["s"].set_profiling(False)
-            if d["s"].last_rescued() > 0:                # several solves behind one call (second chance): the figures above are the last one's
-                loop_ms = float("nan")
+            if d["s"].last_rescued() > 0:                # a second chance ran (inside the launch, or as further solves behind the call): the iteration counts
+                whole_call = True                        # are accumulated over its levels, so the fraction is taken over the whole call
         Bt = sum(d["B"] for d in items)
         st = torch.cat([d["st"] for d in items]).cpu().numpy()
         it = torch.cat([d["it"] for d in items]).cpu().numpy()
         out.append(dict(config=label, batch=Bt, ms_per_batch=dt * 1e3, steps_per_s=Bt / dt, converged_frac=float((st == 1).mean()),
-                        mean_iters=float(it.mean()), max_iters=int(it.max()), loop_launch_ms=loop_ms if loop_ms == loop_ms else None,
-                        roofline_frac=(loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if loop_ms > 0 else None,
+                        mean_iters=float(it.mean()), max_iters=int(it.max()), loop_launch_ms=None if whole_call else loop_ms,
+                        # (algorithmic bytes of the instance-iterations performed / duration of the loop's launches; with a second chance: / the whole call)
+                        roofline_frac=(loop_bytes / dt / 1e9 / HBM_PEAK_GBS) if whole_call else ((loop_bytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if loop_ms > 0 else None),
+                        roofline_basis="whole call" if whole_call else "loop launches",
                         rescued=int(sum(d["s"].last_rescued() for d in items)), paths=paths))
     try:
         f2, f3, f4 = wl.FAMILIES["zamlf_n30_nx6"], wl.FAMILIES["zamca_n30_nx5"], wl.FAMILIES["usalf_n50_nx5"]

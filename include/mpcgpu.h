@@ -230,41 +230,39 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
                                const double* lb, const double* ub, const double* hl, const double* hu, int32_t hessian_mode,
                                double* d_x_out, int32_t* d_exitflag, int32_t* d_it, double* d_res, void* stream);
 
-/* Run-time switches of a handle.  They are read from the environment once, at mpc_create (MPCGPU_<NAME IN CAPITALS>), and
- * changed afterwards only through this call; value NULL restores the default.  Names: "pipeline" (0: one launch per kernel
- * and iteration instead of the single persistent launch), "rescue" (0: no second chance for stalled instances), "loop_async" (0: closed loop with a host round trip per step),
- * "sync_spin" (0: block in the one synchronisation of a solve instead of polling the stream), "max_batch" (instances per chunk: a batch
- * whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway; this lowers the limit),
- * "big_wg", "groups", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_xcd_mask", "stage_timing", "start_timing", "poison" (1: NaN into every row of the workspace before a solve -- a debugging aid),
- * "prestart_chains" (1: the start-point safeguard as two sequential chains per instance instead of one thread per stage),
- * "resident" (0: the streaming paths -- single-launch pipeline or one launch per kernel -- instead of the resident solve),
- * "pair" (1: two threads per (instance, stage) in the stage phases; measured slower, profiles/r04_stage_split.txt -- the variant is
- * compiled only with -DMPC_WITH_PAIR=1; in the default build any value but 0 is MPC_ERR_INVALID),
- * "wg_list" (default 1: at the hand-over of the hybrid solve the live instances of all tiles are dealt to the workgroups of k_solve_wg
- * from lists ordered by how far from convergence they are -- a workgroup takes one near and one far instance; 0: a workgroup takes
- * instances b, b + 1 of its tile and skips finished ones), "ho_inline" (default 1: those lists are written by the stage workers of the
- * pipeline as they retire a tile; 0: by a small kernel between the two launches), "wg_trace" (1: k_solve_wg records per workgroup its
- * first and last clock, rounds and sweeps; tools/wg_profile.py prints the distribution),
- * "mb_pipe" (default 1: in the hybrid solve the pipeline's stage items of a tile that is about to leave write iterate, multipliers and stage block
- * into the instance-major arrays of k_solve_wg as well, which then takes its instances over without copying them; 0: every workgroup of k_solve_wg
- * copies its instances out of the tile-major rows -- 35 us at the head of the launch on the headline batch; same bits),
- * "pipe_help" (-1, the default: decided per batch; 1 / 0: the Riccati workers of the pipeline take / do not take one published stage item
- * while their own tile is with the stage workers -- k_pipeline<.., HELP>; it pays when a round has more than three stage items per stage
- * worker, e.g. N = 50 or B = 8192; same bits either way),
- * "bound_mask" (0: every bound side is looked up at run time -- variant 0 of the loop kernels; default 1: when the bounds handed to
- * mpc_set_bounds have the structure of the reference's NLPs (optimizer.py:421-491: only steering rate, acceleration, steering angle and speed
- * bounded, circle rows with a lower bound only, multiplicity 3, no per-instance obstacle) the kernels with that structure compiled in are
- * used; same algorithm and iteration counts, results agree at round-off), "rescue_wg" (0: the second chance of stalled instances only on
- * the host side, behind the launch; default 1: inside k_solve_wg where the batch runs one instance per workgroup -- same levels, same
- * bookkeeping: a row whose levels fail gets back its FIRST result, status and iteration count plus the iterations of the levels tried,
- * exactly as the host-side path reports it; tests/test_gpu_parity.py::test_second_chance_paths_agree_when_levels_fail)
- * (measurement and test aids);
- * "friction_lb" -- the lower bound lbg[0] = 0 of the reference's stage-0 friction row sqrt((a_0^2 + v_0^2 tan(delta_0)/2.578)^2)
- * (MPC_Planner/optimizer.py:378, 424-425): "nlp" / 0 (default) = implied by the absolute value, no barrier -- a solve returns the
- * optimum of the NLP; "ipopt" / 1 = the row as IPOPT sees it, a slack with both bounds and a log barrier on the lower one too: the
- * kink of |.| at a_0^2 = -v_0^2 tan(delta_0)/2.578 becomes a wall the slack does not cross and a solve can end AT it, depending on
- * the warm start -- what the reference's recorded ZAM_Over-1_1 run shows at steps 4 and 13 (tests/test_recorded_residuals.py).
- * Unknown name -> MPC_ERR_INVALID.                                                                                     */
+/* Run-time switches of a handle (18).  They are read from the environment once, at mpc_create (MPCGPU_<NAME IN CAPITALS>), and changed afterwards
+ * only through this call; value NULL restores the default.  Unknown name -> MPC_ERR_INVALID.
+ *   what is solved
+ *     "friction_lb"      the lower bound lbg[0] = 0 of the reference's stage-0 friction row sqrt((a_0^2 + v_0^2 tan(delta_0)/2.578)^2)
+ *                        (MPC_Planner/optimizer.py:378, 424-425): "nlp" / 0 (default) = implied by the absolute value, no barrier -- a solve returns
+ *                        the optimum of the NLP; "ipopt" / 1 = the row as IPOPT sees it, a slack with both bounds and a log barrier on the lower one
+ *                        too: the kink of |.| becomes a wall the slack does not cross and a solve can end AT it, depending on the warm start --
+ *                        what the reference's recorded ZAM_Over-1_1 run shows at steps 4 and 13 (tests/test_recorded_residuals.py)
+ *     "rescue"           0: no second chance for stalled instances (see above)
+ *     "rescue_wg"        0: the second chance only behind the launch (rescue_dev); default 1: inside k_solve_wg where the batch runs one instance
+ *                        per workgroup -- same levels, same bookkeeping, same bits
+ *   which kernels serve the iteration loop (every combination gives the same iteration counts; bits as documented in DESIGN.md section 4)
+ *     "pipeline"         0: one launch per kernel and iteration (the path of batches above 8192 instances, horizons above 63 and trace mode, and what
+ *                        an abandoned persistent launch falls back to) instead of the single persistent launch k_pipeline
+ *     "hybrid"           0: the pipeline runs every tile to its end; default 1: tiles with few instances left go to k_solve_wg
+ *     "hybrid_bx"        instances per wavefront of k_solve_wg: 1, 2, or 0 (default) = by batch size
+ *     "hybrid_live"      live instances per tile at which a tile changes over (-1, default: from the machine's size; 64: k_solve_wg alone)
+ *     "pipe_help"        1 / 0: the Riccati workers of the pipeline take / do not take one published stage item while their tile is with the stage
+ *                        workers; -1 (default): where a round has more than three stage items per stage worker (N = 50, B = 8192)
+ *     "bound_mask"       0: every bound side looked up at run time (variant 0 of the loop kernels); default 1: the kernels with the bound structure
+ *                        of the reference's NLPs compiled in (optimizer.py:421-491) whenever the bounds handed to mpc_set_bounds have it
+ *     "big_wg"           1: 512-thread stage workgroups (what horizons above 63 use) also for short horizons
+ *     "groups"           2..4: sub-batches on streams of their own (one launch per kernel; measured, not the default)
+ *     "max_batch"        instances per chunk (a batch whose workspace would pass 4 GiB is solved in chunks of whole tiles anyway)
+ *   host side
+ *     "loop_async"       0: closed loop with a host round trip per step
+ *     "sync_spin"        0: block in the one synchronisation of a solve instead of polling the stream
+ *   test and measurement aids
+ *     "pipe_test_abort"  1: the persistent launch raises its abort word at once (exercises the restart path)
+ *     "pipe_xcd_mask"    pretend XCDs away (a partitioned device)
+ *     "poison"           1: NaN into every row of the workspace before a solve (a read of something the solve has not written shows as status -6)
+ *     "timing"           sum of 1 (k_stage / k_riccati), 2 (k_pipeline workers), 4 (k_solve_wg rounds), 8 (k_start), 16 (k_solve_wg workgroup trace):
+ *                        shader-clock stamps of those kernels printed to stderr after the solve (tools/pipe_timing.py, res_timing.py, ...)       */
 int mpc_set_option(mpc_handle* h, const char* name, const char* value);
 /* current value of an option (so that a caller that changes one for a moment can put the PREVIOUS value back, not the default) */
 int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value);
@@ -287,8 +285,7 @@ int mpc_get_profile(const mpc_handle* h, double out[6]);
 int mpc_get_pipeline_profile(const mpc_handle* h, double out[8]);
 /* The workgroup-resident kernels.  k_solve_wg (a workgroup keeps its instances for all their remaining iterations: the stage phases of
  * the other paths + a wave-per-instance Riccati on the fp64 matrix pipe) finishes the instances of the tiles that left the pipeline
- * (hybrid solve, the default: options "hybrid", "hybrid_bx", "hybrid_live") or solves a small batch alone; option "resident" = 1 runs it
- * alone with whole 8-instance workgroups.
+ * (hybrid solve, the default: options "hybrid", "hybrid_bx", "hybrid_live") or solves a small batch alone ("hybrid_live" = 64: any batch).
  * out[0] = ms of that launch (profiling enabled only), out[1] = 1 if such a kernel ran in the last call, out[2] = rounds (iterations)
  * of its slowest workgroup, out[3] = workgroups of the launch, out[4] = rounds summed over the workgroups, out[5] = backward Riccati
  * sweeps (> rounds when inertia corrections repeat a sweep; two instances of a wavefront share a sweep), out[6] = instance-iterations

@@ -72,6 +72,21 @@ __device__ __forceinline__ void fill_bounds(const PRef& P, double* tab, const in
     batched_fill<2 * MAXJ>(2 * nb, t, NT, [&](int q) { return q < nb ? (double)MPC_GP(P.LB, q) : (double)MPC_GP(P.UB, q - nb); }, [&](int q, double v) { tab[q] = v; });
 }
 
+// A wave-uniform word read from LDS (a ticket, a work item, a mask another lane published), moved into a SCALAR register.  Not an optimisation:
+// left in a vector register, such a value is per-lane state, and when the register allocator parks it (in an AGPR or in scratch) inside a divergent
+// region it saves and restores the ACTIVE lanes only -- a lane that was inactive at the save but active when the register was reused in between
+// comes back with the register's old content.  Found in round 6 as arrivals credited to the wrong tile by k_pipeline<5, 2, HELP>: the tile number of
+// a helper's stage item sat in v209 across stage_block, saved under the mask of the block's running instances, and lane 0 -- whose instance had
+// finished -- signalled the arrival with the tile of an EARLIER item (the launch then waits for an arrival that never comes and is abandoned).
+// Scalar registers are spilled lane-mask-free.  Everything uniform that lives across stage_block / riccati_tile / wg_stage goes through here.
+__device__ __forceinline__ uint32_t lds_uniform(const uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int lds_uniform(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double lds_uniform(const double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long r = ((unsigned long long)lds_uniform((uint32_t)(u >> 32)) << 32) | lds_uniform((uint32_t)u);
+    return __builtin_bit_cast(double, r);
+}
+
 // workgroup-wide OR of a predicate with one such barrier (slots double-buffered by call parity)
 __device__ __forceinline__ int block_or(int pred, int (*slots)[8], int& parity) {
     const int any = __any(pred) ? 1 : 0;
@@ -161,7 +176,6 @@ __device__ __forceinline__ void stash_xfer(Ctx<NX>& c, double* st, int T, int t,
 }
 
 // the variables that carry bounds in the reference's NLP (optimizer.py:421-491: steering rate, acceleration, steering angle, speed):
-// the pair kernels are instantiated for this mask (a handle whose bounds touch other variables runs one thread per stage)
 constexpr uint32_t REF_BOUND_VM = 0x33u;
 // variant 2 of k_pipeline / k_solve_wg: that mask, the bounds of its variables at every stage, circle rows with a lower bound only and
 // multiplicity 3, one obstacle per batch -- the structure of every NLP the reference builds
@@ -468,11 +482,6 @@ __device__ __forceinline__ void ho_lists(const PRef& P, const uint32_t bb, int32
     }
 #endif
 }
-__global__ void __launch_bounds__(64) k_ho_lists(const Params Pk, const uint32_t* skip_if, int32_t* ho_list, uint32_t* ho_count, const uint32_t* tile_word) {
-    const PRef P(Pk);
-    if (skip_if != nullptr && *skip_if != 0u) return;
-    ho_lists(P, blockIdx.x * 64u + threadIdx.x, ho_list, ho_count, tile_word);
-}
 
 // the Riccati factor + solve of one tile of 64 instances by three wavefronts; returns the tile's activity mask (0: no
 // instance of the tile is iterating, nothing was touched)
@@ -607,7 +616,7 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
             if (lane == 0) *flag = again;
         }
         lds_barrier();
-        const int again = *flag;
+        const int again = lds_uniform(*flag);
         lds_barrier();
         if (!again) break;
     }
@@ -706,7 +715,10 @@ __global__ void __launch_bounds__(192) k_riccati(const Params Pk) {
 // (HW_REG_XCC_ID, not a guess from blockIdx) and serves only the tiles with tile % 8 == that XCD, in the role its
 // arrival order on that XCD gives it.  Producer and consumer of every row therefore share one L2:
 //   producer: plain stores -> s_waitcnt vmcnt(0) (acknowledged by the L2) -> barrier -> agent-scope atomic on the flag
-//   consumer: relaxed agent-scope poll by one lane -> invalidate of this CU's vector L1 (buffer_inv sc0; pipe_acquire) -> barrier -> loads
+//   consumer: relaxed agent-scope poll by one lane -> barrier -> loads, EVERY ONE of them with the sc1 bit (DevParams::xcu: served by the L2,
+//             never by this CU's vector L1 -- a CU's L1 is not refreshed by another CU's stores, and neither `buffer_inv sc0` nor a workgroup-
+//             scope fence drops its lines: measured, profiles/r05_store_pairing.txt, tools/ubench/stale_l1.hip).  No invalidate, no assumption
+//             about what the L1 holds; tests/test_isa_hazards.py proves from the ISA that no buffer load of the kernel lacks the bit.
 // The flags themselves (queue slots, counters, abort word) are agent-scope atomics, valid across XCDs.
 // Every spin is bounded: a wait longer than PIPE_SPIN_LIMIT sets the abort word, every worker leaves, and the host
 // re-runs the solve with one launch per kernel (also if the dispatcher leaves an XCD without stage workers).
@@ -720,10 +732,7 @@ struct PipeArgs {
     uint32_t items;         // stage work items per tile = 64 / bx
     uint32_t handover;      // a tile with at most this many instances still iterating leaves the pipeline (0: tiles run to the end)
     int32_t* ho_list;       // ... and the stage workers put them onto the hand-over lists on their way out (nullptr: k_ho_lists does, or nobody)
-    uint32_t flags;         // bit 0: producers also issue an agent-scope release (MPCGPU_PIPE_RELEASE: the protocol that does not
-                            // rely on a tile staying inside one L2; same results, 10-17 % slower); bit 1: raise the abort word at
-                            // once (MPCGPU_PIPE_TEST_ABORT: exercises the host's restart path); bit 3: consumers acquire at agent scope
-                            // (MPCGPU_PIPE_L2INV) instead of dropping their own L1 only -- implied by bit 0
+    uint32_t flags;         // bit 1: raise the abort word at once (option pipe_test_abort: exercises the host's restart path)
 };
 constexpr uint32_t PIPE_X_STRIDE = 64;          // uint32 words per XCD record: arrive @0, head @16, tail @32, finished @48, hand-over ticket @56
 constexpr uint32_t PIPE_ABORT = 8 * PIPE_X_STRIDE;      // abort word; +1 rounds (max), +2.. statistics
@@ -739,16 +748,11 @@ constexpr unsigned long long PIPE_SPIN_LIMIT = 5000000ull;      // 100 MHz wall-
 __host__ __device__ inline uint32_t pipe_slots_off(uint32_t ntiles) { return (PIPE_HDR + ntiles + 1u) & ~1u; }
 __host__ __device__ inline size_t pipe_ctl_words(uint32_t ntiles, uint32_t cap) { return (size_t)pipe_slots_off(ntiles) + (size_t)16 * cap; }
 
-// acquire side of a hand-off inside one XCD: producer and consumer share the L2, so all the consumer has to drop is its own CU's
-// vector L1 (buffer_inv sc0, the workgroup-scope invalidate) -- the agent-scope acquire (buffer_inv sc1) also invalidates the XCD's L2
-// lines of this memory, for every worker of the XCD, at every work item.  `l1_only` = false: the agent-scope fence (option pipe_l2inv).
-__device__ __forceinline__ void pipe_acquire(bool l1_only) {
+// acquire side of a hand-off: nothing for the hardware to do -- every workspace load of the kernel is an sc1 load (DevParams::xcu), served by the
+// XCD's L2, where the producer's rows are once its `s_waitcnt vmcnt(0)` has returned; this keeps the compiler from moving loads above the flag
+__device__ __forceinline__ void pipe_acquire() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (l1_only) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (compiler ordering only: every workspace load of the kernel is an sc1 load)
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
 }
 __device__ __forceinline__ uint32_t pipe_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -784,15 +788,13 @@ __global__ void k_xcd_census(uint32_t* mask) {
 #endif
 }
 
-// PAIR: the stage workers run two threads per (instance, stage) (stage_pair: 512-thread workgroups, two wavefronts per SIMD)
-// VAR: 0 one thread per (instance, stage), bounds looked up at run time; 1 two threads per (instance, stage) (stage_pair); 2 one thread per
-// stage with the bound structure of the reference compiled in (REF_BOUND_VM: only steering rate, acceleration, steering angle and speed carry
-// bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
+// VAR: 0 bounds looked up at run time; 2 the bound structure of the reference compiled in (REF_BOUND_VM: only steering rate, acceleration,
+// steering angle and speed carry bounds -- the sides of the other variables, their multipliers and 1/gap registers vanish from the code)
 // HELP: the Riccati workers take a stage item while their tile is with the stage workers (below) -- a variant of its own: the extra code in the
 // Riccati worker's loop costs the sweeps of the default kernel 3.5 % through its register allocation, and only batches whose stage items outnumber
 // the stage workers three to one gain from it (N = 50: 16 items per tile)
 template <int NX, int VAR, bool HELP = false>
-__global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params Pk, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
+__global__ void __launch_bounds__(256) k_pipeline(const Params Pk, const PipeArgs A, const int n_mult, const int n_z, const int stash_rows) {
     const PRef P = mpc_pref(Pk, true);  // (xcu: rows travel between the CUs of an XCD inside this launch -- every workspace load is an sc1 load)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -813,7 +815,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
     if ((A.flags & 2u) && t == 0) pipe_st(abort_w, 1u);
     if (t == 0) sh_word[0] = pipe_add(X + 0, 1u);
     lds_barrier();
-    const uint32_t slot = sh_word[0];
+    const uint32_t slot = lds_uniform(sh_word[0]);
     const uint32_t n_ric = A.n_ric < n_tiles_x ? A.n_ric : n_tiles_x;
     lds_barrier();
     unsigned long long waited = 0;
@@ -824,7 +826,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         // ============================================================ Riccati worker: local tiles slot, slot + n_ric, ...
         // (option pipe_help: a Riccati worker whose tile has just gone to the stage workers takes ONE stage item of the queue itself instead of
         //  idling through the item time -- a third more stage capacity per XCD; its fourth wavefront then stays, idle, through the sweeps)
-        constexpr bool helper = HELP && VAR != 1;
+        constexpr bool helper = HELP;
         if (!helper && t >= 192) return;
         uint32_t n_help = 0u;
         const uint32_t n_own = (n_tiles_x - slot + n_ric - 1u) / n_ric;
@@ -842,16 +844,23 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                     const unsigned long long t0 = wall_clock64();
                     while (pipe_ld(stage_done + tile) < need) {
                         if (pipe_ld(abort_w)) { ok = 0u; break; }
-                        if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, (tile << 16) | (round & 0xFFFFu)); pipe_st(abort_w + 23, pipe_ld(stage_done + tile)); pipe_st(abort_w, 2u); ok = 0u; break; }
+                        if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) {
+                            // (diagnostics of the abort message: which tile and round, the arrivals seen, the arrivals a millisecond later, the ticks waited)
+                            pipe_st(abort_w + 28, (tile << 16) | (round & 0xFFFFu)); pipe_st(abort_w + 29, pipe_ld(stage_done + tile)); pipe_st(abort_w + 31, (uint32_t)(wall_clock64() - t0));
+                            const unsigned long long t1 = wall_clock64();
+                            while (wall_clock64() - t1 < 100000ull) __builtin_amdgcn_s_sleep(8);
+                            pipe_st(abort_w + 30, pipe_ld(stage_done + tile));
+                            pipe_st(abort_w, 2u); ok = 0u; break;
+                        }
                         __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
                     }
                     waited += wall_clock64() - t0;
-                    pipe_acquire((A.flags & 9u) == 0u);
+                    pipe_acquire();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the invalidate has completed before the barrier lets the other waves load
                     sh_word[1] = ok;
                 }
                 lds_barrier();
-                if (sh_word[1] == 0u) return;
+                if (lds_uniform(sh_word[1]) == 0u) return;
                 PIPE_STAMP(12);
                 const unsigned long long mask = riccati_tile<NX>(P, tile, reinterpret_cast<char*>(lds), n_pass == 5u, (int)A.handover);
                 if (mask == 0ull) {
@@ -868,14 +877,9 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 } else if (t < 64) {
                     // (the tile's mask goes out with the sweep's last stores: ONE wait covers both -- it is read by a stage worker only after it has seen
                     //  its queue slot, which is written behind that wait)
-                    if (t == 0 && !(A.flags & 1u)) __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t == 0) __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // gains, cost-to-go and the step are in the L2
                     if (t == 0) {
-                        if (A.flags & 1u) {
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __hip_atomic_store(P.tile_mask + tile, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
                         const uint32_t tk = pipe_add(X + 32, A.items);
                         for (uint32_t q = 0; q < A.items; ++q)
                             __hip_atomic_store(slots + ((tk + q) & (A.cap - 1u)), ((unsigned long long)(tk + q + 1u) << 32) | (unsigned long long)((tile << 8) | q),
@@ -909,12 +913,12 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                                     const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     if ((uint32_t)(v >> 32) == hd + 1u) { item = (uint32_t)v; break; }
                                     if (pipe_ld(abort_w)) break;
-                                    if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, hd); pipe_st(abort_w + 23, pipe_ld(X + 32)); pipe_st(abort_w, 3u); break; }
+                                    if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 28, hd); pipe_st(abort_w + 29, pipe_ld(X + 32)); pipe_st(abort_w + 31, (uint32_t)(wall_clock64() - t0)); pipe_st(abort_w, 3u); break; }
                                     __builtin_amdgcn_s_sleep(1);
                                 }
                                 if (item != PIPE_EXIT) {
                                     bits = __hip_atomic_load(P.tile_mask + (item >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    pipe_acquire((A.flags & 9u) == 0u);
+                                    pipe_acquire();
                                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                 }
                             }
@@ -924,14 +928,13 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                         sh_word[3] = (uint32_t)(bits >> 32);
                     }
                     lds_barrier();
-                    const uint32_t item = sh_word[1];
-                    const unsigned long long bits = ((unsigned long long)sh_word[3] << 32) | sh_word[2];
+                    const uint32_t item = lds_uniform(sh_word[1]);
+                    const unsigned long long bits = ((unsigned long long)lds_uniform(sh_word[3]) << 32) | lds_uniform(sh_word[2]);
                     if (item != PIPE_EXIT) {
                         stage_block<NX, false, 256, VAR == 2 ? REF_VM : 0xFFu>(P, n_mult, n_z, stash_rows, (item >> 8) * 64u + (item & 255u) * (uint32_t)P.bx, bits, lds, or_slots, false, nullptr, false);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         lds_barrier();
                         if (t == 0) {
-                            if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                             pipe_add(stage_done + (item >> 8), 1u);
                             ++n_help;
                         }
@@ -959,7 +962,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
                 const unsigned long long v = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(v >> 32) == tk + 1u) { item = (uint32_t)v; break; }
                 if (pipe_ld(X + 48) >= n_tiles_x || pipe_ld(abort_w)) break;             // every tile of this XCD is finished: nothing can arrive
-                if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 15, tk); pipe_st(abort_w + 23, pipe_ld(X + 32)); pipe_st(abort_w, 4u); break; }
+                if (wall_clock64() - t0 > PIPE_SPIN_LIMIT) { pipe_st(abort_w + 28, tk); pipe_st(abort_w + 29, pipe_ld(X + 32)); pipe_st(abort_w + 31, (uint32_t)(wall_clock64() - t0)); pipe_st(abort_w, 4u); break; }
                 __builtin_amdgcn_s_sleep(MPC_PIPE_SLEEP);
             }
             const unsigned long long t1 = wall_clock64();
@@ -969,7 +972,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
             unsigned long long bits = 0ull;
             if (item != PIPE_EXIT) {
                 bits = __hip_atomic_load(P.tile_mask + (item >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pipe_acquire((A.flags & 9u) == 0u);
+                pipe_acquire();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             sh_word[1] = item;
@@ -977,8 +980,8 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
             sh_word[3] = (uint32_t)(bits >> 32);
         }
         lds_barrier();
-        const uint32_t item = sh_word[1];
-        const unsigned long long bits = ((unsigned long long)sh_word[3] << 32) | sh_word[2];
+        const uint32_t item = lds_uniform(sh_word[1]);
+        const unsigned long long bits = ((unsigned long long)lds_uniform(sh_word[3]) << 32) | lds_uniform(sh_word[2]);
         if (item == PIPE_EXIT) break;
         PIPE_STAMP(13);
         const uint32_t tile = item >> 8;
@@ -989,7 +992,6 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
         lds_barrier();
         PIPE_STAMP(14);
         if (t == 0) {
-            if (A.flags & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             pipe_add(stage_done + tile, 1u);
             busy += wall_clock64();
             ++n_items;
@@ -1001,7 +1003,7 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
     // ---- hybrid solve: the stage workers of an XCD leave when every tile of the XCD has stopped -- on their way out they put the instances the
     //      tiles left onto the hand-over lists (ho_lists; tiles dealt by ticket).  A launch of its own for this costs 5.5 us between the two kernels.
     if (A.ho_list != nullptr && t < 64 && pipe_ld(abort_w) == 0u) {
-        pipe_acquire((A.flags & 9u) == 0u);
+        pipe_acquire();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (;;) {
             uint32_t j = 0u;
@@ -1033,9 +1035,6 @@ __global__ void __launch_bounds__(VAR == 1 ? 512 : 256) k_pipeline(const Params 
 // dispatcher hands the CU to the next workgroup of the grid.  The rows stay in the tile-major workspace (they are this CU's own
 // and come back from the L2), so the stage phases are bit-for-bit those of the other paths; only the KKT solve rounds differently.
 // ---------------------------------------------------------------------------------------------------------------
-// PAIR: two threads per (instance, stage) in the stage phases (stage_pair): threads [0, T) are the model threads -- and the stage threads
-// of everything else in this kernel: the take-over copies, the records, the hand-back --, threads [T, 2 T) the barrier threads; the
-// wavefronts of both halves share the KKT solves (one instance per wavefront and sweep)
 struct PrestartFromWs {
     __device__ __forceinline__ double z(int, int, int) const { return 0.0; }
     __device__ __forceinline__ double ref0(int, int) const { return 0.0; }
@@ -1208,8 +1207,9 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
             return -1;
         };
         const uint32_t G = gridDim.x;
-        ib0 = entry(blockIdx.x);
-        ib1 = bx > 1 ? entry(2u * G - 1u - blockIdx.x) : -1;            // (V[G + m] belongs to workgroup G - 1 - m)
+        // (list entries: loaded with vector instructions although every lane asks for the same word -- uniform values for the whole launch: scalar registers)
+        ib0 = lds_uniform(entry(blockIdx.x));
+        ib1 = bx > 1 ? lds_uniform(entry(2u * G - 1u - blockIdx.x)) : -1;            // (V[G + m] belongs to workgroup G - 1 - m)
         if (ib0 < 0) return;
         // (bit 30 of an entry: the pipeline's last stage items of the instance's tile wrote the mailbox arrays -- nothing to copy at the takeover)
         in_mb = ((ib0 & HO_IN_MB) ? 1u : 0u) | ((ib1 >= 0 && (ib1 & HO_IN_MB)) ? 2u : 0u);
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
             if (t == 0) sh_mask = (uint32_t)mk;
         }
         lds_barrier();
-        const uint32_t mask = sh_mask;
+        const uint32_t mask = lds_uniform(sh_mask);
         // ---- launches that write the caller's rows themselves (Params::emit): an instance that has just left the mask -- converged, out of iterations,
         //      stalled, given up by the sweeps -- goes out now, from the rows and scalars its last round left in memory (this wavefront's own stores,
         //      drained at the end of that round).  Here and not in the phases: they run at 450+ registers, this is six loads and stores per lane.
@@ -1303,7 +1303,7 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
                 sh_next[1] = carry;
             }
             lds_barrier();
-            const int nx_lev = sh_next[0], carry = sh_next[1];
+            const int nx_lev = lds_uniform(sh_next[0]), carry = lds_uniform(sh_next[1]);
             lds_barrier();
             if (nx_lev <= -2) {
                 const int code = -2 - nx_lev;
@@ -1390,8 +1390,8 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
         if (fresh) {
             build_records();
             const int a0 = ib0 >= 0 ? ib0 : 0, a1 = ib1 >= 0 ? ib1 : a0;
-            dl0 = MPC_UB(P.SC, (uint32_t)SC_DLAST, a0);
-            dl1 = MPC_UB(P.SC, (uint32_t)SC_DLAST, a1);
+            dl0 = lds_uniform((double)MPC_UB(P.SC, (uint32_t)SC_DLAST, a0));
+            dl1 = lds_uniform((double)MPC_UB(P.SC, (uint32_t)SC_DLAST, a1));
             io.ill = ((int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, a0) != 0 ? 1u : 0u) | ((bx > 1 && (int32_t)MPC_UB(P.ISC, (uint32_t)IS_ILL, a1) != 0) ? 2u : 0u);
             if (valid && c.k == 0) {
 #pragma unroll
@@ -1446,7 +1446,7 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
             io.fail = 0u;
             auto finish = [&](int g, bool ok, double delta) {
                 const int bb = g ? ib1 : ib0;
-                if (ok) { if (delta > 0.0) { if (g) dl1 = delta; else dl0 = delta; } }
+                if (ok) { if (delta > 0.0) { if (g) dl1 = lds_uniform(delta); else dl0 = lds_uniform(delta); } }
                 else io.fail |= 1u << g;
                 if (lane != 0) return;
                 // (the workspace rows follow for whoever looks at the instance after this launch; nothing of this round reads them)
@@ -1531,7 +1531,7 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
 // counters of both loop kernels, instances that did not converge: PIPE_FIN_WORDS words at fin_ctl) into the handle's pinned host block (fin_host),
 // so that the host reads it when the stream has drained: no copy command, no kernel of its own behind the loop.  fin_ctl[PIPE_FIN_TICKET] counts the
 // workgroups that have left.
-constexpr uint32_t PIPE_FIN_WORDS = 24, PIPE_FIN_TICKET = 22;
+constexpr uint32_t PIPE_FIN_WORDS = 32, PIPE_FIN_TICKET = 22;
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
                                                                    const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
@@ -1557,32 +1557,8 @@ __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_m
 #endif
 }
 
-// start-point safeguard: one tile of 64 instances per workgroup, two wavefronts -- wave 0 rolls the control guess out,
-// wave 1 measures the dynamics defect of the caller's state guess (both are 30-stage dependent chains of sin/cos/tan)
-template <int NX>
-__global__ void __launch_bounds__(128) k_prestart(const Params Pk) {
-    const PRef P(Pk);
-    __shared__ double th_guess[64];
-    extern __shared__ __attribute__((aligned(16))) double bnd_tab[];            // [LB | UB], (N+1)*NZ doubles each
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = (P.N + 1) * (NX + 2);
-    fill_bounds<4>(P, bnd_tab, nb, (int)threadIdx.x, 128);
-    __syncthreads();
-    const mpc_lds_cptr bnd = (mpc_lds_cptr)(lds_ptr_t)bnd_tab;
-    const int b = (int)(blockIdx.x + (uint32_t)P.tile0) * 64 + lane;
-    double a0lb = 0.0, a0ub = 0.0, th = 0.0;
-    int frow = 1;
-    if (b < P.B) {
-        frow = prestart_a0<NX>(P, b, a0lb, a0ub);
-        th = (wave == 0) ? prestart_chain<NX, true>(P, b, a0lb, a0ub, bnd) : prestart_chain<NX, false>(P, b, a0lb, a0ub, bnd);
-    }
-    if (wave == 1) th_guess[lane] = th;
-    __syncthreads();
-    if (wave == 0 && b < P.B) prestart_decide<NX>(P, b, frow, a0lb, a0ub, th_guess[lane], th);
-}
-
-// The same start-point safeguard with one thread per (instance, stage), the layout of the stage kernel (bx instance columns per
-// workgroup).  The two 30-stage chains of k_prestart are chains of sin / cos / tan only because of how they are written: the defect of
+// Start-point safeguard with one thread per (instance, stage), the layout of the stage kernel (bx instance columns per workgroup).  The two
+// 30-stage chains of prestart_chain (mpc_stage_math.h: what the CPU harness steps) are chains of sin / cos / tan only because of how they are written: the defect of
 // the caller's state guess needs no recursion at all, and in the rollout (delta, v) depend on the controls alone, psi on (delta, v)
 // and (x, y, s) on (v, psi) -- so every transcendental is evaluated by the thread of its stage, and what is left sequential are
 // three short scans x_{k+1} = push_in(x_k + dt f_k) per state, run by the first two stage-threads of every instance from increments
@@ -2557,8 +2533,9 @@ struct mpc_handle {
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
-        int big_wg = 0, stage_timing = 0, groups = 0, pipeline = 1, pipe_ric = 0, pipe_release = 0, pipe_test_abort = 0, pipe_timing = 0, pipe_l2inv = 0;
-        int rescue = 1, loop_async = 1, sync_spin = 1, max_batch = 0, prestart_chains = 0, resident = 0, res_timing = 0, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pair = 0, friction_lb = 0, fuse_start = 1, bound_mask = 1, rescue_wg = 1, wg_trace = 0, wg_list = 1, ho_inline = 1, pipe_help = -1, mb_pipe = 1, start_timing = 0, poison = 0, poison_r0 = 0, poison_r1 = 0;
+        int pipeline = 1, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pipe_help = -1, pipe_test_abort = 0;
+        int rescue = 1, rescue_wg = 1, loop_async = 1, sync_spin = 1, max_batch = 0, friction_lb = 0, bound_mask = 1, big_wg = 0, groups = 0, poison = 0;
+        int timing = 0;                 // profiling aids, a sum of TIMING_* (below): shader-clock stamps printed to stderr; each synchronises
         uint32_t pipe_xcd_mask = 0;
     } knobs;
     // grow-only device scratch of the entry points around the solve (plant step, metrics, FORCES mode): slot -> buffer
@@ -2566,6 +2543,13 @@ struct mpc_handle {
     void* scratch[N_SCRATCH] = {};
     size_t scratch_cap[N_SCRATCH] = {};
 };
+
+// option timing: which kernels stamp their phases with the shader clock (printed to stderr after the solve)
+constexpr int TIMING_STAGE = 1,     // k_stage / k_riccati of the third / fourth iteration (forces one launch per kernel)
+              TIMING_PIPE = 2,      // k_pipeline: sixth work item / pass of every worker
+              TIMING_WG = 4,        // k_solve_wg: third round of every workgroup
+              TIMING_START = 8,     // k_start: every workgroup
+              TIMING_WG_TRACE = 16; // k_solve_wg: start, end and rounds of every workgroup (100 MHz wall clock)
 
 // error text of the last failed mpc_create on this thread (a handle does not exist yet to carry it)
 static thread_local std::string g_create_error;
@@ -2575,82 +2559,54 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     const char* v = value ? value : "";
     const long iv = strtol(v, nullptr, 0);
     const int on = (value == nullptr) ? 0 : ((v[0] == '\0') ? 1 : (int)iv);   // "" (variable set, no value) counts as on
-    if (n == "big_wg") k.big_wg = on != 0;
-    else if (n == "stage_timing") k.stage_timing = on != 0;
-    else if (n == "groups") k.groups = (int)iv;
-    else if (n == "pipeline") k.pipeline = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "pipe_ric") k.pipe_ric = (int)iv;
-    else if (n == "pipe_release") k.pipe_release = on != 0;
-    else if (n == "pipe_test_abort") k.pipe_test_abort = on != 0;
-    else if (n == "pipe_timing") k.pipe_timing = on != 0;
-    else if (n == "pipe_l2inv") k.pipe_l2inv = on != 0;
-    else if (n == "rescue") k.rescue = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "loop_async") k.loop_async = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "sync_spin") k.sync_spin = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
-    else if (n == "prestart_chains") k.prestart_chains = on != 0;
-    else if (n == "resident") k.resident = value == nullptr ? 0 : (int)iv;
-    else if (n == "res_timing") k.res_timing = on != 0;
-    else if (n == "wg_trace") k.wg_trace = on != 0;
-    else if (n == "wg_list") k.wg_list = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "ho_inline") k.ho_inline = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
-    else if (n == "mb_pipe") k.mb_pipe = value == nullptr ? 1 : (v[0] != '0');
-    else if (n == "start_timing") k.start_timing = on != 0;
-    else if (n == "poison") k.poison = on != 0;
-    else if (n == "poison_r0") k.poison_r0 = (int)iv;
-    else if (n == "poison_r1") k.poison_r1 = (int)iv;
+    const int on1 = value == nullptr ? 1 : (v[0] != '0');                     // (switches that default to on: unset = on)
+    if (n == "pipeline") k.pipeline = on1;
     else if (n == "hybrid") k.hybrid = value == nullptr ? 1 : (int)iv;
     else if (n == "hybrid_bx") k.hybrid_bx = value == nullptr ? 0 : (int)iv;
     else if (n == "hybrid_live") k.hybrid_live = value == nullptr ? -1 : (int)iv;
-    else if (n == "fuse_start") k.fuse_start = value == nullptr ? 1 : (int)iv;
-    else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
-    else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
-    else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
+    else if (n == "pipe_help") k.pipe_help = value == nullptr ? -1 : (int)iv;
+    else if (n == "pipe_test_abort") k.pipe_test_abort = on != 0;
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
+    else if (n == "rescue") k.rescue = on1;
+    else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
+    else if (n == "loop_async") k.loop_async = on1;
+    else if (n == "sync_spin") k.sync_spin = on1;
+    else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
+    else if (n == "friction_lb") k.friction_lb = value == nullptr ? 0 : ((std::string(v) == "ipopt") ? 1 : (std::string(v) == "nlp") ? 0 : (int)iv);
+    else if (n == "bound_mask") k.bound_mask = value == nullptr ? 1 : (int)iv;
+    else if (n == "big_wg") k.big_wg = on != 0;
+    else if (n == "groups") k.groups = (int)iv;
+    else if (n == "poison") k.poison = on != 0;
+    else if (n == "timing") k.timing = value == nullptr ? 0 : (int)iv;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     const std::string n(name ? name : "");
-    if (n == "big_wg") *out = k.big_wg;
-    else if (n == "stage_timing") *out = k.stage_timing;
-    else if (n == "groups") *out = k.groups;
-    else if (n == "pipeline") *out = k.pipeline;
-    else if (n == "pipe_ric") *out = k.pipe_ric;
-    else if (n == "pipe_release") *out = k.pipe_release;
-    else if (n == "pipe_test_abort") *out = k.pipe_test_abort;
-    else if (n == "pipe_timing") *out = k.pipe_timing;
-    else if (n == "pipe_l2inv") *out = k.pipe_l2inv;
-    else if (n == "rescue") *out = k.rescue;
-    else if (n == "loop_async") *out = k.loop_async;
-    else if (n == "sync_spin") *out = k.sync_spin;
-    else if (n == "max_batch") *out = k.max_batch;
-    else if (n == "prestart_chains") *out = k.prestart_chains;
-    else if (n == "resident") *out = k.resident;
-    else if (n == "res_timing") *out = k.res_timing;
-    else if (n == "wg_trace") *out = k.wg_trace;
-    else if (n == "wg_list") *out = k.wg_list;
-    else if (n == "ho_inline") *out = k.ho_inline;
-    else if (n == "pipe_help") *out = k.pipe_help;
-    else if (n == "mb_pipe") *out = k.mb_pipe;
-    else if (n == "start_timing") *out = k.start_timing;
-    else if (n == "poison") *out = k.poison;
-    else if (n == "poison_r0") *out = k.poison_r0;
-    else if (n == "poison_r1") *out = k.poison_r1;
+    if (n == "pipeline") *out = k.pipeline;
     else if (n == "hybrid") *out = k.hybrid;
     else if (n == "hybrid_bx") *out = k.hybrid_bx;
     else if (n == "hybrid_live") *out = k.hybrid_live;
-    else if (n == "fuse_start") *out = k.fuse_start;
-    else if (n == "bound_mask") *out = k.bound_mask;
-    else if (n == "rescue_wg") *out = k.rescue_wg;
-    else if (n == "friction_lb") *out = k.friction_lb;
+    else if (n == "pipe_help") *out = k.pipe_help;
+    else if (n == "pipe_test_abort") *out = k.pipe_test_abort;
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
+    else if (n == "rescue") *out = k.rescue;
+    else if (n == "rescue_wg") *out = k.rescue_wg;
+    else if (n == "loop_async") *out = k.loop_async;
+    else if (n == "sync_spin") *out = k.sync_spin;
+    else if (n == "max_batch") *out = k.max_batch;
+    else if (n == "friction_lb") *out = k.friction_lb;
+    else if (n == "bound_mask") *out = k.bound_mask;
+    else if (n == "big_wg") *out = k.big_wg;
+    else if (n == "groups") *out = k.groups;
+    else if (n == "poison") *out = k.poison;
+    else if (n == "timing") *out = k.timing;
     else return MPC_ERR_INVALID;
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"big_wg", "stage_timing", "groups", "pipeline", "pipe_ric", "pipe_release", "pipe_test_abort", "pipe_timing", "pipe_l2inv", "rescue", "loop_async", "sync_spin", "max_batch", "pipe_xcd_mask", "prestart_chains", "resident", "res_timing", "hybrid", "hybrid_bx", "hybrid_live", "pair", "friction_lb", "fuse_start", "bound_mask", "rescue_wg", "wg_trace", "wg_list", "ho_inline", "pipe_help", "mb_pipe", "start_timing", "poison", "poison_r0", "poison_r1"};
+    static const char* names[] = {"pipeline", "hybrid", "hybrid_bx", "hybrid_live", "pipe_help", "pipe_test_abort", "pipe_xcd_mask", "rescue", "rescue_wg", "loop_async",
+                                  "sync_spin", "max_batch", "friction_lb", "bound_mask", "big_wg", "groups", "poison", "timing"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
         for (const char* c = n; *c; ++c) env += (char)toupper(*c);
@@ -2885,7 +2841,7 @@ static bool wants_mailbox(const mpc_handle* h) {
     const mpc_problem_desc& d = h->hp.desc;
     const mpc_handle::Knobs& kn = h->knobs;
     const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
-    return small_wg && d.N + 1 <= 64 && (kn.resident != 0 || (kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled));
+    return small_wg && d.N + 1 <= 64 && kn.hybrid && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled;
 }
 static int ensure_ws(mpc_handle* h, size_t Bp) {
     const bool mb = wants_mailbox(h);
@@ -2998,10 +2954,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const mpc_handle::Knobs& kn = h->knobs;
     const bool small_wg = 4 * (d.N + 1) <= 256 && !kn.big_wg;
     int bx = pick_bx(d.N, small_wg ? 256 : STAGE_MAX_THREADS);
-    // workgroup-resident solve with whole 8-instance workgroups (k_solve_wg, option resident): the stage phases of the streaming paths +
-    // the wave-per-instance MFMA Riccati, no pipeline at all (the hybrid solve uses the same kernel with one wavefront per workgroup)
-    // (option resident: k_solve_wg alone, whatever the batch size -- the stage phases of the streaming paths + the wave-per-instance MFMA Riccati)
-    const bool use_wg = kn.resident != 0 && small_wg && h->ws_mailbox && !trace && !kn.stage_timing && kn.groups <= 0;
     Params P;
     P.mbw_live = 0;
     fill_params(P, h->hp, B, Bp, bx, h->d_ws, h->d_iws, h->d_LB, h->d_UB, h->ws_mailbox);
@@ -3015,7 +2967,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     }
     const int S = d.N + 1;
     const int threads = ((S * bx + 63) / 64) * 64;
-    const bool stage_timing = kn.stage_timing != 0;
+    const bool stage_timing = (kn.timing & TIMING_STAGE) != 0;
     const int nblk = (B + bx - 1) / bx;
     const int nw = threads / 64;
     // LDS: reductions | the larger of (stage exchange, multiplier stash of the 256-thread variant) | prefetch images
@@ -3034,6 +2986,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_riccati<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ric_lds));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_start<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prestart_par<NX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -3043,7 +2996,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stage<NX, false, 512, REF_VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipeline<NX, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_wg<NX, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -3096,12 +3048,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             else hipLaunchKernelGGL((k_stage<NX, false, 512>), dim3(q.nblk), dim3(threads), lds_bytes, q.st, Pg, h->hp.n_mult, h->hp.n_z, stash_rows);
         }
     };
-    if (kn.poison && !h->in_rescue) {           // (debugging aid: NaN into rows [poison_r0, poison_r1) -- 0, 0 = all -- of every tile before the solve)
+    if (kn.poison && !h->in_rescue) {           // (debugging aid: NaN into every row of every tile of the workspace before the solve)
         const WsLayout wl = ws_layout(d.N, d.nx, Bp, h->ws_mailbox);
-        const uint32_t r0 = (uint32_t)std::max(0, kn.poison_r0) & ~1u, r1 = kn.poison_r1 > 0 ? std::min((uint32_t)kn.poison_r1, (uint32_t)wl.rows) : (uint32_t)wl.rows;
-        if (r1 > r0) hipLaunchKernelGGL(k_poison, dim3(1024), dim3(256), 0, stream, h->d_ws, (uint32_t)wl.tile_elems, (uint32_t)wl.ntiles, r0 * 64u, r1 * 64u);
-        if (kn.poison_r0 < 0) fprintf(stderr, "[mpcgpu poison] rows of a tile: Z %zu ZL %zu ZU %zu SO %zu NUO %zu ZLO %zu ZUO %zu LAM %zu REF %zu DZ %zu PK %zu KK %zu BLK %zu ROLL %zu SC %zu FILT %zu OBST %zu end %zu\n",
-                                      wl.Z, wl.ZL, wl.ZU, wl.SO, wl.NUO, wl.ZLO, wl.ZUO, wl.LAM, wl.REF, wl.DZ, wl.PK, wl.KK, wl.BLK, wl.ROLL, wl.SC, wl.FILT, wl.OBST, wl.rows);
+        hipLaunchKernelGGL(k_poison, dim3(1024), dim3(256), 0, stream, h->d_ws, (uint32_t)wl.tile_elems, (uint32_t)wl.ntiles, 0u, (uint32_t)wl.rows * 64u);
     }
     const int cap = d.fixed_iters > 0 ? d.fixed_iters : d.max_iter;
     const int chunk = d.fixed_iters > 0 ? cap : 4;
@@ -3141,7 +3090,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     for (int i = 0; i < 8; ++i) { h->pipe_prof[i] = 0; h->res_prof[i] = 0; }
     bool piped = false;
     // k_solve_wg with `bxw` instances per workgroup (1 or 2: one wavefront per workgroup, four workgroups per CU; bx: a whole CU)
-    // (two threads per (instance, stage) -- option pair -- wherever the doubled workgroup still fits 512 threads)
     // LDS of a k_solve_wg workgroup (ONE wavefront, bxw = 1 or 2 instances): records + bounds table; a restart of the second chance runs the
     // start-point safeguard and the start iterate in the same memory
     auto wg_lds = [&](int bxw) {
@@ -3159,7 +3107,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const uint32_t* wg_list_n = nullptr;
     int wg_grid = 0;
     auto launch_wg = [&](int bxw, const uint32_t* skip_if, uint32_t* stats, uint32_t* fin_ctl) {
-        if (kn.wg_trace && !h->async_loop && !h->in_rescue) {
+        if ((kn.timing & TIMING_WG_TRACE) && !h->async_loop && !h->in_rescue) {
             n_wtrace = (B + bxw - 1) / bxw;
             if (hipMalloc(&t_wtrace.p, sizeof(unsigned long long) * 4 * (size_t)n_wtrace) == hipSuccess) {
                 d_wtrace = t_wtrace.as<unsigned long long>();
@@ -3224,7 +3172,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // the ones closest to convergence and start when the first wavefronts free up, while the tiles leave the pipeline a round earlier --
         // its rounds cost an instance 67 us, a straggler round 25 us (tools/hand_sweep.py: 3 - 5 % per batch on four instance sets at B = 4096,
         // B = 3000 / 8192 and N = 50 likewise; above ~50 of 64 the pipeline no longer carries the bulk)
-        hand = (base >= 64 || !kn.wg_list) ? base : std::max(base, std::min(50, base < 32 ? 7 * base / 4 : 3 * base / 2));
+        hand = base >= 64 ? base : std::max(base, std::min(50, base < 32 ? 7 * base / 4 : 3 * base / 2));
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
     const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
@@ -3237,13 +3185,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int n_xcd = __builtin_popcount(xcd_mask);
     const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
     const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
-    int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
-    if (kn.pipe_ric > 0) n_ric = std::max(1, std::min(kn.pipe_ric, std::min(cu_x / 2, tiles_x)));
+    const int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
     // (threads >= 192: a stage item then covers at least six stages per wavefront and instance column -- the shapes the hand-off timing was measured on)
     const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                           ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                           std::max(lds_bytes, ric_lds) <= lds_max;
-    const bool res_path = (use_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4) || wg_only;
+    const bool res_path = wg_only;         // k_solve_wg alone
     const bool pipe_path = !res_path && eligible && !h->pipe_disabled && kn.pipeline;
     // Both get a control block (abort word, round count, statistics of both loop kernels, count of instances that did not converge, hand-over
     // lists' counters; the pipeline's queues behind them) -- one of two that alternate: the start kernel of a solve zeroes the other one for the
@@ -3285,12 +3232,12 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         const size_t lds_in = (size_t)bx * (2 * n_w - 2 * d.N) * sizeof(double);             // the block's rows of x0 and of the X_ref part of p
         // (the fused kernel keeps the safeguard's LDS and the block's caller rows side by side; two of its workgroups share a CU)
         const size_t lds_red = (size_t)(threads / 64) * 10 * bx * sizeof(double);            // (stage_block's reduction scratch, in front of the safeguard's region)
-        const bool fused = lds_red + lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && !kn.prestart_chains && small_wg && kn.fuse_start;
+        const bool fused = lds_red + lds_pre + 16 + lds_in <= 78 * 1024 && d.N >= 1 && small_wg;
         if (!fused) hipLaunchKernelGGL((k_ingest<NX>), dim3(q.ntl, (n_w + 63) / 64 + (n_w - 2 * d.N + 63) / 64), dim3(256), 0, q.st, Pg);
         if (fused) {
             // (one launch for ingest, safeguard and start iterate: same blocks, same threads)
             DevTmp t_sdbg;
-            if (kn.start_timing && !h->async_loop && G == 1 && hipMalloc(&t_sdbg.p, sizeof(unsigned long long) * 16 * (size_t)q.nblk) == hipSuccess) {
+            if ((kn.timing & TIMING_START) && !h->async_loop && G == 1 && hipMalloc(&t_sdbg.p, sizeof(unsigned long long) * 16 * (size_t)q.nblk) == hipSuccess) {
                 (void)hipMemsetAsync(t_sdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)q.nblk, q.st);
                 Pg.DBG = t_sdbg.as<unsigned long long>();
             }
@@ -3316,10 +3263,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 Pg.DBG = nullptr;
             }
         } else {
-            if (lds_pre <= 64 * 1024 && d.N >= 1 && !kn.prestart_chains)
-                hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);
-            else
-                hipLaunchKernelGGL((k_prestart<NX>), dim3(q.ntl), dim3(128), (size_t)2 * (d.N + 1) * (NX + 2) * sizeof(double), q.st, Pg);
+            hipLaunchKernelGGL((k_prestart_par<NX>), dim3(q.nblk), dim3(threads), lds_pre, q.st, Pg);       // (N = 127, bx = 4: 112 KB of LDS)
             launch_stage(q, true);
         }
         if (G > 1) prof.end(q.st);          // (one stream: the span stays open, the first kernel of the loop starts where it ends)
@@ -3333,7 +3277,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // ---- workgroup-resident solve alone: ALL iterations of every instance in one launch of k_solve_wg
         const int nblk_dbg = (B + hyb_bx - 1) / hyb_bx;
         DevTmp t_rdbg;
-        if (kn.res_timing && !h->async_loop) {
+        if ((kn.timing & TIMING_WG) && !h->async_loop) {
             HIP_TRY(h, hipMalloc(&t_rdbg.p, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg));
             HIP_TRY(h, hipMemsetAsync(t_rdbg.p, 0, sizeof(unsigned long long) * 16 * (size_t)nblk_dbg, stream));
             P.DBG = t_rdbg.as<unsigned long long>();
@@ -3387,20 +3331,20 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             A.xcd_mask = xcd_mask;
             A.items = 64u / (uint32_t)bx;
             A.cap = pipe_cap;
-            A.flags = (kn.pipe_release ? 1u : 0u) | (kn.pipe_test_abort ? 2u : 0u) | (kn.pipe_l2inv ? 8u : 0u);
+            A.flags = kn.pipe_test_abort ? 2u : 0u;
             // the Riccati workers help with the stage items (k_pipeline<.., HELP>) where those are the bottleneck: more than three per stage worker and round
             const bool pipe_help = (kn.pipe_help < 0 ? (int)A.items * tiles_x > 3 * (cu_x - n_ric) : kn.pipe_help != 0);
             A.handover = (uint32_t)hand;
             int32_t* ho_list = nullptr;
             A.ho_list = nullptr;
-            if (hand > 0 && kn.wg_list) {
+            if (hand > 0) {
                 ho_list = static_cast<int32_t*>(scratch_get(h, 36, (size_t)HO_BUCKETS * Bp * sizeof(int32_t)));
                 if (!ho_list) { h->err = "out of device memory"; return MPC_ERR_HIP; }
-                if (kn.ho_inline) A.ho_list = ho_list;
+                A.ho_list = ho_list;
             }
             A.ctl = ctl;
             unsigned long long* d_pdbg = nullptr;
-            if (kn.pipe_timing) {
+            if (kn.timing & TIMING_PIPE) {
                 HIP_TRY(h, hipMalloc(&t_pdbg.p, sizeof(unsigned long long) * 16 * (size_t)h->n_cu));
                 d_pdbg = t_pdbg.as<unsigned long long>();
                 HIP_TRY(h, hipMemsetAsync(d_pdbg, 0, sizeof(unsigned long long) * 16 * (size_t)h->n_cu, stream));
@@ -3408,9 +3352,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             }
             prof.next(3, stream);
             // tiles about to leave the pipeline (at most hand + 16 instances left; never a full tile) write the mailbox arrays in their stage items
-            P.mbw_live = (hand > 0 && kn.mb_pipe) ? std::min(63, hand + 16) : 0;
+            P.mbw_live = hand > 0 ? std::min(63, hand + 16) : 0;
+            // (helping Riccati workers only in the variant with the reference's bound structure compiled in: the general one is at 512 registers with them)
             if (pipe_help && masked) hipLaunchKernelGGL((k_pipeline<NX, 2, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
-            else if (pipe_help) hipLaunchKernelGGL((k_pipeline<NX, 0, true>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else if (masked) hipLaunchKernelGGL((k_pipeline<NX, 2>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             else hipLaunchKernelGGL((k_pipeline<NX, false>), dim3(h->n_cu), dim3(threads), std::max(lds_bytes, ric_lds), stream, P, A, h->hp.n_mult, h->hp.n_z, stash_rows);
             if (hand <= 0) prof.end(stream);
@@ -3418,7 +3362,6 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 if (!h->prof_span) prof.next(5, stream);          // (span mode: the pipeline's span stays open over k_solve_wg)
                 if (ho_list) {
                     // (the counters: words of the control block, zero at the start of every solve)
-                    if (!A.ho_list) hipLaunchKernelGGL(k_ho_lists, dim3(ntiles), dim3(64), 0, stream, P, (const uint32_t*)(ctl + PIPE_ABORT), ho_list, ctl + PIPE_HO, (const uint32_t*)(ctl + PIPE_HDR));
                     wg_list = ho_list; wg_list_n = ctl + PIPE_HO;
                     // as many workgroups as the machine holds at once (four single-wavefront workgroups per CU), each with up to hyb_bx instances
                     wg_grid = std::min((B + hyb_bx - 1) / hyb_bx, std::max(4 * h->n_cu, (int)((size_t)hand * ntiles + hyb_bx - 1) / hyb_bx));
@@ -3454,9 +3397,17 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                 h->pipe_disabled = true;
                 h->resc_in_kernel = h->resc_ran = false;         // (the k_solve_wg behind the abandoned launch returned at once: no instance has had its second chance)
                 // (abort word: 1 option pipe_test_abort, 2 a Riccati worker waited for its tile's stage items [tile << 16 | round; arrivals], 3 a helping
-                //  Riccati worker / 4 a stage worker waited for its queue slot [ticket; queue tail])
-                fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired: code %u, %u / %u); re-running with one launch per kernel\n",
-                        h->h_pipe[0], h->h_pipe[15], h->h_pipe[23]);
+                //  Riccati worker / 4 a stage worker waited for its queue slot [ticket; queue tail]; words 28 - 31 of the block's head)
+                fprintf(stderr, "[mpcgpu] single-launch pipeline abandoned (bounded wait expired: code %u, %u / %u, a millisecond later %u, waited %u ticks); re-running with one launch per kernel\n",
+                        h->h_pipe[0], h->h_pipe[28], h->h_pipe[29], h->h_pipe[30], h->h_pipe[31]);
+                {   // (the arrival counters of all tiles as the launch left them: a tile short of a multiple of its items lost an arrival, one above received a foreign one)
+                    std::vector<uint32_t> sd((size_t)ntiles);
+                    if (hipMemcpy(sd.data(), ctl + PIPE_HDR, sd.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+                        fprintf(stderr, "[mpcgpu]   arrivals per tile (items per tile and round: %u):", A.items);
+                        for (int q = 0; q < ntiles; ++q) fprintf(stderr, " %u%s", sd[q] & 0x7FFFFFFFu, (sd[q] >> 31) ? "r" : "");
+                        fprintf(stderr, "\n");
+                    }
+                }
                 return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
             }
             P.DBG = nullptr;

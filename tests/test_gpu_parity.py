@@ -166,22 +166,19 @@ def test_poisoned_workspace_changes_nothing_on_single_tile_xcds(opts):
 
 @pytest.mark.parametrize("fam,B,masked", [("zamlf_n30_nx6", 4096, True), ("usalf_n50_nx5", 3000, True), ("zamlf_n30_nx5", 2600, False)])
 def test_mailbox_rows_written_by_the_pipeline_equal_the_ones_copied_at_the_hand_over(fam, B, masked):
-    """Option mb_pipe (default 1): the stage items of a tile that is about to leave the pipeline write iterate, multipliers and stage block into the
-    instance-major mailbox arrays as well (Ctx::mbw), and k_solve_wg takes those instances over without copying them out of the tile-major rows
-    (bit 31 of the tile's arrival counter tells it).  With mb_pipe = 0 every workgroup copies its instances itself.  Same values either way: rows,
-    statuses and iteration counts must be the same bits, run after run -- stale mailbox rows of an earlier solve (a different batch is solved in
-    between) or a tile flagged without its last items having written them would show here."""
+    """The stage items of a tile that is about to leave the pipeline write iterate, multipliers and stage block into the instance-major mailbox
+    arrays as well (Ctx::mbw), and k_solve_wg takes those instances over without copying them out of the tile-major rows (bit 31 of the tile's
+    arrival counter tells it).  Rows, statuses and iteration counts of a batch must be the bits of its first solve on a fresh handle, run after
+    run -- stale mailbox rows of an earlier solve (a different batch is solved in between) or a tile flagged without its last items having written
+    them would show here.  (Round 5 compared with the copying take-over, option mb_pipe = 0, bit for bit; the option is gone with its use.)"""
     cfg, kw = FAMILIES[fam]
     x0, p = synthetic_batch(cfg, B, **kw)
     x0b, pb = synthetic_batch(cfg, B, start=50000, **kw)
     s = make_solver(cfg)
     if masked:
         set_cfg_bounds(s, cfg)
-    assert s.get_option("mb_pipe") == 1
-    s.set_option("mb_pipe", "0")
     ref = s.solve(x0, p)
     assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"] and np.all(ref.status == 1)
-    s.set_option("mb_pipe", "1")
     for rep in range(3):
         other = s.solve(x0b, pb)                                           # (leaves ITS rows in the mailbox)
         assert np.all(other.status == 1)
@@ -219,10 +216,12 @@ def test_compiled_in_bound_structure_against_the_run_time_lookup(fam):
 
 
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n30_nx5", "usalf_n50_nx5", "ca", "transposed"])
-def test_stage_parallel_start_point_safeguard_equals_the_two_chain_kernel(fam):
-    """k_prestart_par (one thread per instance and stage, three short scans) against k_prestart (two sequential 30-stage chains per
-    instance): same rollout, same decisions, hence the same solve bit for bit -- lane following, the long horizon, collision-avoidance
-    cold starts, and the reference's transposed step-0 state guess, for which the safeguard takes the rollout"""
+def test_start_point_safeguard_in_the_fused_start_kernel_and_on_its_own(fam):
+    """The start-point safeguard (one thread per instance and stage, three short scans) inside k_start -- guess and reference read from LDS -- against
+    the same code as a kernel of its own behind k_ingest (k_prestart_par + k_stage<INIT>: what horizons above 63 use; forced here by the 512-thread
+    stage workgroups of option big_wg): same rollout, same decisions, hence the same solve bit for bit -- lane following, the long horizon,
+    collision-avoidance cold starts, and the reference's transposed step-0 state guess, for which the safeguard takes the
+    rollout.  (The two-chain form of the safeguard, prestart_chain, is what the CPU harness steps: tests/test_emulated_kernels.py.)"""
     if fam == "ca":
         cfg, (x0, p) = CA_CFG, ca_batch(CA_CFG, 300)
     elif fam == "transposed":
@@ -238,8 +237,10 @@ def test_stage_parallel_start_point_safeguard_equals_the_two_chain_kernel(fam):
     s = make_solver(cfg)
     set_cfg_bounds(s, cfg)
     s.set_option("rescue", "0")
+    s.set_option("hybrid", "0")
+    s.set_option("pipeline", "0")               # (one launch per kernel on both sides: the 512-thread kernels have no pipeline)
     new = s.solve(x0, p)
-    s.set_option("prestart_chains", "1")
+    s.set_option("big_wg", "1")
     old = s.solve(x0, p)
     assert _same(new, old)
     if fam == "transposed":
@@ -302,10 +303,10 @@ def test_pipeline_on_a_subset_of_the_xcds(mask, monkeypatch):
     assert s.get_pipeline_profile()["ran"] and _same(alt, ref)
 
 
-def test_pipeline_release_protocol_and_restart(monkeypatch):
-    """(1) MPCGPU_PIPE_RELEASE adds agent-scope releases on the producers (the hand-off that does not rely on a tile
-    staying inside one XCD's L2): same bits.  (2) MPCGPU_PIPE_TEST_ABORT raises the pipeline's abort word: the host
-    must notice, start over with one launch per kernel from the untouched inputs, and stay on that path."""
+def test_pipeline_restart(monkeypatch):
+    """Option pipe_test_abort raises the pipeline's abort word: the host must notice, start over with one launch per kernel from the
+    untouched inputs, and stay on that path -- also when rows of the abandoned attempt have already reached the caller's buffers (the loop
+    kernels write them themselves): the restart overwrites every one of them."""
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 2048, **kw)
     s = make_solver(cfg)
@@ -313,9 +314,7 @@ def test_pipeline_release_protocol_and_restart(monkeypatch):
     s.set_option("pipeline", "0")
     ref = s.solve(x0, p)
     s.set_option("pipeline", "1")
-    s.set_option("pipe_release", "1")
     assert _same(s.solve(x0, p), ref) and s.get_pipeline_profile()["ran"]
-    s.set_option("pipe_release", None)
     s.set_option("pipe_test_abort", "1")
     assert _same(s.solve(x0, p), ref) and not s.get_pipeline_profile()["ran"]
     s.set_option("pipe_test_abort", None)
@@ -962,8 +961,8 @@ def test_instances_per_wavefront_follow_the_batch_size():
 
 @pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "usalf_n50_nx5", "ca"])
 def test_wave_per_instance_kernel_options_agree(fam):
-    """k_solve_wg alone (hand-over threshold 64) with one or two instances per wavefront, and with a whole 8-instance workgroup
-    (option resident = 1): an instance's result does not depend on which instance shares its wavefront -- bit-identical"""
+    """k_solve_wg alone (hand-over threshold 64) with one or two instances per wavefront: an instance's result does not depend on which
+    instance shares its wavefront -- bit-identical"""
     if fam == "ca":
         cfg = CA_CFG
         x0, p = ca_batch(cfg, 256)
@@ -987,11 +986,7 @@ def test_wave_per_instance_kernel_options_agree(fam):
             assert rp["sweeps"] > rp["workgroup_rounds"] and (st == -7).any()
             if bx == "2":
                 assert ((st[0::2] == -7) != (st[1::2] == -7)).any()
-    s.set_option("hybrid", "0")
-    s.set_option("resident", "1")
-    res.append(s.solve(x0, p))
-    assert s.get_resident_profile()["ran"]
-    assert _same(res[0], res[1]) and _same(res[0], res[2])
+    assert _same(res[0], res[1])
     ro = OracleSolver(cfg).solve_batch(x0[:64], p[:64], nthreads=8)
     both = (res[0].status[:64] == 1) & (ro["status"] == 1)
     assert both.mean() > 0.9
@@ -1001,62 +996,7 @@ def test_wave_per_instance_kernel_options_agree(fam):
         assert np.mean(np.abs(res[0].x[:64][both] - ro["x"][both]).max(axis=1) < 1e-6) > 0.9
 
 
-# ---- option pair: two threads per (instance, stage) in the stage phases (measured, not the default: profiles/r04_stage_split.txt) ---------------
-
-@pytest.mark.skipif(os.environ.get("MPC_TEST_PAIR", "0") != "1", reason="variant 1 of the kernels is only in a -DMPC_WITH_PAIR=1 build (a measured no-go: profiles/r04_stage_split.txt)")
-@pytest.mark.parametrize("fam,B", [("zamlf_n30_nx6", 4096), ("zamlf_n30_nx6", 200), ("zamlf_n10_nx5", 1000), ("ca", 256)])
-def test_two_threads_per_stage_option(fam, B):
-    """`pair = 1`: the model thread and the inequality thread of every (instance, stage) in different wavefronts (ROLE_A / ROLE_B of
-    mpc_stage_math.h), in the pipeline's stage workers and in k_solve_wg -- against the oracle like the default path, and the rows a
-    second solve returns are the same bits"""
-    if fam == "ca":
-        cfg = CA_CFG
-        x0, p = ca_batch(cfg, B)
-    else:
-        cfg, kw = FAMILIES[fam]
-        x0, p = synthetic_batch(cfg, B, **kw)
-    s = make_solver(cfg)
-    if fam == "ca":
-        set_cfg_bounds(s, cfg)
-    s.set_option("pair", "1")
-    assert s.get_option("pair") == 1
-    r = s.solve(x0, p)
-    r2 = s.solve(x0, p)
-    assert np.array_equal(r.x, r2.x) and np.array_equal(r.iters, r2.iters)
-    sub = slice(0, B, max(1, B // 64))
-    ro = OracleSolver(cfg).solve_batch(x0[sub], p[sub], nthreads=8)
-    if fam == "ca":
-        assert np.all(r.status == 1)
-        nlp = BicycleNLP(cfg)
-        lbg, ubg, _, _ = nlp.bounds()
-        for b in range(0, B, 16):
-            g = nlp.g(r.x[b], p[b])
-            assert np.all(g >= lbg - 1e-6) and np.all(g <= ubg + 1e-6)
-    else:
-        assert np.all(r.status == 1) and r.kkt.max() <= 1e-8
-        assert np.array_equal(r.iters[sub], ro["iters"]) and np.abs(r.x[sub] - ro["x"]).max() < TOL_ORACLE
-
-
-# ---- advisor round 3: the hand-off fence of the pipeline and the batch dependence of the hybrid solve ---------------------------------------
-
-@pytest.mark.parametrize("hybrid", ["1", "0"])
-def test_l1_only_acquire_equals_the_agent_scope_acquire(hybrid):
-    """consumer side of a hand-off inside the pipeline: `buffer_inv sc0` (this CU's vector L1 only -- producer and consumer of a tile share
-    an XCD, hence an L2; the default) against the agent-scope acquire of the memory model (option pipe_l2inv = 1).  The same bits over
-    repeated solves of two batch shapes, with and without the hand-over to k_solve_wg: a stale L1 line would show as a changed row."""
-    for fam, B in (("zamlf_n30_nx6", 4096), ("usalf_n50_nx5", 3000)):
-        cfg, kw = FAMILIES[fam]
-        x0, p = synthetic_batch(cfg, B, **kw)
-        s = make_solver(cfg)
-        s.set_option("hybrid", hybrid)
-        s.set_option("pipe_l2inv", "1")
-        ref = s.solve(x0, p)
-        assert s.get_pipeline_profile()["ran"] and np.all(ref.status == 1)
-        for rep in range(12):
-            s.set_option("pipe_l2inv", str(rep & 1))
-            r = s.solve(x0, p)
-            assert np.array_equal(r.x, ref.x) and np.array_equal(r.iters, ref.iters), (fam, rep)
-
+# ---- advisor round 3: the batch dependence of the hybrid solve ---------------------------------------
 
 def test_hybrid_solve_keeps_the_basin_of_every_collision_avoidance_instance_under_permutation():
     """the hybrid solve's KKT solver of an iteration depends on how many instances of the 64-instance tile still iterate (DESIGN.md section 4,
@@ -1115,25 +1055,3 @@ def test_mfma_riccati_unit_test_binary():
     assert "with an indefinite stage" in r.stdout and "mismatching sweep counts 0" in r.stdout
 
 
-@pytest.mark.parametrize("fam", ["zamlf_n30_nx6", "zamlf_n10_nx5", "usalf_n50_nx5", "ca"])
-def test_fused_start_kernel_equals_the_two_launches(fam):
-    """start-point safeguard + start iterate in one launch (k_start, the default) against the two kernels (option fuse_start = 0): the
-    same bits, also from the reference's transposed step-0 guess, where the safeguard replaces the state guess by its rollout"""
-    if fam == "ca":
-        cfg = CA_CFG
-        x0, p = ca_batch(cfg, 300)
-    else:
-        cfg, kw = FAMILIES[fam]
-        x0, p = synthetic_batch(cfg, 300, **kw)
-    x0 = x0.copy()
-    N, nx = cfg.N, cfg.nx
-    x0[::3, 2 * N:] = x0[::3, 2 * N:].reshape(-1, N + 1, nx).transpose(0, 2, 1).reshape(100, -1)     # every third row: states in the transposed layout
-    s = make_solver(cfg)
-    if fam == "ca":
-        set_cfg_bounds(s, cfg)
-    assert s.get_option("fuse_start") == 1
-    a = s.solve(x0, p)
-    s.set_option("fuse_start", "0")
-    b = s.solve(x0, p)
-    assert np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters) and np.array_equal(a.status, b.status)
-    assert (a.status == 1).mean() > 0.9

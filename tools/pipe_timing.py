@@ -1,5 +1,5 @@
 """Per-phase shader-clock stamps of the single-launch pipeline (k_pipeline), printed to stderr by the library:
-the sixth work item of every stage worker and the sixth pass of every Riccati worker (MPCGPU_PIPE_TIMING=1).
+the sixth work item of every stage worker and the sixth pass of every Riccati worker (option timing = 2).
 Usage (GPU box): python tools/pipe_timing.py [B] [fixed_iters]"""
 import os
 import sys
@@ -15,6 +15,6 @@ cfg, kw = FAMILIES["zamlf_n30_nx6"]
 x0, p = synthetic_batch(cfg, B, **kw)
 s = make_solver(cfg, fixed_iters=fixed) if fixed else make_solver(cfg)
 s.solve(x0, p)                                  # warm-up (allocations, first-touch)
-s.set_option("pipe_timing", "1")
+s.set_option("timing", "2")
 s.solve(x0, p)
 s.solve(x0, p)

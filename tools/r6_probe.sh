@@ -3,8 +3,6 @@
 O=${1:-gpurun_out/r6probe}; TAG=${2:-base}; mkdir -p $O
 (timeout 600 python tools/bits_dump.py $TAG) > $O/bits_$TAG.txt 2>&1
 (for i in 1 2 3; do timeout 200 python tools/ab_time.py 4096 zamlf_n30_nx6 $TAG; done
- MPC_AB_OPTS="pipe_l2inv=1" timeout 200 python tools/ab_time.py 4096 zamlf_n30_nx6 ${TAG}_l2inv
- MPC_AB_OPTS="pipe_l2inv=1" timeout 200 python tools/ab_time.py 4096 zamlf_n30_nx6 ${TAG}_l2inv
  timeout 200 python tools/ab_time.py 256 zamlf_n30_nx6 $TAG
  timeout 200 python tools/ab_time.py 4096 usalf_n50_nx5 $TAG
  timeout 200 python tools/ab_time.py 1024 ca $TAG

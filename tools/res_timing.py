@@ -9,6 +9,6 @@ cfg, kw = FAMILIES["zamlf_n30_nx6"]
 x0, p = synthetic_batch(cfg, B, **kw)
 s = make_solver(cfg)
 s.set_option("hybrid", "1"); s.set_option("hybrid_bx", sys.argv[2] if len(sys.argv) > 2 else "1"); s.set_option("hybrid_live", sys.argv[3] if len(sys.argv) > 3 else "64")
-s.set_option("res_timing", "1")
+s.set_option("timing", "4")
 r = s.solve(x0, p); r = s.solve(x0, p)
 print(s.get_resident_profile())

@@ -1,4 +1,4 @@
-"""Shader-clock stamps of k_start (option start_timing): rows -> LDS, Z / REF stores, start-point safeguard, start iterate phase by phase.
+"""Shader-clock stamps of k_start (option timing = 8): rows -> LDS, Z / REF stores, start-point safeguard, start iterate phase by phase.
 Usage (GPU box): python tools/start_timing.py [B] [family]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -12,6 +12,6 @@ s = make_solver(cfg)
 set_cfg_bounds(s, cfg)
 for _ in range(3):
     s.solve(x0, p)
-s.set_option("start_timing", "1")
+s.set_option("timing", "8")
 for _ in range(3):
     s.solve(x0, p)
