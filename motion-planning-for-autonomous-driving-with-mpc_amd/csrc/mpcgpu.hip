@@ -3294,7 +3294,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         HIP_TRY(h, wait_stream(h, stream));          // (the last workgroup to leave has put the block's head into h_pipe)
         h->h_fail[0] = h->h_pipe[14];
         for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
-        if (h->resc_ran) h->rescued_last = (int)h->h_pipe[20];
+        if (h->resc_ran && !h->in_rescue) h->rescued_last = (int)h->h_pipe[20];
         report_wtrace();
         if (P.DBG) {          // shader-clock stamps of every workgroup's third round
             std::vector<unsigned long long> hd((size_t)16 * nblk_dbg);
@@ -3386,7 +3386,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             h->h_fail[0] = h->h_pipe[14];
             report_wtrace();
             for (int q = 0; q < 4; ++q) h->h_fail[2 + q] = h->h_pipe[16 + q];
-            if (h->resc_ran) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
+            if (h->resc_ran && !h->in_rescue) h->rescued_last = (int)h->h_pipe[20];       // (fifth word: instances that took the second chance inside the launch)
             if (hand > 0) {        // the stragglers' kernel: rounds of its slowest workgroup, workgroups, workgroup-rounds, sweeps, instance-iterations
                 h->res_prof[1] = 1; h->res_prof[2] = h->h_fail[2]; h->res_prof[3] = wg_grid > 0 ? wg_grid : (B + hyb_bx - 1) / hyb_bx;      // (workgroups launched: what the machine holds when they are dealt from the hand-over lists)
                 h->res_prof[4] = h->h_fail[3]; h->res_prof[5] = h->h_fail[4]; h->res_prof[6] = h->h_fail[5];

@@ -270,65 +270,67 @@ class CasadiOptimizer(Optimizer):
             ok = bool(np.all(st == 1))
             sol._stats = dict(status=st[0].copy(), success=ok, return_status="Solve_Succeeded" if ok else "Not_Converged")
             return traj[0], ctrl[0], np.full(self.iter_length, (time.time() - t_) / self.iter_length)
-        t0 = 0.0
-        init_state = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation]).reshape(-1, 1)
-        current_state = init_state.copy()
-        u0 = np.array([0.0, 0.0] * N).reshape(-1, 2).T
-        next_trajectories = np.tile(current_state.reshape(1, -1), N + 1).reshape(N + 1, -1)
-        next_states = next_trajectories.copy()
-        next_controls = np.zeros((N, 2))
-        u_c, traj, index_t = [], [], []
-        for i in range(self.iter_length):
-            c_p = np.concatenate((next_controls.reshape(-1, 1), next_trajectories.reshape(-1, 1)))
-            # (the reference's warm-start layouts, including their transposition quirks: optimizer.py:602)
-            init_control = np.concatenate((u0.T.reshape(-1, 1), next_states.T.reshape(-1, 1)))
-            t_ = time.time()
+        # ---- host-side loop: one solve per step through `sol(...)`, the plant and the warm start on the host.  Not the default path (the device
+        #      loop above is); it is what runs the reference's unseeded noise and what tests/ check the device loop against.  State of the loop:
+        #      the measured state, the last plan (controls 2 x N, states nx x (N + 1)) and whether a plan exists yet.
+        x_now = np.array([self.init_position[0], self.init_position[1], 0.0, self.init_velocity, self.init_orientation], dtype=float)
+        plan_u, plan_x = np.zeros((num_controls, N)), np.tile(x_now[:, None], (1, N + 1))
+        window = np.tile(x_now, (N + 1, 1))                       # step 0 tracks the initial state itself
+        applied, visited, seconds = [], [x_now.copy()], []
+        for step in range(self.iter_length):
+            p_vec = np.concatenate((np.zeros(num_controls * N), window.ravel()))[:, None]           # [U_ref = 0 | X_ref], optimizer.py:552
+            w0 = self.warm_start(plan_u, plan_x, first=(step == 0))
+            tic = time.time()
             sol, f = self.solver()
-            res = sol(x0=init_control, p=c_p, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)
-            index_t.append(time.time() - t_)
-            estimated_opt = res["x"].full()
-            u0 = estimated_opt[:int(num_controls * N)].reshape(N, num_controls).T
+            w = sol(x0=w0, p=p_vec, lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)["x"].full().ravel()
+            seconds.append(time.time() - tic)
+            plan_u = w[:num_controls * N].reshape(N, num_controls).T
+            plan_x = w[num_controls * N:].reshape(N + 1, num_states).T
             if noised:
-                # optimizer.py:611-615 draws 20 samples (N = 10); generalised to 2 N samples for other horizons
-                if seed is None:
-                    u0 = u0 + np.random.normal(0, sigma, 2 * N).reshape(num_controls, N)
-                else:
-                    u0 = u0 + _noise.sequence_noise(int(seed), 0, i, N, sigma)
-            x_m = estimated_opt[int(num_controls * N):].reshape(N + 1, num_states).T
-            u_c.append(u0[:, 0])
-            t0, current_state, u0, next_states = self.shift_movement(t0, current_state, u0, x_m, f)
-            current_state = ca.reshape(current_state, -1, 1).full()
-            next_trajectories, next_controls = self.desired_command_and_trajectory(i, current_state, N)
-            traj.append(current_state)
-        t_v = np.array(index_t)
-        u = np.array(u_c)
-        traj_s = np.array(np.squeeze(traj))
-        traj_s = np.insert(traj_s, 0, init_state.T, axis=0)
-        traj_s = np.delete(traj_s, -1, axis=0)
-        return traj_s, u, t_v
+                # optimizer.py:611-615 perturbs the WHOLE predicted input sequence (20 samples at N = 10; 2 N here), applies its first column and
+                # shifts the perturbed sequence into the next warm start
+                eps = np.random.normal(0, sigma, 2 * N).reshape(num_controls, N) if seed is None else _noise.sequence_noise(int(seed), 0, step, N, sigma)
+                plan_u = plan_u + eps
+            applied.append(plan_u[:, 0].copy())
+            x_now = x_now + self.delta_t * np.asarray(f(x_now, plan_u[:, 0]).full()).ravel()          # forward Euler plant, optimizer.py:649-651
+            plan_u, plan_x = self.shift(plan_u), self.shift(plan_x)
+            window, _ = self.desired_command_and_trajectory(step, x_now, N)
+            visited.append(x_now.copy())
+        # (what the reference returns: the states the solver was called AT -- the last propagated one is dropped, optimizer.py:639-641)
+        return np.array(visited[:-1]), np.array(applied), np.array(seconds)
+
+    @staticmethod
+    def shift(plan):
+        """a plan (columns = stages) moved one step ahead: the first column leaves, the last one is repeated (optimizer.py:653-654)"""
+        return np.concatenate((plan[:, 1:], plan[:, -1:]), axis=1)
+
+    @staticmethod
+    def warm_start(plan_u, plan_x, first):
+        """The vector handed to `sol(x0=...)`, with the layouts the reference's reshapes produce (optimizer.py:602) -- they are
+        part of the behaviour: IPOPT starts where they put it.  The solver expects [u_0 .. u_{N-1} | x_0 .. x_N] stage by stage.
+          states:   step 0 hands them over COMPONENT-major ([sx of all stages, sy of all stages, ...]: `next_states` is (N + 1, nx) there and is
+                    transposed before it is flattened); from step 1 on stage-major, as expected
+          controls: from step 1 on COMPONENT-major ([all steering rates, all accelerations]: `shift_movement` returns the transpose); at step 0 they
+                    are zeros either way"""
+        u_part = plan_u.ravel() if not first else np.zeros(plan_u.size)              # (2, N) row-major = component-major
+        x_part = plan_x.ravel() if first else plan_x.T.ravel()                       # (nx, N + 1) row-major = component-major; transposed = stage-major
+        return np.concatenate((u_part, x_part))[:, None]
 
     def shift_movement(self, t0, x0, u, x_f, f):
-        """optimizer.py:645-655."""
-        f_value = f(x0, u[:, 0])
-        st = x0 + self.delta_t * f_value.full()
-        t = t0 + self.delta_t
-        u_end = np.concatenate((u[:, 1:], u[:, -1:]), axis=1)
-        x_f = np.concatenate((x_f[:, 1:], x_f[:, -1:]), axis=1)
-        return t, st, u_end.T, x_f
+        """the reference's method of that name (optimizer.py:645-655), kept for callers that use it: Euler plant step + shifted plan; note the
+        TRANSPOSED controls it returns (App. C-7)"""
+        x_next = x0 + self.delta_t * f(x0, u[:, 0]).full()
+        return t0 + self.delta_t, x_next, self.shift(u).T, self.shift(x_f)
 
     def desired_command_and_trajectory(self, i, x0_, N_):
-        """optimizer.py:657-702: reference window, frozen to the last N path points once i >= L - N."""
-        x_ = x0_.reshape(1, -1).tolist()[0]
-        u_ = []
+        """Reference window of step i (optimizer.py:657-702): row 0 = the measured state, row 1 + k = (path point, delta = 0, desired velocity,
+        path heading) at index i + 1 + k -- and once i >= L - N the window stops moving: it stays on the LAST N points of the path (App. C-10)."""
         L = self.iter_length
-        for k in range(N_):
-            idx = i + k + 1
-            if i >= L - self.predict_horizon:
-                idx = i + k + 1 - (i - (L - self.predict_horizon) + 1)
-            x_ += [self.resampled_path_points[idx, 0], self.resampled_path_points[idx, 1], 0.0, self.desired_velocity,
-                   self.orientation[idx]]
-            u_ += [0, 0]
-        return np.array(x_).reshape(N_ + 1, -1), np.array(u_).reshape(N_, -1)
+        first = min(i, L - self.predict_horizon - 1) + 1 if i >= L - self.predict_horizon else i + 1
+        idx = first + np.arange(N_)
+        rows = np.column_stack((self.resampled_path_points[idx, 0], self.resampled_path_points[idx, 1], np.zeros(N_),
+                                np.full(N_, float(self.desired_velocity)), np.asarray(self.orientation)[idx]))
+        return np.vstack((np.asarray(x0_, dtype=float).reshape(1, -1), rows)), np.zeros((N_, 2))
 
 
 class ForcesInfo(object):

@@ -910,6 +910,8 @@ int mpco_solve_batch(const mpco_desc* d, const double* lbx, const double* ubx, i
          * unmapping (and faulting in) its workspaces on every call made every other batch 15 x slower than its neighbours (6.5 / 94 ms) */
         static _Thread_local work_t* tls_W = NULL;
         if (!tls_W) tls_W = (work_t*)malloc(sizeof(work_t));
+        /* (never freed: it lives as long as the thread.  A failed malloc leaves NULL: solve_impl then allocates -- and checks -- a workspace of its
+         *  own per instance.  solve_impl zeroes the whole workspace first thing, so an instance never sees what the previous one left in it.) */
         work_t* W = tls_W;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 4)

@@ -492,6 +492,40 @@ def test_second_chance_paths_agree_when_levels_fail(max_iter):
         assert len(lost) > 0 and len(by_pass2) > 0, (len(lost), len(won), len(by_pass2))
 
 
+def test_second_chance_behind_the_pipeline_with_one_instance_per_wavefront():
+    """advisor, round 5: the configuration the two tests above do not reach -- collision avoidance at B = 4096 with one instance per wavefront of
+    k_solve_wg (hybrid_bx = 1): the pipeline runs first, k_solve_wg<.., RESC> takes its instances from the hand-over lists, so the instance of a
+    workgroup is a LIST ENTRY, not #blockIdx.x (the second chance once restarted the wrong instance), and an instance that stalls INSIDE the pipeline
+    is on no list: it must still get its levels (rescue_dev, behind the launch).  Against the host-side second chance alone (rescue_wg = 0): every
+    instance converges either way, the same instances are rescued, rows agree to the hybrid solve's round-off (the KKT solver that serves an
+    iteration differs between the two), and the rescued rows certify against the NLP alone."""
+    from helpers import kkt_certificate
+    B = 4096
+    x0, p = ca_batch(CA_CFG, B)
+    s = make_solver(CA_CFG)
+    set_cfg_bounds(s, CA_CFG)
+    s.set_option("hybrid_bx", "1")
+    a = s.solve(x0, p)
+    na = s.last_rescued()
+    assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+    s.set_option("rescue_wg", "0")
+    b = s.solve(x0, p)
+    nb = s.last_rescued()
+    assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+    s.set_option("rescue", "0")
+    plain = s.solve(x0, p)
+    stalled = np.flatnonzero(plain.status != 1)
+    assert len(stalled) > 0 and na == nb == len(stalled)
+    assert np.all(a.status == 1) and np.all(b.status == 1)
+    same_basin = np.abs(a.x - b.x).max(axis=1) < 1e-6
+    assert same_basin.mean() > 0.99 and np.all(same_basin[plain.status == 1])
+    nlp = BicycleNLP(CA_CFG)
+    for i in stalled[:6]:
+        cert = kkt_certificate(nlp, a.x[i], p[i])
+        assert cert["stationarity"] <= 1e-6 and cert["feasibility"] <= 1e-6, (i, cert)
+        assert a.iters[i] > plain.iters[i]
+
+
 def test_fixed_iteration_mode_matches_converged():
     cfg, kw = FAMILIES["zamlf_n30_nx6"]
     x0, p = synthetic_batch(cfg, 512, **kw)
