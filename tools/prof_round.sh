@@ -1,5 +1,5 @@
 set -u
-O=${1:-gpurun_out/r5prof}; mkdir -p $O
+O=${1:-gpurun_out/r6prof}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O/bench.err; echo bench rc=$?
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/head -o head --output-format csv -- python bench.py --headline-only --no-cpu-baseline --no-traffic > $O/head.log 2>&1; echo head rc=$?
