@@ -667,26 +667,11 @@ MPC_HD void emit_result(const PRef& P, const Ctx<NX>& c, const int status, const
     emit_row<NX>(emit_dst(P), P.N, c.b, c.k, c.z, status, iters, e0);
 }
 
-// ---- two threads per (instance, stage): the ROLE template parameter of the phases ---------------------------------------
-// ROLE_ALL  one thread does all the work of its (instance, stage) -- k_stage, the start-iterate kernel, the emulation harness
-// ROLE_A    the "model" thread: dynamics, cost, equality multipliers, stationarity residual, condensed stage block -- the K rows of
-//           SURVEY.md section 8(d)'s byte model (and the stage-0 friction row when it is kept as a row: rare, and then one lane's business)
-// ROLE_B    the "inequality" thread: the I rows -- every bound side of the variables and the circle-distance rows with their geometry,
-//           slacks and multipliers: multiplier steps, fraction to the boundary, gap products of the trial points (log barrier),
-//           multiplier updates, what the rows add to the condensed Hessian / gradient / stationarity residual
-// The two threads of a pair sit in DIFFERENT wavefronts (the role is wave-uniform: no divergence), share the per-instance scalars
-// (both take part in every reduction) and meet ONCE per iteration outside the reductions: B -> A, IneqOut, through LDS in front of
-// the barrier of the neighbour-stage exchange.  Both evaluate sin / cos of the heading they need (A for the dynamics, B for the circle
-// centres): a sincos costs less than a round trip through LDS with a barrier.  The arithmetic of every term is the same source line
-// in all three instantiations; what differs between ROLE_ALL and the pair is the order in which partial sums of a stage meet.
-constexpr int ROLE_ALL = 0, ROLE_A = 1, ROLE_B = 2;
-#define MPC_RA (ROLE != ROLE_B)
-#define MPC_RB (ROLE != ROLE_A)
-// Whose are the bound sides of variable i of (u, x)?  The inputs' (i < 2) go with the model thread, the states' with the inequality
-// thread -- the split that balances the pair: four sides each on the reference's bounds, plus the three circle rows on B and the
-// dynamics on A.  VM: compile-time mask of the variables that have a bound at SOME stage (0xFF: not known -- every side is looked up
-// in the bounds table at run time); the kernels of the pair are instantiated for the mask of the reference's bounds, where the sides
-// of x, y, psi (and the progress state) vanish from the code together with their registers.
+// VM: compile-time mask of the variables of (u, x) that have a bound at SOME stage (0xFF: not known -- every side is looked up in the bounds
+// table at run time); variant 2 of the kernels is instantiated for the mask of the reference's bounds, where the sides of x, y, psi (and the
+// progress state) vanish from the code together with their registers.  (Round 4's split of a stage thread into a model thread and an
+// inequality thread -- template parameter ROLE, variant 1 of the kernels, measured 40 - 70 % slower: profiles/r04_stage_split.txt -- left the
+// sources in round 6; what remains of it is that phase 4 is written in three pieces, below.)
 // Upper bits of VM: more of the reference's structure compiled in (the host checks the handle before it picks such an instantiation)
 //   VM_OSPEC  circle-distance rows with a lower bound only, multiplicity 3, one obstacle for the whole batch (optimizer.py:395-403, 426-428)
 //   bits 16-23 / 24-31: variables whose LOWER / UPPER bound is there at every stage the variable exists at (optimizer.py:421-491): no
@@ -699,12 +684,11 @@ MPC_HD constexpr uint32_t vm_dense(uint32_t lo, uint32_t hi) { return (lo << 16)
 #define MPC_OMULT ((VM & VM_OSPEC) ? 3 : P.obst_mult)
 #define MPC_HAS_LO(lb_) (((VM >> (16 + i)) & 1u) ? true : has_lo(lb_))
 #define MPC_HAS_HI(ub_) (((VM >> (24 + i)) & 1u) ? true : has_hi(ub_))
-template <int ROLE, uint32_t VM>
-MPC_HD constexpr bool side_mine(int i) { return ((VM >> i) & 1u) != 0u && (ROLE == ROLE_ALL || (ROLE == ROLE_A) == (i < 2)); }
+template <uint32_t VM>
+MPC_HD constexpr bool side_mine(int i) { return ((VM >> i) & 1u) != 0u; }
 // Rows of the hand-over: 3 i + {0, 1, 2} = (sum z/gap, barrier-gradient factor, -zl + zu) of variable i; behind them the circle rows'
 // contributions to the (x, y, psi) entries of rx / gx_a / gx_b (3 each) and to the Hessian entries (xx, xy, xpsi, yy, ypsi, psipsi).
-// The phases take the carrier as a template parameter: IneqOut (registers: ROLE_ALL, the emulation harness) or the kernels' LDS column
-// (put / get of one row at a time: neither thread of a pair ever holds the 39 values at once).
+// (The carrier is a template parameter of the phases: IneqOut, registers.)
 template <int NX>
 struct IneqRows {
     static constexpr int NZ = NX + 2;
@@ -1147,13 +1131,13 @@ MPC_HD void phase_load_scalars(const PRef& P, Ctx<NX>& c) {
 // loads between its two sweeps and reads the record once the forward sweep is through (phase_preload_rec)
 // KEEPC (k_solve_wg, from a workgroup's second round on its instances): what does not change from round to round -- the reference of the next
 // stage, r_0, and whether any instance of the workgroup keeps its friction row at all -- is the caller's business (LDS / a register): no loads
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu, bool REC = true, bool KEEPC = false>
+template <int NX, bool MB = false, uint32_t VM = 0xFFu, bool REC = true, bool KEEPC = false>
 MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool fric_maybe = true) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
     if (!c.valid) return;
     const int N = P.N, k = c.k;
-    if (MPC_RB) load_obst<NX, (VM & 0x100u) != 0u>(P, c);
+    load_obst<NX, (VM & 0x100u) != 0u>(P, c);
     // (rows come in pairs, one 16-byte load per pair: see mpc_prow)
     ws_load_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
     // (MB: step and cost-to-go come from the LDS record the sweeps of this workgroup left them in -- see Rec)
@@ -1168,7 +1152,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
         c.zl[i] = 0.0;
         c.zu[i] = 0.0;
         if (i + 1 < NZ) { c.zl[i + 1] = 0.0; c.zu[i + 1] = 0.0; }
-        const bool mine = side_mine<ROLE, VM>(i) || (i + 1 < NZ && side_mine<ROLE, VM>(i + 1));      // (compile time: whose pair of rows)
+        const bool mine = side_mine<VM>(i) || (i + 1 < NZ && side_mine<VM>(i + 1));      // (compile time: whose pair of rows)
         if (mine && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else c.zl[i] = MPC_KX(ZL, NZ, 0, i);
         }
@@ -1176,7 +1160,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
             if (i + 1 < NZ) MPC_LD2(MPC_KX(ZU, NZ, 0, i), c.zu[i], c.zu[i + 1]); else c.zu[i] = MPC_KX(ZU, NZ, 0, i);
         }
     }
-    if (MPC_RA && k < N) {
+    if (k < N) {
         if (!KEEPC) ws_load_rows<NX>(MPC_ROWS(MPC_K(P.REF, NX, 1, e)), c.rn);           // (constant: read where the start kernel put it, MB or not)
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(Z, NZ, 1, 2 + e)), c.xn);
         if (MB) { if (REC) rec_load<NX>(c.rec + Rec<NX>::SIZE + Rec<NX>::DX, c.dxn); } else ws_load_rows<NX>(MPC_ROWS(MPC_K(P.DZ, NZ, 1, 2 + e)), c.dxn);
@@ -1184,7 +1168,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
 #pragma unroll
         for (int i = 0; i < NX; ++i) { if (!KEEPC) c.rn[i] = 0.0; c.xn[i] = 0.0; c.dxn[i] = 0.0; }
     }
-    if (MPC_RA) {
+    {
         ws_load_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), tmp.lam);
         if (!KEEPC) {
 #pragma unroll
@@ -1196,7 +1180,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
     c.nuo[0] = c.nuo[1] = c.nuo[2] = 0.0;
     c.zlo[0] = c.zlo[1] = c.zlo[2] = 0.0;
     c.zuo[0] = c.zuo[1] = c.zuo[2] = 0.0;
-    if (MPC_RB) {
+    {
         ws_load_rows<3>(MPC_ROWS(MPC_KX(SO, 3, 0, e)), c.so);
         ws_load_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
         if (MPC_HAS_OL) ws_load_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
@@ -1204,7 +1188,7 @@ MPC_HD void phase_preload(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp, const bool
     }
     c.sf = c.dsf = c.nuf = c.zlf = c.zuf = c.dfric0 = 0.0;
     c.gfr0[0] = c.gfr0[1] = c.gfr0[2] = 0.0;
-    if (MPC_RA && k == 0 && fric_maybe) {                  // (fric_row is not known yet; the values are only used if it is set)
+    if (k == 0 && fric_maybe) {                  // (fric_row is not known yet; the values are only used if it is set)
         c.sf = MPC_S(P.SC, SC_SF);
         c.nuf = MPC_S(P.SC, SC_NUF);
         c.zlf = P.has_fl ? (double)MPC_S(P.SC, SC_ZLF) : 0.0;
@@ -1228,13 +1212,13 @@ MPC_HD void phase_preload_rec(const PRef& P, Ctx<NX>& c, PreTmp<NX>& tmp) {
 }
 
 // arithmetic on the loaded arrays only: slack steps ds = J dx + (d - s), multiplier steps dlam = -(P dx + p) - lam
-template <int NX, int ROLE = ROLE_ALL>
+template <int NX>
 MPC_HD void phase_premath(const PRef& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     using D = Dim<NX>;
     if (!c.valid) return;
     // slack steps need the circle distances and their Jacobians at the iterate: recomputed here (the same evaluation
     // phase 4 of the previous launch made, bit for bit) rather than stored and re-read -- the kernel is bandwidth bound
-    if (MPC_RB) {
+    {
         const int oi[3] = {0, 1, 4};
         const Trig tg = psi_trig(c.z[2 + 4]);
 #pragma unroll
@@ -1247,7 +1231,7 @@ MPC_HD void phase_premath(const PRef& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
             c.dso[j] = ds;
         }
     }
-    if (MPC_RA) {
+    {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double s = tmp.pk[D::NS + i];
@@ -1260,7 +1244,7 @@ MPC_HD void phase_premath(const PRef& P, Ctx<NX>& c, const PreTmp<NX>& tmp) {
     }
 }
 
-template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
+template <int NX, uint32_t VM = 0xFFu>
 MPC_HD void phase_step_candidates(const PRef& P, Ctx<NX>& c, Red1& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1278,9 +1262,9 @@ MPC_HD void phase_step_candidates(const PRef& P, Ctx<NX>& c, Red1& red) {
         if (isu && k == N) continue;
         const double zi = c.z[i], dv = c.dz[i];
         double gradf = 0.0;
-        if (MPC_RA && k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
+        if (k < N) gradf = isu ? c.df * 2 * P.R[i] * zi : c.df * 2 * P.Q[i - 2] * (zi - c.rn[i - 2]);
         double gb = 0.0;
-        if (side_mine<ROLE, VM>(i)) {
+        if (side_mine<VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (MPC_HAS_LO(lb)) { side_step(zi - lb, c.zl[i], dv, mu, sel, c.igl[i]); gb -= mu * c.igl[i]; }
             if (MPC_HAS_HI(ub)) { side_step(ub - zi, c.zu[i], -dv, mu, sel, c.igu[i]); gb += mu * c.igu[i]; }
@@ -1292,11 +1276,11 @@ MPC_HD void phase_step_candidates(const PRef& P, Ctx<NX>& c, Red1& red) {
         const double s = c.so[j], ds = c.dso[j];
         double gb = 0.0;
         c.iglo[j] = c.iguo[j] = 0.0;
-        if (MPC_RB && MPC_HAS_OL) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
-        if (MPC_RB && MPC_HAS_OU) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
-        if (MPC_RB) dphi += m * gb * ds;
+        if (MPC_HAS_OL) { side_step(s - P.ol, c.zlo[j], ds, mu, sel, c.iglo[j]); gb -= mu * c.iglo[j]; }
+        if (MPC_HAS_OU) { side_step(P.ou - s, c.zuo[j], -ds, mu, sel, c.iguo[j]); gb += mu * c.iguo[j]; }
+        dphi += m * gb * ds;
     }
-    if (MPC_RA && k == 0 && c.fric_row) {
+    if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf;
         double gb = 0.0, ig;
         if (P.has_fl) { side_step(s - P.fl, c.zlf, ds, mu, sel, ig); gb -= mu * ig; }
@@ -1339,7 +1323,7 @@ MPC_HD void phase_linesearch_begin(const PRef& P, Ctx<NX>& c, const Red1& red) {
 // =========================================================================================================
 // Phase 2: evaluate constraint violation / barrier objective at the trial point w + alpha dw
 // =========================================================================================================
-template <int NX, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
+template <int NX, uint32_t VM = 0xFFu>
 MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1355,18 +1339,18 @@ MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
         const double v = c.z[i] + al * c.dz[i];
         zt[i] = v;
         if (isu && k == N) continue;
-        if (side_mine<ROLE, VM>(i)) {
+        if (side_mine<VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (MPC_HAS_LO(lb)) { const double gap = v - lb; if (gap <= 0) bad = 1.0; else gp *= gap; }
             if (MPC_HAS_HI(ub)) { const double gap = ub - v; if (gap <= 0) bad = 1.0; else gp *= gap; }
         }
-        if (MPC_RA && k < N) {
+        if (k < N) {
             if (isu) fc += P.R[i] * v * v;
             else { const double e = v - c.rn[i - 2]; fc += P.Q[i - 2] * e * e; }
         }
     }
     const Trig tg = psi_trig(zt[2 + 4]);                    // (both threads of a pair: the dynamics and the circle centres need it)
-    if (MPC_RA) {
+    {
         double f[NX], sps = tg.sps, cps = tg.cps, td;
         ode_eval<NX, true>(P, zt + 2, zt, f, sps, cps, td);
         if (k < N) {
@@ -1381,7 +1365,7 @@ MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
             for (int i = 0; i < NX; ++i) theta += fabs(zt[2 + i] - c.r0[i]);
         }
     }
-    if (MPC_RB) {
+    {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double dist = circle_eval(P, c.obst, j, zt[2], zt[3], tg.sps, tg.cps, nullptr, nullptr, false);
@@ -1391,7 +1375,7 @@ MPC_HD void phase_trial_eval(const PRef& P, Ctx<NX>& c, Red2& red) {
             if (MPC_HAS_OU) { const double gap = P.ou - s; if (gap <= 0) bad = 1.0; else gp *= powi_small(gap, m); }
         }
     }
-    if (MPC_RA && k == 0 && c.fric_row) {
+    if (k == 0 && c.fric_row) {
         const double s = c.sf + al * c.dsf;
         const double dfr = friction_eval(P, zt[1], zt[2 + 2], zt[2 + 3], nullptr, nullptr, false);
         theta += fabs(dfr - s);
@@ -1439,7 +1423,7 @@ MPC_HD void phase_linesearch_decide(const PRef& P, Ctx<NX>& c, const Red2& red) 
 // =========================================================================================================
 // Phase 3: accept the step -- update primal, slack, multiplier values, augment the filter
 // =========================================================================================================
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
+template <int NX, bool MB = false, uint32_t VM = 0xFFu>
 MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ;
@@ -1447,9 +1431,9 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     const int N = P.N, k = c.k;
     if (!c.accepted) {                      // line search failed: freeze the instance
         c.active = false;
-        if (MPC_RA && k == 0) { MPC_SCW(ISC, IS_STATUS, STATUS, c.status); MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
+        if (k == 0) { MPC_SCW(ISC, IS_STATUS, STATUS, c.status); MPC_S(P.SC, SC_ALPHA) = 0.0; MPC_S(P.SC, SC_NTRIAL) = c.ntrial; }
         // (the iterate the search started from; MB -- k_solve_wg -- writes the rows of an instance when it leaves the workgroup's mask)
-        if (!MB && ROLE == ROLE_ALL && P.emit) emit_result<NX>(P, c, c.status, c.iters, k == 0 ? (double)MPC_S(P.SC, SC_E0) : 0.0);
+        if (!MB && P.emit) emit_result<NX>(P, c, c.status, c.iters, k == 0 ? (double)MPC_S(P.SC, SC_E0) : 0.0);
         return;
     }
     const double mu = c.mu, al = c.alpha, ad = c.a_du;
@@ -1457,7 +1441,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     for (int i = 0; i < NZ; ++i) {
         if (i < 2 && k == N) continue;
         const double zi = c.z[i], dv = c.dz[i], zn = zi + al * dv;       // (the accepted trial point, formed again)
-        if (side_mine<ROLE, VM>(i)) {
+        if (side_mine<VM>(i)) {
             MPC_BOUNDS(k, i, lb, ub);
             if (MPC_HAS_LO(lb)) { const double ign = mpc_rcp(zn - lb); c.zl[i] = side_update(c.igl[i], c.zl[i], dv, mu, ad, ign); c.igl[i] = ign; }
             if (MPC_HAS_HI(ub)) { const double ign = mpc_rcp(ub - zn); c.zu[i] = side_update(c.igu[i], c.zu[i], -dv, mu, ad, ign); c.igu[i] = ign; }
@@ -1466,14 +1450,14 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         c.z[i] = zn;
     }
     // stores by row pair (the u rows of the terminal stage keep their zeros; multiplier rows of absent bounds keep theirs)
-    if (MPC_RA) ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
-    const bool mbw = !MB && ROLE == ROLE_ALL && c.mbw;           // (wave-uniform: a property of the tile)
+    ws_store_rows<NZ>(MPC_ROWS(MPC_KX(Z, NZ, 0, e)), c.z);
+    const bool mbw = !MB && c.mbw;           // (wave-uniform: a property of the tile)
     if (mbw) ws_store_rows<NZ>(MPC_ROWS(MPC_KI(P.MZ, NZ, 0, e)), c.z);
 #pragma unroll
     for (int i = 0; i < NZ; i += 2) {
         const bool a0 = (i == 0) && (k == 0);
         const uint32_t both = (i + 1 < NZ) ? 3u : 1u;
-        const bool mine = side_mine<ROLE, VM>(i) || (i + 1 < NZ && side_mine<ROLE, VM>(i + 1));
+        const bool mine = side_mine<VM>(i) || (i + 1 < NZ && side_mine<VM>(i + 1));
         if (mine && (((P.lo_mask >> i) & both) || a0)) {
             if (i + 1 < NZ) MPC_ST2(MPC_KX(ZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KX(ZL, NZ, 0, i) = c.zl[i];
             if (mbw) { if (i + 1 < NZ) MPC_ST2(MPC_KI(P.MZL, NZ, 0, i), c.zl[i], c.zl[i + 1]); else MPC_KI(P.MZL, NZ, 0, i) = c.zl[i]; }
@@ -1484,7 +1468,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         }
     }
     // equality multipliers: lambda+ = -(P_k dx_k + p_k), step computed in phase_preload
-    if (MPC_RA) {
+    {
 #pragma unroll
         for (int i = 0; i < NX; ++i) c.lam[i] += al * c.dlam[i];
         ws_store_rows<NX>(MPC_ROWS(MPC_KX(LAM, NX, 0, e)), c.lam);
@@ -1494,22 +1478,22 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
     for (int j = 0; j < 3; ++j) {
         const double s = c.so[j], ds = c.dso[j], sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
-        if (MPC_RB && MPC_HAS_OL) {
+        if (MPC_HAS_OL) {
             const double ig = c.iglo[j], ign = mpc_rcp(sn - P.ol);
             sg += c.zlo[j] * ig; gb -= mu * ig;
             c.zlo[j] = side_update(ig, c.zlo[j], ds, mu, ad, ign);
             c.iglo[j] = ign;
         }
-        if (MPC_RB && MPC_HAS_OU) {
+        if (MPC_HAS_OU) {
             const double ig = c.iguo[j], ign = mpc_rcp(P.ou - sn);
             sg += c.zuo[j] * ig; gb += mu * ig;
             c.zuo[j] = side_update(ig, c.zuo[j], -ds, mu, ad, ign);
             c.iguo[j] = ign;
         }
         (void)s;
-        if (MPC_RB) { c.nuo[j] += al * (gb - c.nuo[j] + sg * ds); c.so[j] = sn; }
+        { c.nuo[j] += al * (gb - c.nuo[j] + sg * ds); c.so[j] = sn; }
     }
-    if (MPC_RB) {
+    {
         if (MPC_HAS_OL) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZLO, 3, 0, e)), c.zlo);
         if (MPC_HAS_OU) ws_store_rows<3>(MPC_ROWS(MPC_KX(ZUO, 3, 0, e)), c.zuo);
         ws_store_rows<3>(MPC_ROWS(MPC_KX(NUO, 3, 0, e)), c.nuo);
@@ -1521,7 +1505,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
             ws_store_rows<3>(MPC_ROWS(MPC_KI(P.MSO, 3, 0, e)), c.so);
         }
     }
-    if (MPC_RA && k == 0 && c.fric_row) {
+    if (k == 0 && c.fric_row) {
         const double s = c.sf, ds = c.dsf, sn = s + al * ds;
         double sg = 0.0, gb = 0.0;
         if (P.has_fl) {
@@ -1541,7 +1525,7 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
         MPC_S(P.SC, SC_SF) = sn;
         c.sf = sn;
     }
-    if (MPC_RA && k == 0) {
+    if (k == 0) {
         // filter augmentation (h-type iteration) and bookkeeping
         if (!c.ftype) {
             int nf = c.nfilt;
@@ -1578,11 +1562,11 @@ MPC_HD void phase_apply_update(const PRef& P, Ctx<NX>& c) {
 //          (requires that Z and LAM of the neighbouring stage are visible: block barrier before)
 // =========================================================================================================
 // REUSE: the update phase ran before and left 1/gap of every bound side at the new iterate in c.ig* (no division here)
-// the inequality rows' share of phase 4 (ROLE_B, or the first part of ROLE_ALL): sigma, barrier-gradient factor and multiplier sum of
+// the inequality rows' share of phase 4: sigma, barrier-gradient factor and multiplier sum of
 // every variable bound; the circle rows with their geometry (distances, Jacobians, Hessians at the new iterate) and what they add to the
 // stationarity residual, the condensed gradient and the condensed Hessian -> xo; complementarity extremes, multiplier sums, gap product,
 // the rows' primal and dual residuals -> kp.  tg: sin / cos of the heading of this stage at the new iterate
-template <int NX, bool REUSE = false, class OUT = IneqOut<NX>, int ROLE = ROLE_ALL, uint32_t VM = 0xFFu>
+template <int NX, bool REUSE = false, class OUT = IneqOut<NX>, uint32_t VM = 0xFFu>
 MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp, const Trig& tg) {
     using D = Dim<NX>;
     using IR = IneqRows<NX>;
@@ -1592,7 +1576,7 @@ MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp,
     const int N = P.N, k = c.k, m = MPC_OMULT;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-        if (!side_mine<ROLE, VM>(i)) continue;            // (rows of the other thread's / of absent sides are never read either)
+        if (!side_mine<VM>(i)) continue;            // (rows of the other thread's / of absent sides are never read either)
         const bool isu = i < 2;
         double sg = 0.0, gbb = 0.0, rz = 0.0;
         if (!(isu && k == N)) {
@@ -1635,20 +1619,18 @@ MPC_HD void phase_ineq_assemble(const PRef& P, Ctx<NX>& c, OUT& xo, KktPart& kp,
     for (int q = 0; q < 6; ++q) xo.put(IR::OH + q, oH[q]);
 }
 
-// Phase 4 comes in two halves, so that the two threads of a pair work side by side for as long as the arithmetic allows:
+// The rest of phase 4 in two pieces:
 //   phase_eval_model   derivatives of the dynamics and the cost at the new iterate, stationarity residual, condensed Hessian -- everything
-//                      that does not need the inequality rows (ROLE_A also: the bound sides of the inputs, its own) -> EvalTmp
-//   phase_eval_finish  adds what the inequality rows contribute (xk: phase_ineq_assemble of this thread for ROLE_ALL, of the other
-//                      thread of the pair -- through LDS, behind a barrier the kernel passes between the halves -- for ROLE_A), then the
-//                      residual norms and the stage-block stores
-// kp: ROLE_ALL the partial results of phase_ineq_assemble, ROLE_A neutral.  TG: sin / cos of the heading are handed in (tg).
+//                      that does not need the inequality rows -> EvalTmp
+//   phase_eval_finish  adds what the inequality rows contribute (xk: phase_ineq_assemble's), then the residual norms and the stage-block stores
+// kp: the partial results of phase_ineq_assemble.  TG: sin / cos of the heading are handed in (tg).
 template <int NX>
 struct EvalTmp {
     double H[Dim<NX>::NS], rx[NX], ru[2], ruu[2], cn[NX], a[6];
     double theta, fc, prim, dual, cmin, cmax, smult, sz, gp;
     double hx0, hx1;              // Hux of stage 0 (the kept friction row's; zero otherwise)
 };
-template <int NX, bool REUSE = false, int ROLE = ROLE_ALL, bool TG = false, uint32_t VM = 0xFFu>
+template <int NX, bool REUSE = false, bool TG = false, uint32_t VM = 0xFFu>
 MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const KktPart& kp, const Trig tg = Trig{0.0, 0.0}) {
     using D = Dim<NX>;
     constexpr int NZ = D::NZ, NS = D::NS;
@@ -1735,19 +1717,6 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
         }
     }
     double gp = kp.gp;                                         // product of all gaps; sum of logs = log(gp)
-    // (ROLE_A: the bound sides of the inputs are this thread's own)
-    if (ROLE == ROLE_A) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!side_mine<ROLE, VM>(i) || k == N) continue;
-            MPC_BOUNDS(k, i, lb, ub);
-            const double zi = c.z[i];
-            double sg = 0.0, gbb = 0.0, rz = 0.0;
-            if (MPC_HAS_LO(lb)) side_kkt(zi - lb, REUSE ? c.igl[i] : mpc_rcp(zi - lb), c.zl[i], 1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-            if (MPC_HAS_HI(ub)) side_kkt(ub - zi, REUSE ? c.igu[i] : mpc_rcp(ub - zi), c.zu[i], -1.0, 1, sg, gbb, rz, cmin, cmax, sz, gp);
-            ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz;
-        }
-    }
     // friction row (stage 0), unless presolved into the bounds of a_0
     t.hx0 = t.hx1 = 0.0;
     if (k == 0 && c.fric_row) {
@@ -1785,7 +1754,7 @@ MPC_HD void phase_eval_model(const PRef& P, Ctx<NX>& c, EvalTmp<NX>& t, const Kk
     t.theta = theta; t.fc = fc; t.prim = prim; t.dual = dual; t.cmin = cmin; t.cmax = cmax; t.smult = smult; t.sz = sz; t.gp = gp;
 }
 
-template <int NX, bool MB = false, int ROLE = ROLE_ALL, class IN = IneqOut<NX>, uint32_t VM = 0xFFu>
+template <int NX, bool MB = false, class IN = IneqOut<NX>, uint32_t VM = 0xFFu>
 MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk, EvalTmp<NX>& t) {
     using D = Dim<NX>;
     using IR = IneqRows<NX>;
@@ -1803,7 +1772,7 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const bool isu = i < 2;
-        if (!side_mine<(ROLE == ROLE_A ? ROLE_B : ROLE_ALL), VM>(i)) continue;
+        if (!side_mine<VM>(i)) continue;
         if (isu && k == N) continue;
         const double sg = xk.get(3 * i + IR::SG), gbb = xk.get(3 * i + IR::GBB), rz = xk.get(3 * i + IR::RZ);
         if (isu) { ruu[i] += sg; c.gub[i] += gbb; ru[i] += rz; }
@@ -1857,7 +1826,7 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
             ws_store_rows<8>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_A + e)), head);
             ws_store_rows<NX>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_CN + e)), cn);
             ws_store_rows<D::NH>(MPC_ROWS(MPC_K(P.BLK, D::NBLK, 0, D::B_H + e)), hh);
-            if (ROLE == ROLE_ALL && c.mbw) {        // (the whole block: k_solve_wg builds its first records from this copy)
+            if (c.mbw) {        // (the whole block: k_solve_wg builds its first records from this copy)
                 ws_store_rows<8>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_A + e)), head);
                 ws_store_rows<NX>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_CN + e)), cn);
                 ws_store_rows<D::NH>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, D::B_H + e)), hh);
@@ -1869,14 +1838,6 @@ MPC_HD void phase_eval_finish(const PRef& P, Ctx<NX>& c, Red3& red, const IN& xk
     red.sum_mult = smult; red.sum_z = sz; red.theta = theta; red.fcost = fc; red.logsum = ls; red.nan = nanflag;
 }
 
-// the inequality thread's share of the KKT-error reduction
-MPC_HD void phase_eval_red_b(bool active, Red3& red, const KktPart& kp) {
-    red = red_neutral3();
-    if (!active) return;
-    red.dual_inf = kp.dual; red.prim_inf = kp.prim; red.cmin = kp.cmin; red.cmax = kp.cmax; red.sum_mult = kp.smult; red.sum_z = kp.sz;
-    red.theta = kp.theta; red.logsum = mpc_log(kp.gp);
-}
-
 // (one thread per (instance, stage): the three pieces back to back, one sincos for all)
 template <int NX, bool REUSE = false, bool MB = false, uint32_t VM = 0xFFu>
 MPC_HD void phase_eval_assemble(const PRef& P, Ctx<NX>& c, Red3& red) {
@@ -1884,15 +1845,15 @@ MPC_HD void phase_eval_assemble(const PRef& P, Ctx<NX>& c, Red3& red) {
     KktPart kp;
     EvalTmp<NX> t;
     const Trig tg = psi_trig(c.z[2 + 4]);
-    phase_ineq_assemble<NX, REUSE, IneqOut<NX>, ROLE_ALL, VM>(P, c, xo, kp, tg);
-    phase_eval_model<NX, REUSE, ROLE_ALL, true, VM>(P, c, t, kp, tg);
-    phase_eval_finish<NX, MB, ROLE_ALL, IneqOut<NX>, VM>(P, c, red, xo, t);
+    phase_ineq_assemble<NX, REUSE, IneqOut<NX>, VM>(P, c, xo, kp, tg);
+    phase_eval_model<NX, REUSE, true, VM>(P, c, t, kp, tg);
+    phase_eval_finish<NX, MB, IneqOut<NX>, VM>(P, c, red, xo, t);
 }
 
 // =========================================================================================================
 // Phase 5: termination test, monotone barrier update, final gradient rows of the condensed system
 // =========================================================================================================
-template <int NX, bool MB = false, int ROLE = ROLE_ALL>
+template <int NX, bool MB = false>
 MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult, int n_z) {
     using D = Dim<NX>;
     if (!c.active) return;
@@ -1925,8 +1886,7 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         double gx[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) gx[i] = c.gxa[i] + mu * c.gxb[i];
-        if (ROLE == ROLE_B) {
-        } else if (MB) {
+        if (MB) {
             const double gu[2] = {c.gua[0] + mu * c.gub[0], c.gua[1] + mu * c.gub[1]};
             ws_store_run<D::B_GX, NX>(MPC_ROWS(MPC_KI(P.MBLK, D::NBLK, 0, e)), gx);
             MPC_ST2(MPC_KI(P.MBLK, D::NBLK, 0, D::B_GU), gu[0], gu[1]);
@@ -1942,8 +1902,8 @@ MPC_HD void phase_finish(const PRef& P, Ctx<NX>& c, const Red3& red, int n_mult,
         }
     }
     c.status = status;
-    if (!MB && ROLE == ROLE_ALL && P.emit && status != ST_RUNNING) emit_result<NX>(P, c, status, c.iters, E0);
-    if (MPC_RA && k == 0) {
+    if (!MB && P.emit && status != ST_RUNNING) emit_result<NX>(P, c, status, c.iters, E0);
+    if (k == 0) {
         MPC_SCW(SC, SC_MU, MU, mu);
         MPC_SCW(SC, SC_TAU, TAU, tau);
         MPC_SCW(SC, SC_THETA, THETA, red.theta);

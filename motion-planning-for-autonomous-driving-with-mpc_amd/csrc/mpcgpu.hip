@@ -231,7 +231,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
     } else {
         phase_load_scalars<NX>(P, c);
         PreTmp<NX> tmp;
-        phase_preload<NX, false, ROLE_ALL, VM>(P, c, tmp);           // every array load of the kernel is in flight before the first wait
+        phase_preload<NX, false, VM>(P, c, tmp);           // every array load of the kernel is in flight before the first wait
         phase_premath<NX>(P, c, tmp);
         MPC_STAMP(1);
         // (launches that write the caller's rows themselves: an instance the Riccati sweep has just given up leaves here -- its iterate is in c.z)
@@ -249,7 +249,7 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         if (!__any(c.active ? 1 : 0)) return;
         MPC_STAMP(2);
         Red1 r1;
-        phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
+        phase_step_candidates<NX, VM>(P, c, r1);
         MPC_STAMP(3);
         block_reduce(r1, bx, lds);
         phase_linesearch_begin<NX>(P, c, r1);
@@ -258,13 +258,13 @@ __device__ __forceinline__ void stage_block(const PRef& P, const int n_mult, con
         if (STASH) stash_xfer<NX, true, VM>(c, stash, blockDim.x, t, has_ou);
         while (__any((c.active && c.searching) ? 1 : 0)) {
             Red2 r2;
-            phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
+            phase_trial_eval<NX, VM>(P, c, r2);
             block_reduce(r2, bx, lds);
             phase_linesearch_decide<NX>(P, c, r2);
         }
         if (STASH) stash_xfer<NX, false, VM>(c, stash, blockDim.x, t, has_ou);
         MPC_STAMP(5);
-        phase_apply_update<NX, false, ROLE_ALL, VM>(P, c);
+        phase_apply_update<NX, false, VM>(P, c);
         MPC_STAMP(6);
     }
     // neighbour-stage exchange through LDS: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate
@@ -343,11 +343,11 @@ __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int
     mid();
     phase_load_scalars<NX, true>(P, c);
     if (io.have) {
-        phase_preload<NX, true, ROLE_ALL, VM, false, true>(P, c, tmp, io.fric);
+        phase_preload<NX, true, VM, false, true>(P, c, tmp, io.fric);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { c.rn[i] = io.rn[t * NX + i]; c.r0[i] = c.k == 0 ? io.r0[c.bl * 8 + i] : 0.0; }
     } else {
-        phase_preload<NX, true, ROLE_ALL, VM, false>(P, c, tmp);
+        phase_preload<NX, true, VM, false>(P, c, tmp);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { io.rn[t * NX + i] = c.rn[i]; if (c.k == 0 && c.valid) io.r0[c.bl * 8 + i] = c.r0[i]; }
         io.fric = __ballot((c.valid && c.k == 0 && c.fric_row) ? 1 : 0) != 0ull;
@@ -361,19 +361,19 @@ __device__ __forceinline__ void wg_stage(const PRef& P, const int ib0, const int
     if (!__any(c.active ? 1 : 0)) return;
     MPC_STAMP(2);
     Red1 r1;
-    phase_step_candidates<NX, ROLE_ALL, VM>(P, c, r1);
+    phase_step_candidates<NX, VM>(P, c, r1);
     MPC_STAMP(3);
     block_reduce(r1, bx, nullptr);
     phase_linesearch_begin<NX>(P, c, r1);
     MPC_STAMP(4);
     while (__any((c.active && c.searching) ? 1 : 0)) {
         Red2 r2;
-        phase_trial_eval<NX, ROLE_ALL, VM>(P, c, r2);
+        phase_trial_eval<NX, VM>(P, c, r2);
         block_reduce(r2, bx, nullptr);
         phase_linesearch_decide<NX, true>(P, c, r2);
     }
     MPC_STAMP(5);
-    phase_apply_update<NX, true, ROLE_ALL, VM>(P, c);
+    phase_apply_update<NX, true, VM>(P, c);
     MPC_STAMP(6);
     {
         // neighbour-stage exchange: thread (k, bl) needs x_{k+1} and lambda_{k+1} of the new iterate -- lane t + bx of this wavefront

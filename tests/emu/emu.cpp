@@ -28,9 +28,7 @@ static void reduce_block(std::vector<R>& part, int bx, int S) {
     }
 }
 
-// SPLIT: two threads per (instance, stage) -- the model thread (ROLE_A) and the barrier thread (ROLE_B) of mpc_stage_math.h, with the
-// hand-over the kernels make through LDS (the inequality rows' contributions B -> A in front of the neighbour exchange) and every reduction taken over both threads of every stage
-template <int NX, bool SPLIT>
+template <int NX>
 static int run(const HostProblem& hp, int B, const double* x0, const double* p, const double* obst, double* x_out,
                int32_t* status, int32_t* iters, double* kkt, double* trace, int trace_rows, int* n_it, int bx_req) {
     const mpc_problem_desc& d = hp.desc;
@@ -50,14 +48,11 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
     }
     const int nblocks = (int)((B + bx - 1) / bx);
     const int nthreads = S * bx;
-    const int R = SPLIT ? 2 : 1;                      // threads per (instance, stage)
-    std::vector<Ctx<NX>> ctx(nthreads), ctb(SPLIT ? nthreads : 0);
-    std::vector<IneqOut<NX>> xk(nthreads);
-    std::vector<KktPart> kp(nthreads);
+    std::vector<Ctx<NX>> ctx(nthreads);
     std::vector<Red0> r0(nthreads);
-    std::vector<Red1> r1(R * nthreads);
-    std::vector<Red2> r2(R * nthreads);
-    std::vector<Red3> r3(R * nthreads);
+    std::vector<Red1> r1(nthreads);
+    std::vector<Red2> r2(nthreads);
+    std::vector<Red3> r3(nthreads);
 
     auto setup1 = [&](std::vector<Ctx<NX>>& cx, int blk) {
         for (int t = 0; t < nthreads; ++t) {
@@ -70,9 +65,7 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
             c.active = false;
         }
     };
-    auto setup = [&](int blk) { setup1(ctx, blk); if (SPLIT) setup1(ctb, blk); };
-    // (the reductions of the pair: thread rows [A stages | B stages], combined per instance column like the GPU's)
-    auto reduce2 = [&](auto& part) { reduce_block(part, bx, R * S); };
+    auto setup = [&](int blk) { setup1(ctx, blk); };
     auto eval_finish = [&](bool reuse) {
         // neighbour-stage exchange (LDS on the GPU): x_{k+1} and lambda_{k+1} at the new iterate
         for (int t = 0; t + bx < nthreads; ++t)
@@ -114,61 +107,21 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
         for (int blk = 0; blk < nblocks; ++blk) {
             setup(blk);
             bool any = false;
-            if (!SPLIT) {
-                for (int t = 0; t < nthreads; ++t) { PreTmp<NX> tmp; phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX>(P, ctx[t], tmp); phase_premath<NX>(P, ctx[t], tmp); any |= ctx[t].active; }
-                if (!any) continue;
-                for (int t = 0; t < nthreads; ++t) phase_step_candidates<NX>(P, ctx[t], r1[t]);
-                reduce_block(r1, bx, S);
-                for (int t = 0; t < nthreads; ++t) phase_linesearch_begin<NX>(P, ctx[t], r1[t]);
-                for (;;) {
-                    bool searching = false;
-                    for (int t = 0; t < nthreads; ++t) searching |= (ctx[t].active && ctx[t].searching);
-                    if (!searching) break;
-                    for (int t = 0; t < nthreads; ++t) phase_trial_eval<NX>(P, ctx[t], r2[t]);
-                    reduce_block(r2, bx, S);
-                    for (int t = 0; t < nthreads; ++t) phase_linesearch_decide<NX>(P, ctx[t], r2[t]);
-                }
-                for (int t = 0; t < nthreads; ++t) phase_apply_update<NX>(P, ctx[t]);
-                eval_finish(true);
-                continue;
-            }
-            // ---- the pair: ctx = model threads (ROLE_A), ctb = inequality threads (ROLE_B); VM: the kernels' compile-time variable mask
-            constexpr uint32_t VM = 0x33u;
-            for (int t = 0; t < nthreads; ++t) {
-                PreTmp<NX> tmp;
-                phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX, false, ROLE_A, VM>(P, ctx[t], tmp); phase_premath<NX, ROLE_A>(P, ctx[t], tmp);
-                phase_load_scalars<NX>(P, ctb[t]); phase_preload<NX, false, ROLE_B, VM>(P, ctb[t], tmp); phase_premath<NX, ROLE_B>(P, ctb[t], tmp);
-                any |= ctx[t].active;
-            }
+            for (int t = 0; t < nthreads; ++t) { PreTmp<NX> tmp; phase_load_scalars<NX>(P, ctx[t]); phase_preload<NX>(P, ctx[t], tmp); phase_premath<NX>(P, ctx[t], tmp); any |= ctx[t].active; }
             if (!any) continue;
-            for (int t = 0; t < nthreads; ++t) { phase_step_candidates<NX, ROLE_A, VM>(P, ctx[t], r1[t]); phase_step_candidates<NX, ROLE_B, VM>(P, ctb[t], r1[nthreads + t]); }
-            reduce2(r1);
-            for (int t = 0; t < nthreads; ++t) { phase_linesearch_begin<NX>(P, ctx[t], r1[t]); phase_linesearch_begin<NX>(P, ctb[t], r1[nthreads + t]); }
+            for (int t = 0; t < nthreads; ++t) phase_step_candidates<NX>(P, ctx[t], r1[t]);
+            reduce_block(r1, bx, S);
+            for (int t = 0; t < nthreads; ++t) phase_linesearch_begin<NX>(P, ctx[t], r1[t]);
             for (;;) {
                 bool searching = false;
                 for (int t = 0; t < nthreads; ++t) searching |= (ctx[t].active && ctx[t].searching);
                 if (!searching) break;
-                for (int t = 0; t < nthreads; ++t) { phase_trial_eval<NX, ROLE_A, VM>(P, ctx[t], r2[t]); phase_trial_eval<NX, ROLE_B, VM>(P, ctb[t], r2[nthreads + t]); }
-                reduce2(r2);
-                for (int t = 0; t < nthreads; ++t) { phase_linesearch_decide<NX>(P, ctx[t], r2[t]); phase_linesearch_decide<NX>(P, ctb[t], r2[nthreads + t]); }
+                for (int t = 0; t < nthreads; ++t) phase_trial_eval<NX>(P, ctx[t], r2[t]);
+                reduce_block(r2, bx, S);
+                for (int t = 0; t < nthreads; ++t) phase_linesearch_decide<NX>(P, ctx[t], r2[t]);
             }
-            for (int t = 0; t < nthreads; ++t) { phase_apply_update<NX, false, ROLE_A, VM>(P, ctx[t]); phase_apply_update<NX, false, ROLE_B, VM>(P, ctb[t]); }
-            // (barrier: the neighbour exchange of the model threads)
-            for (int t = 0; t + bx < nthreads; ++t)
-                for (int i = 0; i < NX; ++i) { ctx[t].xn[i] = ctx[t + bx].z[2 + i]; ctx[t].lamn[i] = ctx[t + bx].lam[i]; }
-            std::vector<EvalTmp<NX>> et(nthreads);
-            const KktPart neutral = kkt_part_neutral();
-            for (int t = 0; t < nthreads; ++t) {
-                phase_eval_model<NX, true, ROLE_A, false, VM>(P, ctx[t], et[t], neutral);
-                phase_ineq_assemble<NX, true, IneqOut<NX>, ROLE_B, VM>(P, ctb[t], xk[t], kp[t], psi_trig(ctb[t].z[2 + 4]));      // B -> A (LDS)
-            }
-            // (barrier)
-            for (int t = 0; t < nthreads; ++t) {
-                phase_eval_finish<NX, false, ROLE_A, IneqOut<NX>, VM>(P, ctx[t], r3[t], xk[t], et[t]);
-                phase_eval_red_b(ctb[t].active, r3[nthreads + t], kp[t]);
-            }
-            reduce2(r3);
-            for (int t = 0; t < nthreads; ++t) { phase_finish<NX, false, ROLE_A>(P, ctx[t], r3[t], hp.n_mult, hp.n_z); phase_finish<NX, false, ROLE_B>(P, ctb[t], r3[nthreads + t], hp.n_mult, hp.n_z); }
+            for (int t = 0; t < nthreads; ++t) phase_apply_update<NX>(P, ctx[t]);
+            eval_finish(true);
         }
         record(it);
     }
@@ -178,7 +131,6 @@ static int run(const HostProblem& hp, int B, const double* x0, const double* p, 
     return MPC_OK;
 }
 
-template <bool SPLIT>
 static int solve_any(const mpc_problem_desc* desc, const double* lbx, const double* ubx, const double* lbg,
                      const double* ubg, int32_t B, const double* x0, const double* p, const double* obst,
                      double* x_out, int32_t* status, int32_t* iters, double* kkt, double* trace,
@@ -190,23 +142,15 @@ static int solve_any(const mpc_problem_desc* desc, const double* lbx, const doub
     if (rc) return rc;
     rc = set_bounds(hp, lbx, ubx, lbg, ubg, err);
     if (rc) return rc;
-    if (desc->nx == 5) return run<5, SPLIT>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
-    return run<6, SPLIT>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
+    if (desc->nx == 5) return run<5>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
+    return run<6>(hp, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
 }
 extern "C" int emu_solve_batch(const mpc_problem_desc* desc, const double* lbx, const double* ubx, const double* lbg,
                                const double* ubg, int32_t B, const double* x0, const double* p, const double* obst,
                                double* x_out, int32_t* status, int32_t* iters, double* kkt, double* trace,
                                int32_t trace_rows, int32_t* n_it, int32_t bx) {
-    return solve_any<false>(desc, lbx, ubx, lbg, ubg, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
+    return solve_any(desc, lbx, ubx, lbg, ubg, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
 }
-// the same solve with two threads per (instance, stage) (ROLE_A / ROLE_B of mpc_stage_math.h)
-extern "C" int emu_solve_batch_split(const mpc_problem_desc* desc, const double* lbx, const double* ubx, const double* lbg,
-                                     const double* ubg, int32_t B, const double* x0, const double* p, const double* obst,
-                                     double* x_out, int32_t* status, int32_t* iters, double* kkt, double* trace,
-                                     int32_t trace_rows, int32_t* n_it, int32_t bx) {
-    return solve_any<true>(desc, lbx, ubx, lbg, ubg, B, x0, p, obst, x_out, status, iters, kkt, trace, trace_rows, n_it, bx);
-}
-
 extern "C" void emu_default_desc(mpc_problem_desc* d, int32_t N, int32_t nx) { default_desc(d, N, nx); }
 
 // closed-loop driver pieces (mpc_closed_loop.h) on host arrays: mode 0 = setup, 1 = advance after step i

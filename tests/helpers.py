@@ -72,8 +72,6 @@ def emu_lib():
         L.emu_solve_batch.argtypes = [C.POINTER(abi.MpcProblemDesc), dp, dp, dp, dp, C.c_int32, dp, dp, dp, dp, ip, ip, dp, dp,
                                       C.c_int32, ip, C.c_int32]
         L.emu_solve_batch.restype = C.c_int
-        L.emu_solve_batch_split.argtypes = L.emu_solve_batch.argtypes
-        L.emu_solve_batch_split.restype = C.c_int
         L.emu_default_desc.argtypes = [C.POINTER(abi.MpcProblemDesc), C.c_int32, C.c_int32]
         L.emu_closed_loop_piece.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             dp, dp, dp, dp, dp, dp, dp, dp, ip, dp, dp, ip, C.c_int32, C.c_int32, C.c_double, C.c_uint64]
@@ -101,8 +99,7 @@ def emu_desc(cfg, fixed_iters=0, max_iter=100):
     return d
 
 
-def emu_solve(cfg, x0, p, bx=0, bounds=None, obst=None, fixed_iters=0, want_rc=False, split=False):
-    """split: two threads per (instance, stage) -- the ROLE_A / ROLE_B instantiation of the stage phases (k_pipeline / k_solve_wg)."""
+def emu_solve(cfg, x0, p, bx=0, bounds=None, obst=None, fixed_iters=0, want_rc=False):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     p = np.ascontiguousarray(p, dtype=np.float64)
     if bounds is None:
@@ -116,7 +113,7 @@ def emu_solve(cfg, x0, p, bx=0, bounds=None, obst=None, fixed_iters=0, want_rc=F
     d = emu_desc(cfg, fixed_iters)
     if obst is not None:
         obst = np.ascontiguousarray(obst, dtype=np.float64)
-    fn = emu_lib().emu_solve_batch_split if split else emu_lib().emu_solve_batch
+    fn = emu_lib().emu_solve_batch
     rc = fn(C.byref(d), abi.as_dp(lbx), abi.as_dp(ubx), abi.as_dp(lbg), abi.as_dp(ubg), B, abi.as_dp(x0),
                                    abi.as_dp(p), abi.as_dp(obst), abi.as_dp(out), abi.as_ip(st), abi.as_ip(it), abi.as_dp(kkt),
                                    abi.as_dp(tr), 101, abi.as_ip(nit), bx)

@@ -104,47 +104,3 @@ def test_trace_matches_oracle_trace():
         assert np.allclose(re["trace"][:n, 4, b], ro["trace"][:n, 4], rtol=1e-9, atol=1e-12)   # alpha_dual
 
 
-_PAIR = pytest.mark.skipif(os.environ.get("MPC_TEST_PAIR", "0") != "1", reason="ROLE_A / ROLE_B only run in a -DMPC_WITH_PAIR=1 build of the kernels (not the default)")
-
-
-@_PAIR
-@pytest.mark.parametrize("fam", list(FAMILIES))
-def test_two_threads_per_stage_match_oracle_and_the_single_thread(fam):
-    """ROLE_A / ROLE_B of the stage phases (the model thread and the barrier thread of an (instance, stage) pair, what k_pipeline and
-    k_solve_wg run): same optimum, same iteration counts as the oracle; against one thread per stage only the order in which the
-    per-stage partial sums of a reduction meet differs"""
-    cfg, kw = FAMILIES[fam]
-    x0, p = synthetic_batch(cfg, 48, **kw)
-    rs = emu_solve(cfg, x0, p, split=True)
-    r1 = emu_solve(cfg, x0, p)
-    ro = OracleSolver(cfg).solve_batch(x0, p)
-    assert np.all(rs["status"] == 1)
-    assert np.array_equal(rs["iters"], ro["iters"])
-    assert np.abs(rs["x"] - ro["x"]).max() < 1e-11
-    assert np.abs(rs["x"] - r1["x"]).max() < 1e-11
-    assert rs["kkt"].max() <= 1e-8
-
-
-@_PAIR
-def test_two_threads_per_stage_on_rows_that_keep_the_friction_row_and_on_collision_avoidance():
-    """the kept stage-0 friction row (a lower slack bound forbids the presolve) is the model thread's business alone; the nonconvex
-    family exercises active circle rows (the slack sides live on the barrier thread, their Jacobians on the model thread)"""
-    cfg, kw = FAMILIES["zamlf_n10_nx5"]
-    x0, p = synthetic_batch(cfg, 24, **kw)
-    lbg, ubg, lbx, ubx = BicycleNLP(cfg).bounds()
-    lbg = lbg.copy()
-    lbg[0] = -1.0                                      # a finite lower bound on the friction row: kept as a row with two slack sides
-    rs = emu_solve(cfg, x0, p, bounds=(lbg, ubg, lbx, ubx), split=True)
-    r1 = emu_solve(cfg, x0, p, bounds=(lbg, ubg, lbx, ubx))
-    assert np.all(rs["status"] == 1) and np.array_equal(rs["iters"], r1["iters"])
-    assert np.abs(rs["x"] - r1["x"]).max() < 1e-10
-    x0, p = ca_batch(CA_CFG, 16)
-    rs = emu_solve(CA_CFG, x0, p, split=True)
-    r1 = emu_solve(CA_CFG, x0, p)
-    both = (rs["status"] == 1) & (r1["status"] == 1)
-    assert both.mean() >= 0.8
-    nlp = BicycleNLP(CA_CFG)
-    for b in np.flatnonzero(rs["status"] == 1):
-        g = nlp.g(rs["x"][b], p[b])
-        lbg_, ubg_, _, _ = nlp.bounds()
-        assert np.all(g >= lbg_ - 1e-6) and np.all(g <= ubg_ + 1e-6)

@@ -37,7 +37,7 @@ def hashes(lib):
     if cur is not None:
         out[cur] = h.hexdigest()[:16]
     names = subprocess.run(["c++filt"], input="\n".join(out), capture_output=True, text=True).stdout.split("\n")
-    return {re.sub(r"\(anonymous namespace\)::|\(.*$", "", n).replace("void ", ""): v for n, v in zip(names, out.values())}
+    return {re.sub(r"\(anonymous namespace\)::|\(.*$", "", n).replace("void ", "").replace(" ", ""): v for n, v in zip(names, out.values())}
 
 
 if __name__ == "__main__":
@@ -50,4 +50,4 @@ if __name__ == "__main__":
         print("kernels whose machine code differs from the reference list:", ", ".join(sorted(changed)) if changed else "none")
     else:
         for k in sorted(hs):
-            print(k.replace(" ", ""), hs[k])
+            print(k, hs[k])
