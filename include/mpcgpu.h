@@ -239,8 +239,10 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  *                        too: the kink of |.| becomes a wall the slack does not cross and a solve can end AT it, depending on the warm start --
  *                        what the reference's recorded ZAM_Over-1_1 run shows at steps 4 and 13 (tests/test_recorded_residuals.py)
  *     "rescue"           0: no second chance for stalled instances (see above)
- *     "rescue_wg"        0: the second chance only behind the launch (rescue_dev); default 1: inside k_solve_wg where the batch runs one instance
- *                        per workgroup -- same levels, same bookkeeping, same bits
+ *     "rescue_wg"        0: the second chance only behind the launch (rescue_dev); 2: inside k_solve_wg wherever the batch runs one instance per
+ *                        workgroup; 1 (default): inside k_solve_wg when the handle's previous solve had stalled instances, else behind the launch
+ *                        -- same levels, same bookkeeping, same bits either way (the kernel with the second chance inside costs a batch that
+ *                        never stalls 6 - 10 %)
  *   which kernels serve the iteration loop (every combination gives the same iteration counts; bits as documented in DESIGN.md section 4)
  *     "pipeline"         0: one launch per kernel and iteration (the path of batches above 8192 instances, horizons above 63 and trace mode, and what
  *                        an abandoned persistent launch falls back to) instead of the single persistent launch k_pipeline

@@ -2528,6 +2528,7 @@ struct mpc_handle {
     bool in_rescue = false;             // rescue_dev is solving its levels: they get no second chance of their own
     bool resc_in_kernel = false;        // the last solve ran k_solve_wg with the second chance inside (RESC) over EVERY instance of the batch: rescue_dev has nothing to add
     bool resc_ran = false;              // ... or at least over the instances the pipeline handed over (what stalled inside the pipeline is rescue_dev's)
+    bool resc_hint = false;             // the last solve of this handle had stalled instances: the next one runs k_solve_wg<.., RESC> (option rescue_wg = 1, the default)
     bool attr_set_fq = false;
     bool attr_set = false;              // dynamic-LDS limits of the kernels raised on this handle's device
     // run-time switches: read from the environment ONCE, at mpc_create (MPCGPU_<NAME>), changed afterwards only through
@@ -3098,7 +3099,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         return std::max(WgLds<NX>::doubles(S, bxw) * sizeof(double), bxw == 1 ? std::max(pre, init) : (size_t)0);
     };
     // the second chance inside the launch (k_solve_wg<.., RESC>): one instance per workgroup, the conditions of rescue_dev
-    const bool resc_cond = kn.rescue && kn.rescue_wg && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
+    // (option rescue_wg: 0 never; 2 always; 1, the default: when the handle's LAST solve had stalled instances -- the kernel with the second chance
+    //  inside carries its restart code at 512 registers and ~1 KB of scratch per thread, which costs a batch that never stalls 6 - 10 %: B = 256 lane
+    //  following 0.405 -> 0.366 ms, N = 50 1.24 -> 1.17 ms; the two give the same bits, so a handle may change between them from solve to solve)
+    const bool resc_cond = kn.rescue && (kn.rescue_wg >= 2 || (kn.rescue_wg == 1 && h->resc_hint)) && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
     auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1; };
     DevTmp t_wtrace;
     unsigned long long* d_wtrace = nullptr;
@@ -3674,6 +3678,8 @@ static int solve_dev(mpc_handle* h, int32_t B, const double* d_x0, const double*
     const int rc = solve_dev_any(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it);
     // (converged mode: the solve has synchronised the stream; a launch of k_solve_wg with the second chance inside has given every stalled
     //  instance its levels already)
+    // (what the next solve of this handle does about stalled instances: see resc_cond)
+    if (rc == MPC_OK && rescue && !h->async_ok) h->resc_hint = h->h_fail[0] != 0u || h->rescued_last > 0;
     if (rc != MPC_OK || !rescue || h->h_fail[0] == 0u || h->resc_in_kernel) return rc;
     double prof_keep[6], pipe_keep[8];
     const int mode_keep = h->last_mode;

@@ -431,7 +431,7 @@ def test_collision_avoidance_batch():
 
 
 def test_second_chance_inside_the_launch_equals_the_one_behind_it():
-    """k_solve_wg<.., RESC> (option rescue_wg, default on; one instance per workgroup) starts the obstacle-radius homotopy of a stalled
+    """k_solve_wg<.., RESC> (option rescue_wg = 2; one instance per workgroup) starts the obstacle-radius homotopy of a stalled
     instance inside the running launch; rescue_dev does the same on the host once the launch is over (sub-batch, one solve per level).
     Same schedule, same warm starts, same arithmetic: every row, status and accumulated iteration count is the same bit for bit, the same
     instances are rescued -- and the result certifies against the NLP alone"""
@@ -441,13 +441,22 @@ def test_second_chance_inside_the_launch_equals_the_one_behind_it():
     s = make_solver(CA_CFG)
     set_cfg_bounds(s, CA_CFG)
     assert s.get_option("rescue_wg") == 1
+    # the default (1) picks by the handle's history: the first solve of a fresh handle gives its stalled instances their second chance behind the
+    # launch, the next one -- the last had stalled instances -- inside it; 2 / 0 pin the choice.  All the same bits.
+    first = s.solve(x0, p)
+    n1 = s.last_rescued()
+    second = s.solve(x0, p)
+    assert s.last_rescued() == n1 and n1 > 0
+    assert np.array_equal(first.x, second.x) and np.array_equal(first.iters, second.iters)
+    s.set_option("rescue_wg", "2")
     a = s.solve(x0, p)
     na = s.last_rescued()
     s.set_option("rescue_wg", "0")
     b = s.solve(x0, p)
     nb = s.last_rescued()
-    assert na == nb and na > 0 and np.all(a.status == 1)
+    assert na == nb == n1 and np.all(a.status == 1)
     assert np.array_equal(a.x, b.x) and np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+    assert np.array_equal(a.x, first.x) and np.array_equal(a.iters, first.iters)
     s.set_option("rescue", "0")
     plain = s.solve(x0, p)
     stalled = np.flatnonzero(plain.status != 1)
@@ -472,6 +481,7 @@ def test_second_chance_paths_agree_when_levels_fail(max_iter):
     x0, p = ca_batch(CA_CFG, B)
     s = make_solver(CA_CFG, max_iter=max_iter)
     set_cfg_bounds(s, CA_CFG)
+    s.set_option("rescue_wg", "2")
     a = s.solve(x0, p)
     na = s.last_rescued()
     s.set_option("rescue_wg", "0")
@@ -505,6 +515,7 @@ def test_second_chance_behind_the_pipeline_with_one_instance_per_wavefront():
     s = make_solver(CA_CFG)
     set_cfg_bounds(s, CA_CFG)
     s.set_option("hybrid_bx", "1")
+    s.set_option("rescue_wg", "2")
     a = s.solve(x0, p)
     na = s.last_rescued()
     assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
