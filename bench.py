@@ -410,6 +410,7 @@ def main():
         ok = bool(torch.equal(gx, d_outs[0]) or torch.equal(gx, d_outs[-1])) and bool(torch.equal(gst, d_st)) and bool(torch.equal(git, d_it))
         gather_info = dict(mode=args.gather, gather_ms_alone=(sharding.max_over_ranks(g_alone, device=dev) if world > 1 else g_alone) * 1e3,
                            bytes_per_rank=B * PW * 8, own_rows_round_trip=ok,
+                           pipeline_abandoned=bool(solver.get_option("pipe_disabled")),     # (a persistent launch starved by the collective's workgroups would show here)
                            wait_ms_in_step=(gather_wait[0] / gather_wait[1] * 1e3) if gather_wait[1] else None)
 
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch

@@ -857,6 +857,34 @@ def test_pipeline_survives_copy_kernels_of_another_stream():
           f"{np.median(t_busy) * 1e3:.3f} ms (x{np.median(t_busy) / t_solo:.2f}, slowest {max(t_busy) * 1e3:.3f} ms); pipeline ran every time, rows bit-identical")
 
 
+def test_rccl_all_gather_of_the_packed_block_beside_the_pipeline():
+    """the same question with RCCL's OWN kernel (the stand-in above uses torch's copy kernels): `MPC_BENCH_FORCE_GATHER=1` sends a single rank
+    of bench.py through the collective code of the multi-GPU path -- an `all_gather_into_tensor` of the 8.1 MB packed block on RCCL's stream
+    under the next solve's persistent launch (`--gather overlap`) and inside the step (`--gather sync`).  No launch may be abandoned, the
+    block that arrives must be the rank's own rows, statuses and iteration counts, and every instance converges as without the collective.
+    (A group of one moves the block with a copy kernel of RCCL's, not over xGMI: what is exercised is the stream / buffer / wait logic of
+    the step and RCCL's workgroups beside the pipeline's, not the links.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("overlap", "sync"):
+        env = dict(os.environ, MPC_BENCH_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29610 + (mode == "sync")))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--headline-only", "--no-cpu-baseline", "--no-traffic", "--steps", "12",
+                            "--warmup", "2", "--gather", mode], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        g = line["gather"]
+        assert g["mode"] == mode and g["own_rows_round_trip"] is True and g["pipeline_abandoned"] is False, g
+        assert g["bytes_per_rank"] == 4096 * (2 * 30 + 6 * 31 + 2) * 8              # rows + status + iterations: 8.13 MB
+        assert line["converged_frac"] == 1.0 and line["value"] > 1e6
+        assert "bounded wait expired" not in r.stderr and "abandon" not in r.stderr.lower().replace("pipeline_abandoned", "")
+        print(f"\n[RCCL all-gather of one rank, --gather {mode}] {line['ms_per_step']:.3f} ms per step, the collective alone {g['gather_ms_alone']:.3f} ms, "
+              f"waited inside a step {g['wait_ms_in_step']}")
+
+
 @pytest.mark.parametrize("friction_lb", ["ipopt", "nlp"])
 def test_gpu_replays_the_friction_row_fixture(golden_dir, friction_lb):
     """the loop that visits the kink of the reference's stage-0 friction row (tests/test_parity_pins.py, closed_loop_n30_friction.npz: N = 30, no
