@@ -41,11 +41,13 @@ def hashes(lib):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
+    ref_path = argv[argv.index("--diff") + 1] if "--diff" in argv else None
+    args = [a for i, a in enumerate(argv) if not a.startswith("--") and not (i and argv[i - 1] == "--diff")]
     lib = args[0] if args else os.path.join(ROOT, "motion-planning-for-autonomous-driving-with-mpc_amd", "csrc", "libmpcgpu.so")
     hs = hashes(lib)
     if "--diff" in sys.argv:
-        ref = dict(l.split() for l in open(sys.argv[sys.argv.index("--diff") + 1]) if l.strip() and not l.startswith("#"))
+        ref = dict(l.split() for l in open(ref_path) if l.strip() and not l.startswith("#"))
         changed = [k for k in hs if ref.get(k) != hs[k]]
         print("kernels whose machine code differs from the reference list:", ", ".join(sorted(changed)) if changed else "none")
     else:
