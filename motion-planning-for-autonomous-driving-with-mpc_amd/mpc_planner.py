@@ -21,11 +21,49 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from . import metrics as _metrics
 from . import scenario as _scenario
 from .optimizer import CasadiOptimizer, ForcesproOptimizer
 
 EGO_SHAPE = SimpleNamespace(length=4.3, width=1.8)          # mpc_planner.py:99
+
+
+# ---- the planner's post-hoc metrics (scope row f4): `plot_deviation_euclidean_dis` (mpc_planner.py:184-199, the array it saves as
+# deviation.txt) and `compute_rmsd` (:279-292, RMSD.txt) without the plotting, the clearance of the 3 x 3 approximation circles the NLP
+# constrains (optimizer.py:395-411) and the collision / road verdict of the reference's test.  `solver`: a BatchedMPCSolver; the arithmetic
+# runs on the device (mpc_metrics_batch / mpc_validity_batch of include/mpcgpu.h), there is no CPU path.
+def deviation_euclidean_dis(solver, x, origin_reference_path):
+    """deviation.txt of mpc_planner.py:184-199 for one trajectory (L,5) or a batch (B,L,5)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = solver.metrics(x, origin_path=origin_reference_path)["deviation"]
+    return out[0] if x.ndim == 2 else out
+
+
+def compute_rmsd(solver, x, reference_path):
+    """(rmsd_x, rmsd_y) of mpc_planner.py:279-292 (divisor L - 1) for one trajectory or a batch."""
+    x = np.asarray(x, dtype=np.float64)
+    out = solver.metrics(x, ref_path=reference_path)["rmsd"]
+    return out[0] if x.ndim == 2 else out
+
+
+def min_clearance(solver, x, r_sum, all_pairs=False):
+    """min over steps and circle pairs of (centre distance - r_sum).  Default: the three pairs (ego circle j, obstacle
+    circle j) the reference constrains (optimizer.py:395-403); all_pairs=True: all nine."""
+    x = np.asarray(x, dtype=np.float64)
+    out = solver.metrics(x, r_sum=r_sum, all_pairs=all_pairs)["clearance"]
+    return out[0] if x.ndim == 2 else out
+
+
+def collision_verdict(solver, x, obstacles=None, left_boundary=None, right_boundary=None, ego_length=4.3, ego_width=1.8):
+    """what test/test_mpc_planner.py:37-47 prints -- does the ego vehicle (mpc_planner.py:99: a 4.3 x 1.8 m rectangle on the planned
+    states) collide with an obstacle of the scenario or with the road boundary? -- for one trajectory (L,5) or a batch (B,L,5).
+    Returns (collides, first_collision_step, leaves_road, first_off_road_step); scenario.obstacle_rectangles / road_corridor build
+    the obstacle rows and boundary polylines from a scenario."""
+    x = np.asarray(x, dtype=np.float64)
+    r = solver.validity(x, obstacles=obstacles, left=left_boundary, right=right_boundary, ego_length=ego_length, ego_width=ego_width)
+    fc, fo = r["first_collision"], r["first_off_road"]
+    if x.ndim == 2:
+        return bool(fc[0] >= 0), int(fc[0]), bool(fo[0] >= 0), int(fo[0])
+    return fc >= 0, fc, fo >= 0, fo
 
 
 class MPCPlanner(object):
@@ -77,8 +115,8 @@ class MPCPlanner(object):
         ego_vehicle = SimpleNamespace(obstacle_shape=EGO_SHAPE, initial_state=initial_state,
                                       prediction=SimpleNamespace(trajectory=trajectory, shape=EGO_SHAPE), obstacle_type="car")
         be = self._backend()
-        deviation = _metrics.deviation_euclidean_dis(be, x, conf.origin_reference_path)
-        rmsd = _metrics.compute_rmsd(be, x, conf.reference_path) if conf.use_case == "lane_following" else None
+        deviation = deviation_euclidean_dis(be, x, conf.origin_reference_path)
+        rmsd = compute_rmsd(be, x, conf.reference_path) if conf.use_case == "lane_following" else None
         self.results = dict(states=x, controls=u, solve_time=solve_time, deviation=deviation, rmsd=rmsd)
         if save_dir is not None:
             os.makedirs(save_dir, exist_ok=True)
@@ -100,7 +138,7 @@ class MPCPlanner(object):
         # the whole scenario, test_mpc_planner.py:40; the lane-following variant of ZAM_Over-1_1 simply has none)
         obst = _scenario.obstacle_rectangles(self.scenario, x.shape[0])
         left, right = _scenario.road_corridor(self.scenario, conf.lanelets_leading_to_goal)
-        return _metrics.collision_verdict(self._backend(), x, obst, left, right, EGO_SHAPE.length, EGO_SHAPE.width)
+        return collision_verdict(self._backend(), x, obst, left, right, EGO_SHAPE.length, EGO_SHAPE.width)
 
 
-__all__ = ["MPCPlanner"]
+__all__ = ["MPCPlanner", "deviation_euclidean_dis", "compute_rmsd", "min_clearance", "collision_verdict"]

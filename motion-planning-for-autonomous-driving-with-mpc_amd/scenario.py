@@ -377,7 +377,7 @@ class Configuration(object):
 
 def obstacle_rectangles(scenario, steps):
     """[n, steps, 5] rows (x, y, length, width, orientation) of every obstacle of the scenario at time steps 0 .. steps-1 -- the
-    input of mpc_validity_batch / metrics.collision_verdict.  Static obstacles repeat their row; a moving obstacle that does not
+    input of mpc_validity_batch / mpc_planner.collision_verdict.  Static obstacles repeat their row; a moving obstacle that does not
     exist at a time step gets length = width = 0 there."""
     rows = []
     for o in scenario.obstacles:
