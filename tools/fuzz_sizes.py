@@ -1,0 +1,52 @@
+"""Random batch sizes and row windows through the default path (start kernel, pipeline, stragglers -- whichever the size selects) against the path
+with one launch per kernel: same statuses, rows to 1e-7 (collision avoidance: 1e-4, see below), every instance converged; the default path twice -> the same bits.  Usage (GPU box): python tools/fuzz_sizes.py [cases=120] [seed=1]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+from helpers import CA_CFG, FAMILIES, ca_batch, make_solver, set_cfg_bounds
+from oracle.nlp_numpy import synthetic_batch
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+POOL = 9000
+pools = {}
+for fam, (cfg, kw) in FAMILIES.items():
+    pools[fam] = (cfg, synthetic_batch(cfg, POOL, **kw))
+pools["ca"] = (CA_CFG, ca_batch(CA_CFG, 3000))
+solvers = {}
+for fam, (cfg, _) in pools.items():
+    a, b = make_solver(cfg), make_solver(cfg)
+    if fam == "ca":
+        set_cfg_bounds(a, cfg); set_cfg_bounds(b, cfg)
+    b.set_option("pipeline", "0"); b.set_option("hybrid", "0")
+    solvers[fam] = (a, b)
+bad = 0
+t0 = time.time()
+names = list(pools)
+sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 255, 257, 511, 1023, 1024, 1025, 2047, 4095, 4097, 8191, 8193]
+for c in range(n):
+    fam = names[c % len(names)]
+    cfg, (X0, P) = pools[fam]
+    cap = X0.shape[0]
+    B = int(sizes[rng.integers(len(sizes))]) if rng.random() < 0.4 else int(rng.integers(1, cap + 1))
+    B = min(B, cap)
+    o = int(rng.integers(0, cap - B + 1))
+    x0, p = np.ascontiguousarray(X0[o:o + B]), np.ascontiguousarray(P[o:o + B])
+    a, b = solvers[fam]
+    r1 = a.solve(x0, p); mode = (a.get_pipeline_profile()["ran"], a.get_resident_profile()["ran"]); resc = a.last_rescued()
+    r2 = a.solve(x0, p)
+    rr = b.solve(x0, p)
+    same = np.array_equal(r1.x, r2.x) and np.array_equal(r1.status, r2.status) and np.array_equal(r1.iters, r2.iters)
+    dx = float(np.abs(r1.x - rr.x).max())
+    st_ok = np.array_equal(r1.status, rr.status)
+    conv = float((r1.status == 1).mean())
+    dit = int(np.abs(r1.iters.astype(int) - rr.iters.astype(int)).max())
+    # (collision avoidance: the two paths' Riccati sweeps round differently -- fp64 matrix pipe in k_solve_wg, scalar FMAs elsewhere --, and at a KKT error
+    #  of 1e-8 the 1e10 ... 1e13 weights of active circle rows pin the rows to 1e-6 ... 1e-5 only, with different iteration counts on the way; the bar
+    #  here is north_star's 1e-4 on the trajectories, the test suite certifies the KKT conditions of such rows against the numpy NLP)
+    n6 = int((np.abs(r1.x - rr.x).max(axis=1) > 1e-6).sum())
+    tol_ok = dx < 1e-7 or (fam == "ca" and dx < 1e-4)
+    ok = same and st_ok and conv == 1.0 and tol_ok
+    if not ok:
+        bad += 1
+    print(f"{'ok ' if ok else 'BAD'} {fam:14s} B={B:5d} off={o:5d} pipeline={int(mode[0])} wg={int(mode[1])} rescued={resc:3d} repeat-bits={same} status-eq={st_ok} conv={conv:.4f} |dx|={dx:.2e} ({n6} rows above 1e-6) |dit|={dit}", flush=True)
+print(f"problems: {bad} of {n} in {time.time() - t0:.0f} s")
