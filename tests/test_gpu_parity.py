@@ -857,6 +857,30 @@ def test_pipeline_survives_copy_kernels_of_another_stream():
           f"{np.median(t_busy) * 1e3:.3f} ms (x{np.median(t_busy) / t_solo:.2f}, slowest {max(t_busy) * 1e3:.3f} ms); pipeline ran every time, rows bit-identical")
 
 
+def test_status_iters_and_kkt_buffers_may_be_null():
+    """include/mpcgpu.h: "status/iters/kkt: [B], any may be NULL" -- the loop kernels write the caller's rows themselves (Params::emit), so the
+    optional outputs are tested where they are written; the second chance needs the statuses and keeps an internal row then.  Rows with and
+    without the optional buffers: the same bits, on the pipeline + stragglers, on the stragglers' kernel alone and on collision avoidance."""
+    import torch
+    cases = [(FAMILIES["zamlf_n30_nx6"][0], synthetic_batch(FAMILIES["zamlf_n30_nx6"][0], 4096), False),
+             (FAMILIES["usalf_n50_nx5"][0], synthetic_batch(FAMILIES["usalf_n50_nx5"][0], 300, **FAMILIES["usalf_n50_nx5"][1]), False),
+             (CA_CFG, ca_batch(CA_CFG, 600), True)]
+    for cfg, (x0, p), ca in cases:
+        s = make_solver(cfg)
+        if ca:
+            set_cfg_bounds(s, cfg)
+        B = x0.shape[0]
+        d0, d1 = torch.from_numpy(x0).cuda(), torch.from_numpy(p).cuda()
+        o1, o2 = torch.zeros_like(d0), torch.zeros_like(d0)
+        st = torch.zeros(B, dtype=torch.int32, device="cuda")
+        for _ in range(2):                                   # (collision avoidance: the second call has the second chance inside the launch)
+            s.solve_device(B, d0.data_ptr(), d1.data_ptr(), o1.data_ptr(), st.data_ptr())
+            n1 = s.last_rescued()
+            s.solve_device(B, d0.data_ptr(), d1.data_ptr(), o2.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2) and bool((st == 1).all()) and s.last_rescued() == n1 and (n1 > 0) == ca
+
+
 def test_rccl_all_gather_of_the_packed_block_beside_the_pipeline():
     """the same question with RCCL's OWN kernel (the stand-in above uses torch's copy kernels): `MPC_BENCH_FORCE_GATHER=1` sends a single rank
     of bench.py through the collective code of the multi-GPU path -- an `all_gather_into_tensor` of the 8.1 MB packed block on RCCL's stream
