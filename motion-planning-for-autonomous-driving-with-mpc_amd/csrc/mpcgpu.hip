@@ -3166,6 +3166,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // that fits the machine one instance per wavefront (4 wavefront slots per CU) is faster that way -- a round of a wavefront with two live
     // instances costs 47 us against 33 us (B = 256: 0.58 -> 0.54 ms).  hybrid_bx = 1 / 2 pins it, 0 chooses.
     int hyb_bx = ((kn.hybrid_bx == 2 || (kn.hybrid_bx == 0 && B > 4 * h->n_cu)) && S * 2 <= 64) ? 2 : 1;
+    // (the levels of the second chance, rescue_dev: always the stragglers' kernel alone with one instance per wavefront -- the configuration the second
+    //  chance INSIDE a launch runs in, whatever the number of stalled instances: the pipeline's sweeps round differently from the matrix-pipe sweeps of
+    //  k_solve_wg, and which of the two paths gave an instance its second chance must not show in its bits)
+    if (h->in_rescue) hyb_bx = 1;
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
     const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
     int hand = 0;
@@ -3177,9 +3181,13 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // its rounds cost an instance 67 us, a straggler round 25 us (tools/hand_sweep.py: 3 - 5 % per batch on four instance sets at B = 4096,
         // B = 3000 / 8192 and N = 50 likewise; above ~50 of 64 the pipeline no longer carries the bulk)
         hand = base >= 64 ? base : std::max(base, std::min(50, base < 32 ? 7 * base / 4 : 3 * base / 2));
+        // ... and with ONE instance per wavefront there (horizons beyond 31 stages) at least 40: a round of the pipeline costs such a tile ~100 us, a
+        // straggler round 30, and the wavefronts beyond the machine's slots start as the first ones retire (tools/hand_sweep.py n50, four instance
+        // sets at B = 4096: 1.17 - 1.21 -> 1.14 - 1.17 ms; B = 5000 / 6000 / 8192: -6 / -10 / -10 %; B = 3000 unchanged)
+        if (hyb_bx == 1 && base < 64 && hand < 40) hand = 40;
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
-    const bool wg_only = hyb_ok && hand >= 64;             // every tile would change over at once: no pipeline launch at all
+    const bool wg_only = hyb_ok && (hand >= 64 || h->in_rescue);             // every tile would change over at once: no pipeline launch at all
     // ---- which path serves the iteration loop (decided before anything is launched: the kernels of the loop write the caller's rows themselves)
     uint32_t xcd_mask = h->xcd_mask;
     if (kn.pipe_xcd_mask) {            // tests: pretend some XCDs away (a partitioned device); workgroups that land there leave

@@ -857,6 +857,30 @@ def test_pipeline_survives_copy_kernels_of_another_stream():
           f"{np.median(t_busy) * 1e3:.3f} ms (x{np.median(t_busy) / t_solo:.2f}, slowest {max(t_busy) * 1e3:.3f} ms); pipeline ran every time, rows bit-identical")
 
 
+def test_second_chance_paths_agree_when_thousands_of_instances_stall():
+    """found by tools/fuzz_sizes.py: with an iteration limit of 6 three quarters of a lane-following batch stop unconverged and take the second
+    chance (the dummy obstacle gives them the levels) -- behind the pipeline at N = 50 some inside the stragglers' launch, most behind it.  The
+    sub-batch of rescue_dev used to go through the pipeline when it was larger than the machine holds one instance per wavefront, whose sweeps
+    round differently from k_solve_wg's: the two paths then differed in the last bits (1e-15) of the instances rescued inside the launch, and so
+    did two consecutive solves of a handle (option rescue_wg = 1 picks by history).  The levels now always run on k_solve_wg alone, one instance
+    per wavefront: rows, statuses and iteration counts are the same bits on rescue_wg = 0 / 2 and from call to call."""
+    cfg, kw = FAMILIES["usalf_n50_nx5"]
+    x0, p = synthetic_batch(cfg, 2724, **kw)
+    res = {}
+    for rw in ("0", "2", "1"):
+        s = make_solver(cfg, max_iter=6)
+        s.set_option("rescue_wg", rw)
+        r1 = s.solve(x0, p)
+        n1 = s.last_rescued()
+        r2 = s.solve(x0, p)
+        assert s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"] and n1 > 1500
+        assert np.array_equal(r1.x, r2.x) and np.array_equal(r1.status, r2.status) and np.array_equal(r1.iters, r2.iters), rw
+        res[rw] = r2
+    for rw in ("2", "1"):
+        assert np.array_equal(res["0"].x, res[rw].x) and np.array_equal(res["0"].status, res[rw].status) and np.array_equal(res["0"].iters, res[rw].iters), rw
+    assert 0.3 < (res["0"].status == 1).mean() < 0.9                  # (what converges within six iterations per attempt and level)
+
+
 def test_status_iters_and_kkt_buffers_may_be_null():
     """include/mpcgpu.h: "status/iters/kkt: [B], any may be NULL" -- the loop kernels write the caller's rows themselves (Params::emit), so the
     optional outputs are tested where they are written; the second chance needs the statuses and keeps an internal row then.  Rows with and
