@@ -35,9 +35,23 @@ for c in range(n):
     x0, p = np.ascontiguousarray(X0[o:o + B]), np.ascontiguousarray(P[o:o + B])
     mi = 100 if (fam == "ca" or rng.random() < 0.7) else int(LIMITS[1 + rng.integers(2)])
     a, b = solvers[fam, mi]
-    r1 = a.solve(x0, p); mode = (a.get_pipeline_profile()["ran"], a.get_resident_profile()["ran"]); resc = a.last_rescued()
-    r2 = a.solve(x0, p)
-    rr = b.solve(x0, p)
+    # options of the default path drawn per case (they pick other kernels, never other results beyond the last bits): instances per wavefront of the
+    # stragglers' kernel, helping Riccati workers, the second chance inside / behind the launch, run-time bound look-up; collision avoidance: the
+    # obstacle handed over per instance (variant 0 of the kernels), moved by up to 0.2 m per instance
+    opts = {}
+    if rng.random() < 0.35:
+        k = ("hybrid_bx", "pipe_help", "rescue_wg", "bound_mask")[rng.integers(4)]
+        opts[k] = {"hybrid_bx": ("1", "2"), "pipe_help": ("0", "1"), "rescue_wg": ("0", "2"), "bound_mask": ("0", "1")}[k][rng.integers(2)]
+    obst = None
+    if fam == "ca" and rng.random() < 0.4:
+        obst = np.tile(cfg.obstacle_centers.ravel(), (B, 1)) + np.repeat(rng.uniform(-0.2, 0.2, (B, 1, 2)), 3, axis=1).reshape(B, 6)
+    for k, v in opts.items():
+        a.set_option(k, v)
+    r1 = a.solve(x0, p, obst=obst); mode = (a.get_pipeline_profile()["ran"], a.get_resident_profile()["ran"]); resc = a.last_rescued()
+    r2 = a.solve(x0, p, obst=obst)
+    for k in opts:
+        a.set_option(k, {"hybrid_bx": "0", "pipe_help": "-1", "rescue_wg": "1", "bound_mask": "1"}[k])
+    rr = b.solve(x0, p, obst=obst)
     same = np.array_equal(r1.x, r2.x) and np.array_equal(r1.status, r2.status) and np.array_equal(r1.iters, r2.iters)
     dx = float(np.abs(r1.x - rr.x).max())
     st_ok = np.array_equal(r1.status, rr.status)
@@ -52,5 +66,5 @@ for c in range(n):
     ok = same and st_ok and (conv == 1.0 or mi < 100) and tol_ok and it_ok
     if not ok:
         bad += 1
-    print(f"{'ok ' if ok else 'BAD'} {fam:14s} max_iter={mi:3d} B={B:5d} off={o:5d} pipeline={int(mode[0])} wg={int(mode[1])} rescued={resc:3d} repeat-bits={same} status-eq={st_ok} conv={conv:.4f} |dx|={dx:.2e} ({n6} rows above 1e-6) |dit|={dit}", flush=True)
+    print(f"{'ok ' if ok else 'BAD'} {fam:14s} max_iter={mi:3d} B={B:5d} off={o:5d} {'obst ' if obst is not None else ''}{' '.join(f'{k}={v}' for k, v in opts.items())} pipeline={int(mode[0])} wg={int(mode[1])} rescued={resc:3d} repeat-bits={same} status-eq={st_ok} conv={conv:.4f} |dx|={dx:.2e} ({n6} rows above 1e-6) |dit|={dit}", flush=True)
 print(f"problems: {bad} of {n} in {time.time() - t0:.0f} s")
