@@ -410,7 +410,7 @@ def main():
         ok = bool(torch.equal(gx, d_outs[0]) or torch.equal(gx, d_outs[-1])) and bool(torch.equal(gst, d_st)) and bool(torch.equal(git, d_it))
         gather_info = dict(mode=args.gather, gather_ms_alone=(sharding.max_over_ranks(g_alone, device=dev) if world > 1 else g_alone) * 1e3,
                            bytes_per_rank=B * PW * 8, own_rows_round_trip=ok,
-                           pipeline_abandoned=bool(solver.get_option("pipe_disabled")),     # (a persistent launch starved by the collective's workgroups would show here)
+                           pipeline_abandoned=bool(solver.get_option("pipe_aborts")),       # (a persistent launch starved by the collective's workgroups would show here)
                            wait_ms_in_step=(gather_wait[0] / gather_wait[1] * 1e3) if gather_wait[1] else None)
 
     # ---- roofline: second pass over the same K steps with HIP events around every kernel launch
@@ -712,7 +712,7 @@ def other_configs(torch, wl, local_rank, dev, stream):
             # (which kernels served the family's last solve -- a pipeline launch that had to be abandoned, e.g. two persistent launches starving each
             #  other, leaves the handle on one launch per kernel for good: that must not go unnoticed)
             paths.append("%s: %s%s" % (d["fam"].name, "+".join((["k_pipeline"] if pp["ran"] else []) + (["k_solve_wg"] if rp["ran"] else [])) or "one launch per kernel",
-                                       " (PIPELINE ABANDONED)" if d["s"].get_option("pipe_disabled") else ""))
+                                       " (PIPELINE ABANDONED %d x)" % d["s"].get_option("pipe_aborts") if d["s"].get_option("pipe_aborts") else ""))
             loop_ms += pp["ms"] + rp["ms"] + pr["riccati_ms"] + pr["stage_ms"]
             loop_bytes += float(d["it"].sum().item()) * ab["b_iter"]
             d["s"].set_profiling(False)

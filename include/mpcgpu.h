@@ -259,6 +259,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  *   host side
  *     "loop_async"       0: closed loop with a host round trip per step
  *     "sync_spin"        0: block in the one synchronisation of a solve instead of polling the stream
+ *   states (mpc_get_option only): "pipe_aborts" persistent launches of this handle that had to be abandoned (each such solve started over with one
+ *                        launch per kernel), "pipe_disabled" 1 once there were three: the handle stays on one launch per kernel
  *   test and measurement aids
  *     "pipe_test_abort"  1: the persistent launch raises its abort word at once (exercises the restart path)
  *     "pipe_xcd_mask"    pretend XCDs away (a partitioned device)

@@ -2495,7 +2495,9 @@ struct mpc_handle {
     size_t pipe_clean[2] = {0, 0};     // leading words of each half known to be zero
     size_t pipe_words = 0;
     uint32_t* h_pipe = nullptr;        // pinned copy of its abort word, round count and statistics (24 words)
-    bool pipe_disabled = false;        // set when a pipeline launch had to be abandoned (see k_pipeline)
+    bool pipe_disabled = false;        // the handle stays on one launch per kernel: three pipeline launches had to be abandoned (see k_pipeline), or the XCD census failed
+    int pipe_aborts = 0;               // pipeline launches of this handle abandoned so far (a solve whose launch is abandoned starts over with one launch per kernel)
+    static constexpr int PIPE_ABORTS_MAX = 3;
     int last_mode = 0;                 // 0: one launch per kernel and iteration, 1: single-launch pipeline (+ k_solve_wg behind it), 2: k_solve_wg alone
     int32_t* d_counter = nullptr;      // [MAX_GROUPS][MAX_POLL_IT] instances still running after iteration it
     int32_t* h_counter = nullptr;      // pinned, [MAX_GROUPS][2] (double-buffered per poll)
@@ -2782,6 +2784,8 @@ int mpc_get_option(const mpc_handle* h, const char* name, int64_t* value) {
     long v = 0;
     // (not a switch, a state: 1 after a pipeline launch of this handle had to be abandoned -- it then stays on one launch per kernel)
     if (std::string(name) == "pipe_disabled") { *value = h->pipe_disabled ? 1 : 0; return MPC_OK; }
+    // (a count: pipeline launches of this handle that had to be abandoned -- their solves started over with one launch per kernel)
+    if (std::string(name) == "pipe_aborts") { *value = h->pipe_aborts; return MPC_OK; }
     const int rc = get_knob(h->knobs, name, &v);
     if (rc == MPC_OK) *value = (int64_t)v;
     return rc;
@@ -3405,7 +3409,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
             }
             if (h->h_pipe[0] != 0u) {
                 // a bounded wait ran out (e.g. the dispatcher left an XCD without stage workers): the workspace is part-way
-                // through an iteration, so start over with one launch per kernel -- and stay there for this handle
+                // through an iteration, so start over with one launch per kernel.  Once may be a transient of the machine's other tenants (the
+                // workgroups of a collective spinning on a slow peer, another handle's persistent launch); the handle stays on that path when it
+                // has happened PIPE_ABORTS_MAX times
                 h->pipe_disabled = true;
                 h->resc_in_kernel = h->resc_ran = false;         // (the k_solve_wg behind the abandoned launch returned at once: no instance has had its second chance)
                 // (abort word: 1 option pipe_test_abort, 2 a Riccati worker waited for its tile's stage items [tile << 16 | round; arrivals], 3 a helping
@@ -3420,7 +3426,9 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
                         fprintf(stderr, "\n");
                     }
                 }
-                return solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
+                const int rc_again = solve_dev_impl<NX>(h, B, d_x0, d_p, d_obst, d_x_out, d_status, d_iters, d_kkt, stream, trace, trace_rows, n_it_out);
+                if (++h->pipe_aborts < mpc_handle::PIPE_ABORTS_MAX) h->pipe_disabled = false;
+                return rc_again;
             }
             P.DBG = nullptr;
             if (d_pdbg) {       // shader-clock stamps of every worker's LAST work item / tile pass
@@ -3824,7 +3832,7 @@ int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp
     // launch, which needs no convergence poll).  What could go wrong on the way -- a pipeline launch abandoned, an instance
     // that needs the second chance -- is recorded on the device and looked at ONCE, at the end; then the loop is replayed
     // step by step with the host in between (the per-kernel path polls for convergence, the second chance needs the count).
-    bool replay = true;
+    bool replay = true, loop_abandoned = false;
     // (a batch beyond the workspace limit is solved in chunks, which the step-by-step form below does)
     if (d.fixed_iters <= 0 && h->knobs.pipeline && !h->pipe_disabled && h->knobs.loop_async && (size_t)B <= max_rows_per_solve(h)) {
         HIP_TRY(h, hipMemsetAsync(h->d_fail, 0, 2 * sizeof(uint32_t), stream));
@@ -3845,6 +3853,7 @@ int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp
             replay = h->h_fail[0] != 0u || h->h_fail[1] != 0u;
             if (h->h_fail[1] != 0u) {
                 h->pipe_disabled = true;
+                loop_abandoned = true;
                 fprintf(stderr, "[mpcgpu] closed loop: a pipeline launch was abandoned (bounded wait expired); replaying the loop with one launch per kernel\n");
             }
         }
@@ -3859,6 +3868,7 @@ int mpc_closed_loop_batch_dev_ex(mpc_handle* h, int32_t B, int32_t L, int32_t Lp
             hipLaunchKernelGGL(k_loop_advance, dim3(B), dim3(128), 0, stream, P, A, i);
         }
     }
+    if (loop_abandoned && ++h->pipe_aborts < mpc_handle::PIPE_ABORTS_MAX) h->pipe_disabled = false;         // (see solve_dev_impl)
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
 }

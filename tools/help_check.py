@@ -21,7 +21,7 @@ for fam, B in (("usalf_n50_nx5", 2500), ("usalf_n50_nx5", 4096), ("zamlf_n30_nx5
             if ref is None: ref = r
             same = np.array_equal(r.x, ref.x) and np.array_equal(r.iters, ref.iters)
             bad += (not same)
-        print(f"{fam} B={B} pipe_help={help_}: {ran} of {reps} solves in the pipeline, abandoned {s.get_option('pipe_disabled')}, same bits {same}", flush=True)
+        print(f"{fam} B={B} pipe_help={help_}: {ran} of {reps} solves in the pipeline, abandoned {s.get_option('pipe_aborts')}, same bits {same}", flush=True)
         bad += ran != reps
 print("problems:", bad)
 sys.exit(1 if bad else 0)
