@@ -509,7 +509,9 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
     if (act_mask == 0ull) return 0ull;                              // all waves see the same 64 instances
     // hybrid solve: a tile with this few instances left is no longer worth a 31-stage pass of a whole wavefront -- it leaves the
     // pipeline untouched, k_solve_wg (one wavefront per instance, MFMA Riccati) finishes its instances behind this launch
-    if (__popcll(act_mask) <= handover_live) return 0ull;
+    // (a threshold per tile -- the same FRACTION of its population: the last tile of a batch that is not a multiple of 64 would otherwise leave at
+    //  once when it holds no more than the count, and its instances would do all their iterations behind the pipeline)
+    if (__popcll(act_mask) * 64 <= handover_live * min(64, P.B - (int)(tile * 64u))) return 0ull;
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = P.rws;

@@ -24,7 +24,7 @@ def code_object(lib):
 def hashes(lib):
     co = code_object(lib)
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", co], check=True, capture_output=True, text=True).stdout
-    out, cur, h = {}, None, None
+    out, cur, h, pcrel = {}, None, None, 0
     for line in dis.split("\n"):
         m = re.match(r"^[0-9a-f]* ?<(\S+)>:$", line.strip())
         if m:
@@ -33,7 +33,17 @@ def hashes(lib):
             cur, h = m.group(1), hashlib.sha256()
             continue
         if cur is not None and line.strip():
-            h.update(re.sub(r"\s+", " ", re.sub(r"<[^>]*>", "", line.strip())).encode())      # (symbolic branch-target annotations dropped; the offsets stay)
+            # (pc-relative addresses of other symbols -- a callee, a table in .rodata --: `s_getpc_b64` followed by `s_add_u32 / s_addc_u32 ..., literal`;
+            #  the literal changes when ANOTHER kernel changes its size, the code does not)
+            if "s_getpc_b64" in line:
+                pcrel = 3
+            elif pcrel > 0:
+                pcrel -= 1
+                if re.search(r"\bs_addc?_u32\b.*0x[0-9a-fA-F]+", line):
+                    line = re.sub(r"0x[0-9a-fA-F]+\s*//.*$", "PCREL", line)
+            # (symbolic branch-target annotations and the instruction's ADDRESS in the trailing comment dropped -- a kernel that merely moved because another
+            #  one changed its size keeps its hash; the encoding words stay, with them every offset and literal)
+            h.update(re.sub(r"\s+", " ", re.sub(r"// [0-9A-Fa-f]+:", "//", re.sub(r"<[^>]*>", "", line.strip()))).encode())
     if cur is not None:
         out[cur] = h.hexdigest()[:16]
     names = subprocess.run(["c++filt"], input="\n".join(out), capture_output=True, text=True).stdout.split("\n")
