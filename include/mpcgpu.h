@@ -248,7 +248,8 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  *                        an abandoned persistent launch falls back to) instead of the single persistent launch k_pipeline
  *     "hybrid"           0: the pipeline runs every tile to its end; default 1: tiles with few instances left go to k_solve_wg
  *     "hybrid_bx"        instances per wavefront of k_solve_wg: 1, 2, or 0 (default) = by batch size
- *     "hybrid_live"      live instances per tile at which a tile changes over (-1, default: from the machine's size; 64: k_solve_wg alone)
+ *     "hybrid_live"      live instances per tile of 64 at which a tile changes over (a smaller last tile: the same fraction; -1, default: from the
+ *                        machine's size; 64: k_solve_wg alone)
  *     "pipe_help"        1 / 0: the Riccati workers of the pipeline take / do not take one published stage item while their tile is with the stage
  *                        workers; -1 (default): where a round has more than three stage items per stage worker (N = 50, B = 8192)
  *     "bound_mask"       0: every bound side looked up at run time (variant 0 of the loop kernels); default 1: the kernels with the bound structure
