@@ -244,7 +244,7 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  *                        -- same levels, same bookkeeping, same bits either way (the kernel with the second chance inside costs a batch that
  *                        never stalls 6 - 10 %)
  *   which kernels serve the iteration loop (every combination gives the same iteration counts; bits as documented in DESIGN.md section 4)
- *     "pipeline"         0: one launch per kernel and iteration (the path of batches above 8192 instances, horizons above 63 and trace mode, and what
+ *     "pipeline"         0: one launch per kernel and iteration (the path of horizons above 63 and trace mode, and what
  *                        an abandoned persistent launch falls back to) instead of the single persistent launch k_pipeline
  *     "hybrid"           0: the pipeline runs every tile to its end; default 1: tiles with few instances left go to k_solve_wg
  *     "hybrid_bx"        instances per wavefront of k_solve_wg: 1, 2, or 0 (default) = by batch size

@@ -511,7 +511,8 @@ __device__ __forceinline__ unsigned long long riccati_tile(const PRef& P, const 
     // pipeline untouched, k_solve_wg (one wavefront per instance, MFMA Riccati) finishes its instances behind this launch
     // (a threshold per tile -- the same FRACTION of its population: the last tile of a batch that is not a multiple of 64 would otherwise leave at
     //  once when it holds no more than the count, and its instances would do all their iterations behind the pipeline)
-    if (__popcll(act_mask) * 64 <= handover_live * min(64, P.B - (int)(tile * 64u))) return 0ull;
+    //  (rounded up: a tile of one to four instances still leaves at once -- it would otherwise keep the whole launch going for its last instance)
+    if (__popcll(act_mask) * 64 < handover_live * min(64, P.B - (int)(tile * 64u)) + 64) return 0ull;
 #define RIC_STAMP(i) do { if (P.DBG && threadIdx.x == 0 && stamp) P.DBG[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     RIC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rsrc = P.rws;
@@ -3203,7 +3204,15 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int n_xcd = __builtin_popcount(xcd_mask);
     const int tiles_x = (ntiles + n_xcd - 1) / n_xcd;
     const int cu_x = std::max(2, h->n_cu / n_xcd);                     // a quarter of an XCD's CUs run Riccati sweeps (8 of 32)
-    const int n_ric = std::min(std::max(1, cu_x / 4), tiles_x);
+    // (nine to twelve tiles per XCD -- batches just above 4096 instances --: every tile its own Riccati worker still; with eight, one worker would own
+    //  two tiles and every round of the XCD would wait for its two passes -- as long as the stage workers that remain are not the scarcer kind:
+    //  at most five stage items per round for each of them.  tools/size_sweep.py, N = 30: B = 4160 ... 6144 -10 ... -4 %; N = 50, sixteen items per
+    //  tile, loses 2 - 11 % with it and keeps eight.)
+    const int n_ric_base = std::max(1, cu_x / 4);
+    // (... and the sweep of a tile is long against its stage items: at N = 10 a worker's second pass hides behind the first tile's stage work,
+    //  and B = 6144 loses 9 % to the four stage workers it gives up)
+    const bool ric_per_tile = tiles_x > n_ric_base && tiles_x <= 3 * cu_x / 8 && (64 / bx) * tiles_x <= 5 * (cu_x - tiles_x) && S >= 24;
+    const int n_ric = std::min(ric_per_tile ? tiles_x : n_ric_base, tiles_x);
     // (threads >= 192: a stage item then covers at least six stages per wavefront and instance column -- the shapes the hand-off timing was measured on)
     const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
                           ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
@@ -3652,9 +3661,20 @@ static int rescue_dev(mpc_handle* h, int32_t B, const double* d_x0, const double
 
 // instances one solve can take: the workspace (tile-major section + mailbox arrays, both linear in the number of tiles) is addressed
 // with 32-bit buffer offsets
+// can a batch of this handle run in the persistent launch at all -- the conditions of solve_dev_impl that do not depend on the batch size
+static bool pipeline_shape(const mpc_handle* h) {
+    const mpc_problem_desc& d = h->hp.desc;
+    const mpc_handle::Knobs& kn = h->knobs;
+    if (4 * (d.N + 1) > 256 || kn.big_wg || !kn.pipeline || h->pipe_disabled || kn.groups > 0 || (kn.timing & TIMING_STAGE) || d.fixed_iters > 0) return false;
+    const int threads = (((d.N + 1) * pick_bx(d.N, 256) + 63) / 64) * 64;
+    return threads >= 192 && threads <= 256;
+}
 static size_t max_rows_per_solve(const mpc_handle* h) {
     const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64, wants_mailbox(h));
     size_t max_b = (((size_t)1 << 32) - 1) / (w1.total * sizeof(double)) * 64;
+    // (the persistent launch takes 128 tiles; beyond that a batch used to fall back to one launch per kernel and iteration -- 43 % more time per
+    //  instance at B = 8193 than at 8192 --: chunks of 8192 through the pipeline instead; B = 12288: 3.05 -> 2.1 ms)
+    if (pipeline_shape(h)) max_b = std::min(max_b, (size_t)8192);
     if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
     return max_b;
 }
