@@ -3192,6 +3192,11 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // straggler round 30, and the wavefronts beyond the machine's slots start as the first ones retire (tools/hand_sweep.py n50, four instance
         // sets at B = 4096: 1.17 - 1.21 -> 1.14 - 1.17 ms; B = 5000 / 6000 / 8192: -6 / -10 / -10 %; B = 3000 unchanged)
         if (hyb_bx == 1 && base < 64 && hand < 40) hand = 40;
+        // A batch somewhat larger than the stragglers' launch holds at once is still faster there alone than through the pipeline -- the wavefronts
+        // beyond the machine's slots start as the first ones retire --: up to 9/8 of the slots with two instances per wavefront (N = 30: B = 2049
+        // 0.75 -> 0.57 ms, 2304 0.74 -> 0.72, 2432 already 0.72 against 0.75), up to 9/4 with one, where a round of the pipeline costs three
+        // straggler rounds (N = 50: B = 1025 0.83 -> 0.54 ms, 1536 0.92 -> 0.77, 2304 0.98 -> 0.92, 2560 equal)
+        if ((size_t)ntiles * 64 * 8 <= (size_t)4 * h->n_cu * hyb_bx * (hyb_bx == 2 ? 9 : 18)) hand = 64;
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
     const bool wg_only = hyb_ok && (hand >= 64 || h->in_rescue);             // every tile would change over at once: no pipeline launch at all

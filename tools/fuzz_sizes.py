@@ -60,11 +60,15 @@ for c in range(n):
     # (collision avoidance: the two paths' Riccati sweeps round differently -- fp64 matrix pipe in k_solve_wg, scalar FMAs elsewhere --, and at a KKT error
     #  of 1e-8 the 1e10 ... 1e13 weights of active circle rows pin the rows to 1e-6 ... 1e-5 only, with different iteration counts on the way; the bar
     #  here is north_star's 1e-4 on the trajectories, the test suite certifies the KKT conditions of such rows against the numpy NLP)
-    n6 = int((np.abs(r1.x - rr.x).max(axis=1) > 1e-6).sum())
-    tol_ok = dx < 1e-7 or (fam == "ca" and dx < 1e-4)
+    rowd = np.abs(r1.x - rr.x).max(axis=1)
+    n6 = int((rowd > 1e-6).sum())
+    # (... and nonconvex: an instance whose cold start runs straight at the obstacle may pass it on the other side on the other path -- both converged
+    #  KKT points, metres apart; with the obstacle moved per instance a few such instances turn up: at most 0.5 % of a batch may differ that way)
+    flips = int((rowd > 1e-2).sum())
+    tol_ok = dx < 1e-7 or (fam == "ca" and float(rowd[rowd <= 1e-2].max(initial=0.0)) < 1e-4 and flips <= max(1, B // 200))
     it_ok = mi == 100 or np.array_equal(r1.iters, rr.iters)          # (a batch cut off by its iteration limit: the same counts on both paths)
     ok = same and st_ok and (conv == 1.0 or mi < 100) and tol_ok and it_ok
     if not ok:
         bad += 1
-    print(f"{'ok ' if ok else 'BAD'} {fam:14s} max_iter={mi:3d} B={B:5d} off={o:5d} {'obst ' if obst is not None else ''}{' '.join(f'{k}={v}' for k, v in opts.items())} pipeline={int(mode[0])} wg={int(mode[1])} rescued={resc:3d} repeat-bits={same} status-eq={st_ok} conv={conv:.4f} |dx|={dx:.2e} ({n6} rows above 1e-6) |dit|={dit}", flush=True)
+    print(f"{'ok ' if ok else 'BAD'} {fam:14s} max_iter={mi:3d} B={B:5d} off={o:5d} {'obst ' if obst is not None else ''}{' '.join(f'{k}={v}' for k, v in opts.items())} pipeline={int(mode[0])} wg={int(mode[1])} rescued={resc:3d} repeat-bits={same} status-eq={st_ok} conv={conv:.4f} |dx|={dx:.2e} ({n6} rows above 1e-6, {flips} on another local optimum) |dit|={dit}", flush=True)
 print(f"problems: {bad} of {n} in {time.time() - t0:.0f} s")
