@@ -1535,6 +1535,7 @@ __device__ __forceinline__ void solve_wg_body(const Params& Pk, const int n_mult
 // so that the host reads it when the stream has drained: no copy command, no kernel of its own behind the loop.  fin_ctl[PIPE_FIN_TICKET] counts the
 // workgroups that have left.
 constexpr uint32_t PIPE_FIN_WORDS = 32, PIPE_FIN_TICKET = 22;
+constexpr int PIPE_MAX_TILES = 256;          // tiles of one persistent launch in converged mode (a Riccati worker owns up to 32: its `fin` mask)
 template <int NX, int VAR, bool RESC = false>
 __global__ void __launch_bounds__(256) k_solve_wg(const Params Pk, const int n_mult, const int n_z, const int stash_rows, uint32_t* stats, const uint32_t* skip_if,
                                                                    const WgRescue resc, unsigned long long* wtrace, const int32_t* list, const uint32_t* list_n) {
@@ -3220,7 +3221,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     const int n_ric = std::min(ric_per_tile ? tiles_x : n_ric_base, tiles_x);
     // (threads >= 192: a stage item then covers at least six stages per wavefront and instance column -- the shapes the hand-off timing was measured on)
     const bool eligible = G == 1 && !trace && !stage_timing && small_wg && threads >= 192 && threads <= 256 &&
-                          ntiles <= (d.fixed_iters > 0 ? 64 : 128) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
+                          ntiles <= (d.fixed_iters > 0 ? 64 : PIPE_MAX_TILES) && (tiles_x + n_ric - 1) / n_ric <= 32 &&
                           std::max(lds_bytes, ric_lds) <= lds_max;
     const bool res_path = wg_only;         // k_solve_wg alone
     const bool pipe_path = !res_path && eligible && !h->pipe_disabled && kn.pipeline;
@@ -3677,9 +3678,10 @@ static bool pipeline_shape(const mpc_handle* h) {
 static size_t max_rows_per_solve(const mpc_handle* h) {
     const WsLayout w1 = ws_layout(h->hp.desc.N, h->hp.desc.nx, 64, wants_mailbox(h));
     size_t max_b = (((size_t)1 << 32) - 1) / (w1.total * sizeof(double)) * 64;
-    // (the persistent launch takes 128 tiles; beyond that a batch used to fall back to one launch per kernel and iteration -- 43 % more time per
-    //  instance at B = 8193 than at 8192 --: chunks of 8192 through the pipeline instead; B = 12288: 3.05 -> 2.1 ms)
-    if (pipeline_shape(h)) max_b = std::min(max_b, (size_t)8192);
+    // (the persistent launch takes PIPE_MAX_TILES tiles -- 128 until the end of round 6, when a batch beyond them fell back to one launch per kernel
+    //  and iteration: 43 % more time per instance at B = 8193 than at 8192; now 256, four tiles per Riccati worker, and chunks of that size beyond:
+    //  B = 8193 2.33 -> 1.37 ms, 12288 3.06 -> 1.96 ms, 16384 2.63 ms; N = 10: 16384 1.0 ms = 16 M instances/s)
+    if (pipeline_shape(h)) max_b = std::min(max_b, (size_t)PIPE_MAX_TILES * 64);
     if (h->knobs.max_batch > 0) max_b = std::min(max_b, (size_t)(h->knobs.max_batch + 63) / 64 * 64);
     return max_b;
 }

@@ -10,7 +10,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 POOL = 9000
 pools = {}
 for fam, (cfg, kw) in FAMILIES.items():
-    pools[fam] = (cfg, synthetic_batch(cfg, POOL, **kw))
+    pools[fam] = (cfg, synthetic_batch(cfg, 17000 if fam in ("zamlf_n30_nx6", "zamlf_n10_nx5") else POOL, **kw))      # (two families beyond one persistent launch's 16384 instances)
 pools["ca"] = (CA_CFG, ca_batch(CA_CFG, 3000))
 solvers = {}
 LIMITS = (100, 6, 9)               # iteration limits: the default, and two at which part of a lane-following batch stops unconverged (status 0)
@@ -24,7 +24,7 @@ for fam, (cfg, _) in pools.items():
 bad = 0
 t0 = time.time()
 names = list(pools)
-sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 255, 257, 511, 1023, 1024, 1025, 2047, 4095, 4097, 8191, 8193]
+sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 255, 257, 511, 1023, 1024, 1025, 2047, 2049, 2305, 4095, 4097, 8191, 8193, 16383, 16385]
 for c in range(n):
     fam = names[c % len(names)]
     cfg, (X0, P) = pools[fam]

@@ -13,7 +13,7 @@ from oracle.nlp_numpy import synthetic_batch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cases = []
-for fam, B in (("zamlf_n30_nx6", 4096), ("zamlf_n30_nx6", 1000), ("zamlf_n30_nx5", 8192), ("usalf_n50_nx5", 2048), ("zamlf_n10_nx5", 3000)):
+for fam, B in (("zamlf_n30_nx6", 4096), ("zamlf_n30_nx6", 1000), ("zamlf_n30_nx5", 8192), ("usalf_n50_nx5", 2048), ("zamlf_n10_nx5", 3000), ("zamlf_n30_nx6", 16384)):
     cfg, kw = FAMILIES[fam]
     x0, p = synthetic_batch(cfg, B, **kw)
     cases.append((fam, make_solver(cfg), x0, p))
