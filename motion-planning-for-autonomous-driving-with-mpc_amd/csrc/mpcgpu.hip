@@ -3177,6 +3177,10 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (the levels of the second chance, rescue_dev: always the stragglers' kernel alone with one instance per wavefront -- the configuration the second
     //  chance INSIDE a launch runs in, whatever the number of stalled instances: the pipeline's sweeps round differently from the matrix-pipe sweeps of
     //  k_solve_wg, and which of the two paths gave an instance its second chance must not show in its bits)
+    // (a handle whose last solve needed second chances: one instance per wavefront also somewhat beyond the machine's slots -- as far as the
+    //  stragglers' kernel serves such a batch alone, below -- so that the kernel with the second chance inside takes it: collision avoidance
+    //  B = 1025 3.49 -> 2.75 ms, B = 2304 6.62 -> 4.79 ms)
+    if (kn.hybrid_bx == 0 && resc_cond && hyb_bx == 2 && (size_t)ntiles * 64 * 8 <= (size_t)4 * h->n_cu * 18) hyb_bx = 1;
     if (h->in_rescue) hyb_bx = 1;
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
     const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
