@@ -243,6 +243,9 @@ int mpc_forces_solve_batch_dev(mpc_handle* h, int32_t B, const double* d_x0, con
  *                        workgroup; 1 (default): inside k_solve_wg when the handle's previous solve had stalled instances, else behind the launch
  *                        -- same levels, same bookkeeping, same bits either way (the kernel with the second chance inside costs a batch that
  *                        never stalls 6 - 10 %)
+ *     "rescue_alone"     1: the caller knows that instances of this handle's batches stall (collision avoidance): batches up to 8192 instances run in
+ *                        k_solve_wg alone, one instance per wavefront, with the second chance inside the launch (B = 4096: 8.3 -> 4.9 ms); an option, not
+ *                        a heuristic, because it changes which Riccati sweeps serve an instance -- the last bits of the rows
  *   which kernels serve the iteration loop (every combination gives the same iteration counts; bits as documented in DESIGN.md section 4)
  *     "pipeline"         0: one launch per kernel and iteration (the path of horizons above 63 and trace mode, and what
  *                        an abandoned persistent launch falls back to) instead of the single persistent launch k_pipeline

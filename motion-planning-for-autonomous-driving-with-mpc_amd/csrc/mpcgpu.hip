@@ -2541,7 +2541,7 @@ struct mpc_handle {
     // mpc_set_option -- no getenv on the solve path
     struct Knobs {
         int pipeline = 1, hybrid = 1, hybrid_bx = 0, hybrid_live = -1, pipe_help = -1, pipe_test_abort = 0;
-        int rescue = 1, rescue_wg = 1, loop_async = 1, sync_spin = 1, max_batch = 0, friction_lb = 0, bound_mask = 1, big_wg = 0, groups = 0, poison = 0;
+        int rescue = 1, rescue_wg = 1, rescue_alone = 0, loop_async = 1, sync_spin = 1, max_batch = 0, friction_lb = 0, bound_mask = 1, big_wg = 0, groups = 0, poison = 0;
         int timing = 0;                 // profiling aids, a sum of TIMING_* (below): shader-clock stamps printed to stderr; each synchronises
         uint32_t pipe_xcd_mask = 0;
     } knobs;
@@ -2576,6 +2576,7 @@ static int set_knob(mpc_handle::Knobs& k, const char* name, const char* value) {
     else if (n == "pipe_xcd_mask") k.pipe_xcd_mask = value == nullptr ? 0u : (uint32_t)strtoul(v, nullptr, 0);
     else if (n == "rescue") k.rescue = on1;
     else if (n == "rescue_wg") k.rescue_wg = value == nullptr ? 1 : (int)iv;
+    else if (n == "rescue_alone") k.rescue_alone = on != 0;
     else if (n == "loop_async") k.loop_async = on1;
     else if (n == "sync_spin") k.sync_spin = on1;
     else if (n == "max_batch") k.max_batch = value == nullptr ? 0 : (int)iv;
@@ -2599,6 +2600,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     else if (n == "pipe_xcd_mask") *out = (long)k.pipe_xcd_mask;
     else if (n == "rescue") *out = k.rescue;
     else if (n == "rescue_wg") *out = k.rescue_wg;
+    else if (n == "rescue_alone") *out = k.rescue_alone;
     else if (n == "loop_async") *out = k.loop_async;
     else if (n == "sync_spin") *out = k.sync_spin;
     else if (n == "max_batch") *out = k.max_batch;
@@ -2612,7 +2614,7 @@ static int get_knob(const mpc_handle::Knobs& k, const char* name, long* out) {
     return MPC_OK;
 }
 static void knobs_from_env(mpc_handle::Knobs& k) {
-    static const char* names[] = {"pipeline", "hybrid", "hybrid_bx", "hybrid_live", "pipe_help", "pipe_test_abort", "pipe_xcd_mask", "rescue", "rescue_wg", "loop_async",
+    static const char* names[] = {"pipeline", "hybrid", "hybrid_bx", "hybrid_live", "pipe_help", "pipe_test_abort", "pipe_xcd_mask", "rescue", "rescue_wg", "rescue_alone", "loop_async",
                                   "sync_spin", "max_batch", "friction_lb", "bound_mask", "big_wg", "groups", "poison", "timing"};
     for (const char* n : names) {
         std::string env = "MPCGPU_";
@@ -3110,7 +3112,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (option rescue_wg: 0 never; 2 always; 1, the default: when the handle's LAST solve had stalled instances -- the kernel with the second chance
     //  inside carries its restart code at 512 registers and ~1 KB of scratch per thread, which costs a batch that never stalls 6 - 10 %: B = 256 lane
     //  following 0.405 -> 0.366 ms, N = 50 1.24 -> 1.17 ms; the two give the same bits, so a handle may change between them from solve to solve)
-    const bool resc_cond = kn.rescue && (kn.rescue_wg >= 2 || (kn.rescue_wg == 1 && h->resc_hint)) && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
+    const bool resc_cond = kn.rescue && (kn.rescue_wg >= 2 || kn.rescue_alone || (kn.rescue_wg == 1 && h->resc_hint)) && d.fixed_iters <= 0 && !trace && h->hp.has_ol && h->hp.ol_raw > 0.0 && !h->in_rescue;
     auto wg_resc = [&](int bxw) { return resc_cond && bxw == 1; };
     DevTmp t_wtrace;
     unsigned long long* d_wtrace = nullptr;
@@ -3177,10 +3179,17 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
     // (the levels of the second chance, rescue_dev: always the stragglers' kernel alone with one instance per wavefront -- the configuration the second
     //  chance INSIDE a launch runs in, whatever the number of stalled instances: the pipeline's sweeps round differently from the matrix-pipe sweeps of
     //  k_solve_wg, and which of the two paths gave an instance its second chance must not show in its bits)
-    // (a handle whose last solve needed second chances: one instance per wavefront also somewhat beyond the machine's slots -- as far as the
-    //  stragglers' kernel serves such a batch alone, below -- so that the kernel with the second chance inside takes it: collision avoidance
-    //  B = 1025 3.49 -> 2.75 ms, B = 2304 6.62 -> 4.79 ms)
+    // A handle whose last solve needed second chances: one instance per wavefront also somewhat beyond the machine's slots -- as far as the stragglers'
+    // kernel serves such a batch alone anyway, below -- so that the kernel with the second chance inside takes it (collision avoidance B = 1025
+    // 3.49 -> 2.83 ms, B = 2304 6.62 -> 4.81 ms; the same bits: an instance's arithmetic in k_solve_wg does not depend on its wavefront's company).
     if (kn.hybrid_bx == 0 && resc_cond && hyb_bx == 2 && (size_t)ntiles * 64 * 8 <= (size_t)4 * h->n_cu * 18) hyb_bx = 1;
+    // Option rescue_alone (the caller knows the family stalls -- collision avoidance: a few instances per thousand, whose chains of 50 + 30 ... 60
+    // iterations are what the batch waits for): the stragglers' kernel ALONE, one instance per wavefront, with the second chance inside, up to 8192
+    // instances -- the bulk of the batch fits beside those chains, while the levels behind a launch cost a synchronised solve each: B = 3072 / 4096
+    // 8.3 -> 4.9 ms, 6144 9.2 -> 7.3, 8192 13.7 -> 12.4 ms.  An option and not the handle's history: it changes which sweeps serve an instance (last
+    // bits), and two consecutive calls of a handle give the same bits.
+    const bool resc_alone = kn.rescue_alone && kn.hybrid_bx == 0 && kn.hybrid_live < 0 && resc_cond && ntiles <= 128;
+    if (resc_alone) hyb_bx = 1;
     if (h->in_rescue) hyb_bx = 1;
     // (not with a fixed iteration count: no instance ever stops iterating, so no tile would ever change over)
     const bool hyb_ok = kn.hybrid && h->ws_mailbox && d.fixed_iters <= 0 && kn.pipeline && !h->pipe_disabled && G == 1 && small_wg && S <= 64 && wg_lds(hyb_bx) <= lds_max / 4 && !trace && !stage_timing;
@@ -3202,6 +3211,7 @@ static int solve_dev_impl(mpc_handle* h, int32_t B, const double* d_x0, const do
         // 0.75 -> 0.57 ms, 2304 0.74 -> 0.72, 2432 already 0.72 against 0.75), up to 9/4 with one, where a round of the pipeline costs three
         // straggler rounds (N = 50: B = 1025 0.83 -> 0.54 ms, 1536 0.92 -> 0.77, 2304 0.98 -> 0.92, 2560 equal)
         if ((size_t)ntiles * 64 * 8 <= (size_t)4 * h->n_cu * hyb_bx * (hyb_bx == 2 ? 9 : 18)) hand = 64;
+        if (resc_alone) hand = 64;
         if (kn.hybrid_live >= 0) hand = std::min(64, kn.hybrid_live);
     }
     const bool wg_only = hyb_ok && (hand >= 64 || h->in_rescue);             // every tile would change over at once: no pipeline launch at all

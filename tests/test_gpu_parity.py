@@ -865,6 +865,29 @@ def test_pipeline_survives_copy_kernels_of_another_stream():
           f"{np.median(t_busy) * 1e3:.3f} ms (x{np.median(t_busy) / t_solo:.2f}, slowest {max(t_busy) * 1e3:.3f} ms); pipeline ran every time, rows bit-identical")
 
 
+def test_option_rescue_alone_for_families_that_stall():
+    """collision-avoidance cold starts beyond the machine's wavefront slots (B = 3000): by default the pipeline takes the batch and the stalled
+    instances get their levels behind the launch; option rescue_alone = 1 keeps the whole batch in k_solve_wg, one instance per wavefront, the
+    second chance inside -- every instance converged on both, the same instances rescued, rows to 1e-4 (other sweeps serve the iterations:
+    ill-conditioned rows differ in the last digits), the KKT error within the tolerance, the same bits from call to call."""
+    B = 3000
+    x0, p = ca_batch(CA_CFG, B)
+    s = make_solver(CA_CFG)
+    set_cfg_bounds(s, CA_CFG)
+    ra = s.solve(x0, p)
+    na = s.last_rescued()
+    assert s.get_pipeline_profile()["ran"] and np.all(ra.status == 1) and na > 20
+    s.set_option("rescue_alone", "1")
+    rb = s.solve(x0, p)
+    nb = s.last_rescued()
+    rc = s.solve(x0, p)
+    assert not s.get_pipeline_profile()["ran"] and s.get_resident_profile()["ran"]
+    assert np.all(rb.status == 1) and rb.kkt.max() <= 1e-8 and nb == na
+    assert np.array_equal(rb.x, rc.x) and np.array_equal(rb.iters, rc.iters)
+    d = np.abs(ra.x - rb.x).max(axis=1)
+    assert (d > 1e-2).sum() <= 3 and d[d <= 1e-2].max() < 1e-4            # (an instance or two may pass the obstacle on the other side)
+
+
 def test_second_chance_paths_agree_when_thousands_of_instances_stall():
     """found by tools/fuzz_sizes.py: with an iteration limit of 6 three quarters of a lane-following batch stop unconverged and take the second
     chance (the dummy obstacle gives them the levels) -- behind the pipeline at N = 50 some inside the stragglers' launch, most behind it.  The
